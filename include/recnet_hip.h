@@ -1,0 +1,212 @@
+/* recnet_hip.h — C ABI of the MI355X (gfx950) RecNet train-step library (librecnet_hip.so).
+ *
+ * The reference (hobincar/reconstruction-network-for-video-captioning) has no FFI layer: its hot
+ * path sits behind Python callables that dispatch to stock PyTorch kernels.  This header is the
+ * boundary a maintainer would bind instead (ctypes stub: INTEGRATION.md).  Every entry point names
+ * the reference interface it replaces.  All pointers are raw DEVICE pointers unless a parameter is
+ * documented "host"; `stream` is a hipStream_t passed as void*; every function only enqueues work
+ * on that stream (no allocation, no synchronisation => hipGraph-capturable) and returns 0 on
+ * success or a negative RECNET_E* code (recnet_last_error() gives the message).
+ *
+ * Tensors are fp32, row-major, with the reference's shapes and state_dict names;
+ * token ids are int64 like the reference's LongTensors.
+ */
+#ifndef RECNET_HIP_H
+#define RECNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RECNET_ABI_VERSION 1
+#define RECNET_OK 0
+#define RECNET_EINVAL (-1)      /* bad dimension / null pointer / unsupported variant */
+#define RECNET_ESTATE (-2)      /* call order violated (e.g. backward before forward) */
+#define RECNET_EHIP (-3)        /* a HIP runtime call failed */
+
+#define RECNET_REC_NONE 0
+#define RECNET_REC_GLOBAL 1     /* models/global_reconstructor.py */
+#define RECNET_REC_LOCAL 2      /* models/local_reconstructor.py  */
+#define RECNET_PREC_F32 0       /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+#define RECNET_PREC_BF16 1      /* bf16 MFMA operands, fp32 accumulate / state / losses */
+
+/* Shapes + hyper-parameters.  Field names follow config.py:27-93 (TrainConfig). */
+typedef struct recnet_config {
+  int32_t batch_size;                 /* B: captions on THIS rank                       config.py:51  */
+  int32_t encoder_output_len;         /* F                                              config.py:63  */
+  int32_t encoder_output_size;        /* D                                              config.py:62  */
+  int32_t embedding_size;             /* E                                              config.py:57  */
+  int32_t decoder_hidden_size;        /* H                                              config.py:67  */
+  int32_t decoder_attn_size;          /* A                                              config.py:68  */
+  int32_t n_vocabs;                   /* V                                              train.py:222  */
+  int32_t reconstructor_hidden_size;  /* R (local reconstructor requires R == D)        config.py:78  */
+  int32_t reconstructor_attn_size;    /* local reconstructor only                       config.py:82  */
+  int32_t caption_max_len;            /* decoder runs <= caption_max_len + 1 steps      config.py:50  */
+  int32_t reconstructor_type;         /* RECNET_REC_*                                   config.py:76  */
+  int32_t precision;                  /* RECNET_PREC_*                                                */
+  int32_t global_batch_size;          /* data parallel: B summed over ranks (== B single GPU)         */
+  int32_t batch_offset;               /* data parallel: global index of this rank's first caption     */
+  int32_t decoder_use_amsgrad, reconstructor_use_amsgrad;       /* config.py:90-91 */
+  float embedding_scale;              /*                                                config.py:59  */
+  float embedding_dropout;            /*                                                config.py:58  */
+  float decoder_out_dropout;          /* dropout applied to the logits, decoder.py:69   config.py:70  */
+  float reconstructor_decoder_dropout;/*                                                config.py:79  */
+  float gradient_clip;                /* <= 0 disables clipping                         config.py:92-93 */
+  float decoder_lambda_reg;           /* train.py:151 (1e-3) */
+  float reconstructor_lambda_reg;     /* train.py:188 (1e-2) */
+  float lambda_recon;                 /* train.py:225 (1.0)  */
+  /* optimiser hyper-parameters are doubles, like the Python floats torch.optim.Adam receives */
+  double decoder_learning_rate, reconstructor_learning_rate;    /* config.py:86-87 */
+  double decoder_weight_decay, reconstructor_weight_decay;      /* config.py:88-89 */
+  double adam_beta1, adam_beta2, adam_eps;                      /* torch.optim.Adam defaults 0.9 / 0.999 / 1e-8 */
+} recnet_config;
+
+/* Decoder parameter set — state_dict keys of models/decoder.py:22-42 (LSTM, 1 layer). */
+typedef struct recnet_decoder_tensors {
+  float* attn_b;           /* [A]          */
+  float* embedding_weight; /* [V, E]       */
+  float* attn_W_weight;    /* [A, H]       */
+  float* attn_U_weight;    /* [A, D]       */
+  float* attn_w_weight;    /* [1, A]       */
+  float* rnn_weight_ih_l0; /* [4H, E + D]  */
+  float* rnn_weight_hh_l0; /* [4H, H]      */
+  float* rnn_bias_ih_l0;   /* [4H]         */
+  float* rnn_bias_hh_l0;   /* [4H]         */
+  float* out_weight;       /* [V, H]       */
+  float* out_bias;         /* [V]          */
+} recnet_decoder_tensors;
+
+/* Reconstructor parameter set — models/global_reconstructor.py:17-28 / local_reconstructor.py:17-35.
+ * attn_* are NULL for the global reconstructor. */
+typedef struct recnet_reconstructor_tensors {
+  float* attn_b;           /* [RA]                              (local) */
+  float* attn_W_weight;    /* [RA, R]                           (local) */
+  float* attn_U_weight;    /* [RA, H]                           (local) */
+  float* attn_w_weight;    /* [1, RA]                           (local) */
+  float* rnn_weight_ih_l0; /* [4R, 2H] global | [4R, H] local           */
+  float* rnn_weight_hh_l0; /* [4R, R]   */
+  float* rnn_bias_ih_l0;   /* [4R]      */
+  float* rnn_bias_hh_l0;   /* [4R]      */
+  float* out_weight;       /* [R, R]    */
+  float* out_bias;         /* [R]       */
+} recnet_reconstructor_tensors;
+
+/* Scalars produced on the device by the forward / optimiser calls (one float each). */
+typedef struct recnet_scalars {
+  float dec_ce;        /* sum_t mean_b CE / sum_t n_t            train.py:56-68  */
+  float dec_reg;       /* sum_p ||p||_2 over decoder tensors     train.py:69     */
+  float dec_loss;      /* dec_ce + lambda_reg * dec_reg          train.py:70     */
+  float rec_mse;       /* MSE term (global: already / T)         train.py:101-102 / :128 */
+  float rec_reg;       /*                                        train.py:103 / :129 */
+  float rec_loss;      /*                                        train.py:104 / :130 */
+  float total_loss;    /* dec_loss + lambda_recon * rec_loss     train.py:260    */
+  float dec_grad_norm; /* total decoder grad norm before clipping, clip_grad_norm_ train.py:270 */
+} recnet_scalars;
+
+typedef struct recnet_handle recnet_handle;
+
+int recnet_abi_version(void);
+const char* recnet_last_error(void);
+
+/* Host-only object describing one (config) problem; owns no device memory. */
+int recnet_create(const recnet_config* cfg, recnet_handle** out);
+void recnet_destroy(recnet_handle* h);
+/* Update the data-parallel placement / learning rates without re-creating (host fields only). */
+int recnet_set_shard(recnet_handle* h, int32_t global_batch_size, int32_t batch_offset);
+
+/* Bytes of device scratch the caller must provide (activations saved for backward, split-K slabs,
+ * packed weights).  Must stay alive and untouched between a forward and its backward. */
+size_t recnet_workspace_bytes(const recnet_handle* h);
+int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes);
+
+/* Parameters, gradients and Adam state.  `grad` tensors are overwritten (not accumulated) by the
+ * backward calls — the reference zero_grad()s before every backward (train.py:265-267).
+ * exp_avg / exp_avg_sq / max_exp_avg_sq mirror torch.optim.Adam's per-parameter state; max_* may be
+ * NULL structs' pointers when amsgrad is off. */
+int recnet_bind_decoder(recnet_handle* h, const recnet_decoder_tensors* param, const recnet_decoder_tensors* grad,
+                        const recnet_decoder_tensors* exp_avg, const recnet_decoder_tensors* exp_avg_sq,
+                        const recnet_decoder_tensors* max_exp_avg_sq);
+int recnet_bind_reconstructor(recnet_handle* h, const recnet_reconstructor_tensors* param,
+                              const recnet_reconstructor_tensors* grad,
+                              const recnet_reconstructor_tensors* exp_avg,
+                              const recnet_reconstructor_tensors* exp_avg_sq,
+                              const recnet_reconstructor_tensors* max_exp_avg_sq);
+
+/* Re-derive the packed (concatenated / bf16) weight images after the fp32 parameters changed
+ * (optimiser step, load_state_dict).  recnet_optimizer_step does this itself. */
+int recnet_pack_weights(recnet_handle* h, void* stream);
+
+/* ---- Decoder.forward, models/decoder.py:45-70: ONE decode step (the API eval.py's greedy / beam
+ * search drive, eval.py:22,48).  tokens [B] int64; h_in/c_in/h_out/c_out [B,H]; enc [B,F,D];
+ * logits [B,V].  `train` != 0 applies the embedding / logits dropout with (seed, t). */
+int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_in, const float* c_in,
+                        const float* enc, float* logits, float* h_out, float* c_out, int32_t train,
+                        uint32_t seed, int32_t t, void* stream);
+
+/* ---- forward_decoder, train.py:17-75 (teacher forcing, train.py:38,45).
+ * enc [B,F,D]; targets [caption_max_len+1, B] int64 (time-major, <PAD>=0, <EOS>=2);
+ * T = number of steps the reference's loop would run (train.py:66), computed by the caller from the
+ * caption lengths (host) — no device sync; step_weight [T] = 1 / (n_t * sum_t n_t) with GLOBAL counts
+ * (SURVEY.md §8e); hiddens_out [T,1,B,H] (may be NULL: they stay in the workspace for the
+ * reconstructor either way); scalars: dec_ce / dec_reg / dec_loss are written. */
+int recnet_forward_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                           const float* step_weight, int32_t train, uint32_t seed, float* hiddens_out,
+                           recnet_scalars* scalars, void* stream);
+
+/* ---- forward_global_reconstructor (train.py:78-105) / forward_local_reconstructor (train.py:108-131),
+ * selected by cfg.reconstructor_type.  Consumes the hidden states left by recnet_forward_decoder
+ * (or `hiddens` [T,1,B,H] when not NULL).  mse_count = GLOBAL element count of the MSE mean
+ * (global: B_global*R, local: B_global*F*D).  Writes rec_mse / rec_reg / rec_loss / total_loss. */
+int recnet_forward_reconstructor(recnet_handle* h, const float* enc, const float* hiddens, int32_t T,
+                                 int32_t train, uint32_t seed, recnet_scalars* scalars, void* stream);
+
+/* ---- loss.backward(), train.py:268, for loss = dec_loss + lambda_recon * rec_loss (train.py:260).
+ * Reconstructor first (produces d loss / d hiddens), then the decoder BPTT.  grad_scale multiplies
+ * the incoming gradient (1.0 in the reference).  The norm-regulariser gradient lambda * p/||p|| is
+ * NOT included here (it is rank-independent; recnet_optimizer_step / recnet_add_reg_grad add it
+ * once, after the data-parallel all-reduce — SURVEY.md §8e). */
+int recnet_backward_reconstructor(recnet_handle* h, const float* enc, float grad_scale, float* dhiddens_out,
+                                  void* stream);
+int recnet_backward_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhiddens,
+                            float grad_scale, void* stream);
+/* grad += lambda_reg * grad_scale * p / ||p||  for every tensor of the model (autograd-compatible path). */
+int recnet_add_reg_grad(recnet_handle* h, int32_t which /*0 decoder, 1 reconstructor*/, float grad_scale,
+                        void* stream);
+
+/* ---- train.py:269-273: clip_grad_norm_(decoder, gradient_clip) + decoder Adam(amsgrad) step +
+ * reconstructor Adam step (torch.optim.Adam semantics, coupled weight decay); then re-packs the
+ * weights.  `step` is the 1-based optimiser step count.  flags: */
+#define RECNET_OPT_REG 1                 /* fold the regulariser gradient lambda * p/||p|| in        */
+#define RECNET_OPT_CLIP 2                /* clip the decoder gradient to cfg.gradient_clip first      */
+#define RECNET_OPT_SKIP_DECODER 4
+#define RECNET_OPT_SKIP_RECONSTRUCTOR 8
+int recnet_optimizer_step(recnet_handle* h, int32_t step, int32_t flags, recnet_scalars* scalars, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (train.py:270) on the bound gradients of one model, in place;
+ * total_norm_out: device float or NULL. */
+int recnet_clip_grad_norm(recnet_handle* h, int32_t which, float max_norm, float* total_norm_out, void* stream);
+
+/* ---- The whole train-step body, train.py:248-273, on one stream: forward decoder, forward
+ * reconstructor, backward, clip, both optimiser steps.  With world size > 1 the caller instead runs
+ * recnet_train_step_fwd_bwd, all-reduces (SUM) the gradient tensors, then recnet_optimizer_step. */
+int recnet_train_step_fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                              const float* step_weight, uint32_t seed, recnet_scalars* scalars, void* stream);
+int recnet_train_step(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                      const float* step_weight, uint32_t seed, int32_t step, recnet_scalars* scalars,
+                      void* stream);
+
+/* ---- plumbing exposed for tests and profiling */
+/* C[M,N] (+)= alpha * op(A) op(B)^T + bias.  a_col / b_col: operand stored with the contraction index
+ * as the ROW index (see csrc/gemm.hpp).  All fp32 device pointers. */
+int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, const float* B, int32_t b_col,
+                int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K,
+                float alpha, int32_t accumulate, int32_t splitk, float* splitk_ws, void* stream);
+/* Name / start / duration of the dominant kernel's launches inside the last train step are measured
+ * by the caller with hipEvents; this returns the algorithmic bytes one recurrent-step launch moves. */
+double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which /*0 decoder,1 reconstructor*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECNET_HIP_H */

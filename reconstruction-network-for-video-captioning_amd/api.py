@@ -1,0 +1,389 @@
+"""Sequence-level entry points with the reference's names and signatures (train.py:17-197) and the
+fused train-step body (train.py:248-273).
+
+  forward_decoder(decoder, encoder_outputs, targets, target_masks, teacher_forcing_ratio)
+      -> (loss, hiddens[T,1,B,H], output_indices)                       train.py:17-75
+  forward_global_reconstructor(decoder_hiddens, encoder_outputs, reconstructor) -> loss   train.py:78-105
+  forward_local_reconstructor(decoder_hiddens, encoder_outputs, reconstructor)  -> loss   train.py:108-131
+  build_decoder(n_vocabs) / build_reconstructor()  -> {'model','loss','optimizer','lambda_reg'}
+                                                                        train.py:134-197
+The returned losses are autograd-connected: `(dec_loss + lambda * rec_loss).backward()` runs the HIP
+backward kernels and leaves the gradients in `param.grad` (views of one flat buffer per model).
+`TrainStep` is the same computation as one stream-ordered launch sequence with the regulariser
+gradient, clipping and both Adam updates fused in — the path bench.py times.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .config import TrainConfig
+from .engine import Engine, FlatState
+from .modules import Decoder, GlobalReconstructor, LocalReconstructor
+
+PAD, SOS, EOS = 0, 1, 2
+
+
+# ----------------------------------------------------------------------------- host-side helpers
+def decode_len(target_masks, caption_max_len=30):
+    """How many decoder steps the reference's loop runs (exit test at train.py:66).
+    target_masks: [caption_max_len+1, B] array-like on the HOST."""
+    m = np.asarray(target_masks).astype(bool)
+    for t in range(caption_max_len + 1):
+        if t == caption_max_len or not m[t + 1].any():
+            return t + 1
+    return caption_max_len + 1
+
+
+def step_weights(target_masks, T):
+    """w[t] = 1 / (n_t * sum_t n_t): the reference's loss is (sum_t mean_{b in mask_t} CE) / (sum_t n_t)
+    (train.py:56-68).  target_masks must cover the GLOBAL batch under data parallelism."""
+    m = np.asarray(target_masks).astype(bool)
+    n_t = m[:T].sum(axis=1).astype(np.float64)
+    N = n_t.sum()
+    if N <= 0 or (n_t <= 0).any():
+        raise ValueError("every executed decoder step needs at least one unmasked caption (n_t >= 1)")
+    return (1.0 / (n_t * N)).astype(np.float32)
+
+
+def _host_masks(targets, target_masks):
+    src = target_masks if target_masks is not None else (targets > PAD)
+    return src.detach().cpu().numpy() if isinstance(src, torch.Tensor) else np.asarray(src)
+
+
+# ----------------------------------------------------------------------------- per-model state
+class ModelState:
+    """fp32 master parameters of one model + flat gradient / Adam-state buffers bound to engines."""
+
+    def __init__(self, model, amsgrad):
+        self.model = model
+        self.amsgrad = bool(amsgrad)
+        self.step = 0
+        self._flat = None
+        self.engines = {}
+
+    def params(self):
+        return {k: v for k, v in self.model.named_parameters()}
+
+    def flat(self):
+        if self._flat is None:
+            P = self.params()
+            dev = next(iter(P.values())).device
+            shapes = {k: tuple(v.shape) for k, v in P.items()}
+            self._flat = {"grad": FlatState(shapes, dev), "exp_avg": FlatState(shapes, dev),
+                          "exp_avg_sq": FlatState(shapes, dev)}
+            if self.amsgrad:
+                self._flat["max_exp_avg_sq"] = FlatState(shapes, dev)
+        return self._flat
+
+    def bind(self, eng, which):
+        fl = self.flat()
+        P = {k: v.data for k, v in self.params().items()}
+        args = (P, fl["grad"].views, fl["exp_avg"].views, fl["exp_avg_sq"].views,
+                fl["max_exp_avg_sq"].views if self.amsgrad else None)
+        (eng.bind_decoder if which == 0 else eng.bind_reconstructor)(*args)
+
+    def publish_grads(self):
+        g = self.flat()["grad"].views
+        for k, p in self.params().items():
+            p.grad = g[k]
+
+
+def _hyper_from(C, model=None):
+    hy = dict(embedding_scale=float(C.embedding_scale), embedding_dropout=C.embedding_dropout,
+              decoder_out_dropout=C.decoder_out_dropout,
+              reconstructor_decoder_dropout=getattr(C, "reconstructor_decoder_dropout", 0.5),
+              decoder_learning_rate=C.decoder_learning_rate,
+              reconstructor_learning_rate=C.reconstructor_learning_rate,
+              decoder_weight_decay=C.decoder_weight_decay, reconstructor_weight_decay=C.reconstructor_weight_decay,
+              decoder_use_amsgrad=C.decoder_use_amsgrad, reconstructor_use_amsgrad=C.reconstructor_use_amsgrad,
+              gradient_clip=C.gradient_clip if C.use_gradient_clip else 0.0,
+              decoder_lambda_reg=getattr(C, "decoder_lambda_reg", 1e-3),
+              reconstructor_lambda_reg=getattr(C, "reconstructor_lambda_reg", 1e-2),
+              lambda_recon=getattr(C, "lambda_recon", 1.0), caption_max_len=C.caption_max_len)
+    return hy
+
+
+def _dims(dec_model, B, F, rec_model=None):
+    d = dec_model.dims(B, F)
+    if rec_model is not None:
+        d["R"] = rec_model.hidden_size
+        if rec_model.kind == "local":
+            d["RA"] = rec_model.attn_size
+    return d
+
+
+# ----------------------------------------------------------------------------- optimiser
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (coupled weight decay, optional AMSGrad — train.py:149,186) executed by
+    the multi-tensor HIP kernel.  `state_dict()` has torch.optim.Adam's layout (step / exp_avg /
+    exp_avg_sq / max_exp_avg_sq per parameter) so checkpoints interchange (train.py:398-420)."""
+
+    def __init__(self, mstate, which, lr, weight_decay=0.0, amsgrad=False, betas=(0.9, 0.999), eps=1e-8,
+                 hyper=None):
+        self._ms, self._which, self._hyper = mstate, which, dict(hyper or {})
+        params = [p for _, p in mstate.model.named_parameters()]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+
+    def _ensure_state(self):
+        fl = self._ms.flat()
+        for k, p in self._ms.model.named_parameters():
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.tensor(float(self._ms.step))
+                st["exp_avg"] = fl["exp_avg"].views[k]
+                st["exp_avg_sq"] = fl["exp_avg_sq"].views[k]
+                if self._ms.amsgrad:
+                    st["max_exp_avg_sq"] = fl["max_exp_avg_sq"].views[k]
+
+    def _engine(self):
+        ms = self._ms
+        if ms.engines:
+            return next(iter(ms.engines.values()))
+        # no forward has run yet: a minimal engine is enough for the optimiser tables
+        m = ms.model
+        if self._which == 0:
+            eng = Engine(m.dims(1, 1), None, m.precision, self._hyper, device=next(m.parameters()).device)
+        else:
+            d = dict(B=1, F=1, D=m.hidden_size, E=4, H=m.decoder_hidden_size, A=4, V=8, R=m.hidden_size,
+                     RA=getattr(m, "attn_size", 0))
+            eng = Engine(d, m.kind, m.precision, self._hyper, device=next(m.parameters()).device)
+        ms.bind(eng, self._which)
+        ms.engines[("opt",)] = eng
+        return eng
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure is not supported")
+        self._ensure_state()
+        g = self.param_groups[0]
+        eng = self._engine()
+        # hyper-parameters may have been edited through param_groups (lr schedules)
+        c = eng.cfg
+        if self._which == 0:
+            c.decoder_learning_rate, c.decoder_weight_decay = float(g["lr"]), float(g["weight_decay"])
+        else:
+            c.reconstructor_learning_rate, c.reconstructor_weight_decay = float(g["lr"]), float(g["weight_decay"])
+        self._ms.step += 1
+        skip = _lib.OPT_SKIP_RECONSTRUCTOR if self._which == 0 else _lib.OPT_SKIP_DECODER
+        eng.optimizer_step(self._ms.step, skip)
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._ms.step))
+
+    def zero_grad(self, set_to_none=True):
+        # every backward overwrites the flat gradient buffer (the reference zero_grad()s before each
+        # backward, train.py:265-267), so dropping the references is all that is needed
+        for p in self.param_groups[0]["params"]:
+            p.grad = None
+
+
+def clip_grad_norm_(model_dict, max_norm):
+    """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) (train.py:270) on the HIP path.
+    Returns the total norm as a device tensor."""
+    ms = model_dict["_state"]
+    eng = next(iter(ms.engines.values()))
+    return eng.clip_grad_norm(0 if isinstance(ms.model, Decoder) else 1, max_norm)
+
+
+# ----------------------------------------------------------------------------- builders
+def build_decoder(n_vocabs, C=TrainConfig):
+    """train.py:134-160."""
+    if C.decoder_model != "LSTM":
+        raise NotImplementedError("decoder_model=%r: the HIP path implements LSTM" % (C.decoder_model,))
+    model = Decoder(model_name=C.decoder_model, n_layers=C.decoder_n_layers, encoder_size=C.encoder_output_size,
+                    embedding_size=C.embedding_size, embedding_scale=C.embedding_scale,
+                    hidden_size=C.decoder_hidden_size, attn_size=C.decoder_attn_size, output_size=n_vocabs,
+                    embedding_dropout=C.embedding_dropout, dropout=C.decoder_dropout,
+                    out_dropout=C.decoder_out_dropout, precision=getattr(C, "precision", "bf16"))
+    model = model.to(C.device)
+    ms = ModelState(model, C.decoder_use_amsgrad)
+    hy = _hyper_from(C)
+    opt = FusedAdam(ms, 0, lr=C.decoder_learning_rate, weight_decay=C.decoder_weight_decay,
+                    amsgrad=C.decoder_use_amsgrad, hyper=hy)
+    return {"model": model, "loss": "masked-cross-entropy (fused, train.py:54-68)", "optimizer": opt,
+            "lambda_reg": hy["decoder_lambda_reg"], "_state": ms, "_hyper": hy, "_C": C}
+
+
+def build_reconstructor(C=TrainConfig):
+    """train.py:163-197."""
+    if C.reconstructor_model != "LSTM":
+        raise NotImplementedError("reconstructor_model=%r: the HIP path implements LSTM" % (C.reconstructor_model,))
+    prec = getattr(C, "precision", "bf16")
+    if C.reconstructor_type == "local":
+        model = LocalReconstructor(model_name=C.reconstructor_model, n_layers=C.reconstructor_n_layers,
+                                   decoder_hidden_size=C.decoder_hidden_size,
+                                   hidden_size=C.reconstructor_hidden_size, dropout=C.reconstructor_dropout,
+                                   decoder_dropout=C.reconstructor_decoder_dropout,
+                                   attn_size=C.reconstructor_attn_size, precision=prec)
+    elif C.reconstructor_type == "global":
+        model = GlobalReconstructor(model_name=C.reconstructor_model, n_layers=C.reconstructor_n_layers,
+                                    decoder_hidden_size=C.decoder_hidden_size,
+                                    hidden_size=C.reconstructor_hidden_size, dropout=C.reconstructor_dropout,
+                                    decoder_dropout=C.reconstructor_decoder_dropout,
+                                    caption_max_len=C.caption_max_len, precision=prec)
+    else:
+        raise NotImplementedError("Unknown reconstructor: {}".format(C.reconstructor_type))
+    model = model.to(C.device)
+    ms = ModelState(model, C.reconstructor_use_amsgrad)
+    hy = _hyper_from(C)
+    opt = FusedAdam(ms, 1, lr=C.reconstructor_learning_rate, weight_decay=C.reconstructor_weight_decay,
+                    amsgrad=C.reconstructor_use_amsgrad, hyper=hy)
+    return {"model": model, "loss": "mse (fused, train.py:101,128)", "optimizer": opt,
+            "lambda_reg": hy["reconstructor_lambda_reg"], "_state": ms, "_hyper": hy, "_C": C}
+
+
+# ----------------------------------------------------------------------------- autograd bridges
+class _DecoderSeq(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, ms, enc, targets, T, stepw, train, seed, *params):
+        hid = eng.forward_decoder(enc, targets, T, stepw, train=train, seed=seed)
+        ctx.eng, ctx.ms, ctx.enc, ctx.targets = eng, ms, enc, targets
+        loss = eng.scalars[2].clone()
+        return loss, hid
+
+    @staticmethod
+    def backward(ctx, dloss, dhid):
+        eng = ctx.eng
+        gs = float(dloss) if dloss is not None else 0.0
+        eng.backward_decoder(ctx.enc, ctx.targets, None if dhid is None else dhid.contiguous(), gs)
+        eng.add_reg_grad(0, gs)
+        ctx.ms.publish_grads()
+        return (None,) * 8 + (None,) * len(ctx.ms.params())
+
+
+class _ReconstructorSeq(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, ms, hiddens, enc, T, train, seed, *params):
+        eng.forward_reconstructor(enc, hiddens, T, train=train, seed=seed)
+        ctx.eng, ctx.ms, ctx.enc = eng, ms, enc
+        return eng.scalars[5].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        eng = ctx.eng
+        gs = float(dloss)
+        dh = eng.backward_reconstructor(ctx.enc, gs)
+        eng.add_reg_grad(1, gs)
+        ctx.ms.publish_grads()
+        return (None, None, dh, None, None, None, None) + (None,) * len(ctx.ms.params())
+
+
+def _engine_for(model_dict, key, factory, which):
+    ms = model_dict["_state"]
+    eng = ms.engines.get(key)
+    if eng is None:
+        eng = factory()
+        ms.bind(eng, which)
+        ms.engines[key] = eng
+    return eng
+
+
+def forward_decoder(decoder, encoder_outputs, targets, target_masks, teacher_forcing_ratio=0., seed=None):
+    """train.py:17-75 (teacher-forced).  Returns (loss, hiddens [T,1,B,H], output_indices)."""
+    if teacher_forcing_ratio < 1.0:
+        raise NotImplementedError("free-running decoding (teacher_forcing_ratio < 1, the validation branch "
+                                  "train.py:46-51) is outside the train-step hot path")
+    model = decoder["model"]
+    B, F = encoder_outputs.shape[0], encoder_outputs.shape[1]
+    masks = _host_masks(targets, target_masks)
+    cml = decoder["_hyper"]["caption_max_len"]
+    T = decode_len(masks, cml)
+    stepw = torch.from_numpy(step_weights(masks, T)).to(encoder_outputs.device)
+    eng = _engine_for(decoder, ("dec", B, F), lambda: Engine(_dims(model, B, F), None, model.precision,
+                                                             decoder["_hyper"], device=encoder_outputs.device), 0)
+    eng.pack_weights()
+    seed = decoder["_C"].dropout_seed + decoder["_state"].step if seed is None else seed
+    decoder["_last_seed"] = seed
+    loss, hid = _DecoderSeq.apply(eng, decoder["_state"], encoder_outputs.contiguous(), targets.contiguous(), T,
+                                  stepw, model.training, seed, *decoder["_state"].params().values())
+    return loss, hid, torch.zeros(0, dtype=torch.long)
+
+
+def _forward_reconstructor(kind, decoder_hiddens, encoder_outputs, reconstructor, seed=None):
+    model = reconstructor["model"]
+    if model.kind != kind:
+        raise ValueError("reconstructor is %s, not %s" % (model.kind, kind))
+    T, _, B, H = decoder_hiddens.shape
+    F = encoder_outputs.shape[1]
+    d = dict(B=B, F=F, D=encoder_outputs.shape[2], E=4, H=H, A=4, V=8, R=model.hidden_size,
+             RA=getattr(model, "attn_size", 0))
+    eng = _engine_for(reconstructor, ("rec", B, F), lambda: Engine(d, kind, model.precision, reconstructor["_hyper"],
+                                                                   device=encoder_outputs.device), 1)
+    eng.pack_weights()
+    seed = reconstructor["_C"].dropout_seed + reconstructor["_state"].step if seed is None else seed
+    return _ReconstructorSeq.apply(eng, reconstructor["_state"], decoder_hiddens.contiguous(),
+                                   encoder_outputs.contiguous(), T, model.training, seed,
+                                   *reconstructor["_state"].params().values())
+
+
+def forward_global_reconstructor(decoder_hiddens, encoder_outputs, reconstructor, seed=None):
+    """train.py:78-105."""
+    return _forward_reconstructor("global", decoder_hiddens, encoder_outputs, reconstructor, seed)
+
+
+def forward_local_reconstructor(decoder_hiddens, encoder_outputs, reconstructor, seed=None):
+    """train.py:108-131."""
+    return _forward_reconstructor("local", decoder_hiddens, encoder_outputs, reconstructor, seed)
+
+
+# ----------------------------------------------------------------------------- fused train step
+class TrainStep:
+    """The train-step body train.py:248-273 as one launch sequence on the current stream:
+    forward decoder, forward reconstructor, backward (reconstructor then decoder BPTT), regulariser
+    gradient, decoder clip, AMSGrad / Adam updates, weight re-pack.  `scalars` (device, 8 floats) holds the
+    losses (names: _lib.SCALAR_NAMES); reading them is the only host synchronisation and is up to the
+    caller (the reference syncs three times per step, train.py:275-277)."""
+
+    def __init__(self, decoder, reconstructor=None, batch_size=None, n_frames=None, global_batch=None,
+                 batch_offset=0):
+        C = decoder["_C"]
+        self.decoder, self.reconstructor = decoder, reconstructor
+        dm = decoder["model"]
+        rm = reconstructor["model"] if reconstructor else None
+        B = batch_size or C.batch_size
+        F = n_frames or C.encoder_output_len
+        self.B, self.F = B, F
+        dev = next(dm.parameters()).device
+        hy = dict(decoder["_hyper"])
+        self.engine = Engine(_dims(dm, B, F, rm), rm.kind if rm else None, dm.precision, hy, device=dev,
+                             global_batch=global_batch or B, batch_offset=batch_offset)
+        decoder["_state"].bind(self.engine, 0)
+        decoder["_state"].engines[("step", B, F)] = self.engine
+        if reconstructor:
+            reconstructor["_state"].bind(self.engine, 1)
+            reconstructor["_state"].engines[("step", B, F)] = self.engine
+        self.engine.pack_weights()
+        self.seed_base = C.dropout_seed
+        self.caption_max_len = C.caption_max_len
+
+    @property
+    def scalars(self):
+        return self.engine.scalars
+
+    def prepare(self, targets_host):
+        """Host-side, from the batch's (global) targets: (T, step weights as a device tensor)."""
+        masks = np.asarray(targets_host) > PAD
+        T = decode_len(masks, self.caption_max_len)
+        w = torch.from_numpy(step_weights(masks, T)).to(self.engine.device)
+        return T, w
+
+    def fwd_bwd(self, enc, targets, T, step_weight, seed=None):
+        ms = self.decoder["_state"]
+        seed = self.seed_base + ms.step if seed is None else seed
+        self.engine.train_step_fwd_bwd(enc, targets, T, step_weight, seed)
+
+    def optimizer_step(self):
+        ms = self.decoder["_state"]
+        ms.step += 1
+        if self.reconstructor:
+            self.reconstructor["_state"].step = ms.step
+        self.engine.optimizer_step(ms.step, _lib.OPT_REG | _lib.OPT_CLIP)
+
+    def __call__(self, enc, targets, T, step_weight, seed=None):
+        ms = self.decoder["_state"]
+        seed = self.seed_base + ms.step if seed is None else seed
+        ms.step += 1
+        if self.reconstructor:
+            self.reconstructor["_state"].step = ms.step
+        self.engine.train_step(enc, targets, T, step_weight, seed, ms.step)
+        return self.engine.scalars

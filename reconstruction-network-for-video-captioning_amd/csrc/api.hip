@@ -1,0 +1,868 @@
+// librecnet_hip.so — C ABI + host-side launch sequencing of the RecNet train step (include/recnet_hip.h).
+//
+// Sequence-level design: loop-invariant products are hoisted into batched MFMA GEMMs
+// (Uv = enc.U^T, Xe = emb.W_e^T, logits, reconstructor input projection, every dW), only the
+// h-recurrences run step by step, each step = one split-K MFMA GEMM over the packed recurrent weights
+// + one fused per-caption kernel (LSTM gates + attention).  No allocation, no host synchronisation:
+// every hot-path entry point only enqueues on the caller's stream.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/recnet_hip.h"
+#include "kernels.hpp"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(RECNET_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define LAUNCH_OK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(RECNET_EHIP, std::string(__func__) + ": " + hipGetErrorString(e_)); } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int ew_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+struct OptGroup {
+  std::vector<TensorDesc> tab;      // host copy
+  std::vector<int2> chunks;
+  TensorDesc* d_tab = nullptr; int2* d_chunks = nullptr;
+  float* d_partial = nullptr; float* d_pnorm = nullptr; float* d_gnorm = nullptr;
+  int ntens = 0, nchunks = 0;
+  bool bound = false;
+};
+
+struct recnet_handle {
+  recnet_config c;
+  int B, F, D, E, H, A, V, R, RA, Tm, kind, prec, cml;
+  // workspace
+  char* ws = nullptr; size_t ws_bytes = 0; size_t need = 0;
+  // ---- carved regions
+  uint32_t* ctrl;        // [0] seed slot, [1] step slot (int32)
+  float* scal;           // internal scalars: [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
+  float *bsum_d, *Uv, *emb, *Xe, *Xcat, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws;
+  float *dG, *dHs, *dc_carry, *dWh, *dUv, *dwacc, *demb, *stepw;
+  void* Wch;             // packed [4H][D+H] (bf16 or f32)
+  // reconstructor
+  float *bsum_r, *mp, *mpd, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dGr, *dmpd, *dmp, *dcr_carry, *msep;
+  float *dHsrec;
+  float *Ud, *Xcat_r, *beta, *Whr, *outl, *dHr, *dUd, *dWhr, *dwacc_r;
+  void* Wihh;            // packed [4R][H+R]
+  size_t gws_floats, slab_floats;
+  // bindings
+  recnet_decoder_tensors dP{}, dGd{}, dM{}, dV{}, dVm{};
+  recnet_reconstructor_tensors rP{}, rG{}, rM{}, rV{}, rVm{};
+  bool dec_bound = false, rec_bound = false;
+  OptGroup og[2];
+  // state between forward and backward
+  int T_last = 0, train_last = 0, fwd_dec_done = 0, fwd_rec_done = 0, rec_bwd_done = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+static size_t carve(recnet_handle* h, char* base) {
+  size_t off = 0;
+  auto take = [&](size_t nfloats) -> float* {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += ((nfloats * 4 + 255) / 256) * 256;
+    return p;
+  };
+  const size_t B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, R = h->R, RA = h->RA, Tm = h->Tm;
+  h->ctrl = (uint32_t*)take(64);
+  h->scal = take(64);
+  h->stepw = take(Tm);
+  h->bsum_d = take(4 * H);
+  h->Uv = take(B * F * A);
+  h->emb = take(Tm * B * E);
+  h->Xe = take(Tm * B * 4 * H);
+  h->Xcat = take(Tm * B * (D + H));
+  h->Hs = take(Tm * B * H);
+  h->Cs = take(Tm * B * H);
+  h->acts = take(Tm * B * 4 * H);
+  h->Wh = take(Tm * B * A);
+  h->att = take(Tm * B * F);
+  h->logits = take(Tm * B * V);
+  h->rowloss = take(Tm * B);
+  h->dG = take(Tm * B * 4 * H);
+  h->dHs = take(Tm * B * H);
+  h->dHsrec = take(Tm * B * H);
+  h->dc_carry = take(B * H);
+  h->dWh = take(Tm * B * A);
+  h->dUv = take(B * F * A);
+  h->dwacc = take(B * A);
+  h->demb = take(Tm * B * E);
+  h->Wch = take(4 * H * (D + H));
+  size_t maxN = 4 * H;
+  if (D + H > maxN) maxN = D + H;
+  if (h->kind != RECNET_REC_NONE) {
+    if (4 * R > maxN) maxN = 4 * R;
+    if (H + R > maxN) maxN = H + R;
+  }
+  h->slab_floats = 32 * B * maxN;
+  h->slab = take(h->slab_floats);
+  h->gws_floats = (size_t)16 << 20;   // 64 MiB of split-K slabs for the batched GEMMs
+  h->gws = take(h->gws_floats);
+  h->msep = take(1024);
+  if (h->kind == RECNET_REC_GLOBAL) {
+    h->bsum_r = take(4 * R);
+    h->mp = take(B * H); h->mpd = take(Tm * B * H); h->Xg = take(Tm * B * 4 * R);
+    h->Hr = take(Tm * B * R); h->Cr = take(Tm * B * R); h->acts_r = take(Tm * B * 4 * R);
+    h->hrmean = take(B * R); h->outm = take(B * R); h->encmean = take(B * R); h->dhrmean = take(B * R);
+    h->dGr = take(Tm * B * 4 * R); h->dmpd = take(Tm * B * H); h->dmp = take(B * H); h->dcr_carry = take(B * R);
+  } else if (h->kind == RECNET_REC_LOCAL) {
+    h->Ud = take(Tm * B * RA); h->Xcat_r = take(F * B * (H + R));
+    h->Hr = take(F * B * R); h->Cr = take(F * B * R); h->acts_r = take(F * B * 4 * R);
+    h->beta = take(F * B * Tm); h->Whr = take(F * B * RA); h->outl = take(F * B * R); h->dHr = take(F * B * R);
+    h->dGr = take(F * B * 4 * R); h->dUd = take(Tm * B * RA); h->dWhr = take(F * B * RA); h->dwacc_r = take(B * RA);
+    h->dcr_carry = take(B * R);
+    h->Wihh = take(4 * R * (H + R));
+  }
+  // optimiser tables (sizes are upper bounds; filled at bind time)
+  for (int g = 0; g < 2; ++g) {
+    OptGroup& o = h->og[g];
+    size_t nparams = g == 0 ? (V * E + A * H + A * D + 2 * A + 4 * H * (E + D) + 4 * H * H + 8 * H + V * H + V)
+                            : (RA * R + RA * H + 2 * RA + 4 * R * 2 * H + 4 * R * R + 8 * R + R * R + R);
+    size_t maxch = nparams / RN_CHUNK + 16;
+    o.d_tab = (TensorDesc*)take(16 * sizeof(TensorDesc) / 4);
+    o.d_chunks = (int2*)take(maxch * 2);
+    o.d_partial = take(maxch);
+    o.d_pnorm = take(16);
+    o.d_gnorm = take(16);
+  }
+  return off;
+}
+
+static DropDesc mkdrop(const recnet_handle* h, uint32_t site, float p, int train) {
+  DropDesc d;
+  d.seed = h->ctrl; d.site = site;
+  d.thr = train ? rn_drop_thr(p) : 0u;
+  d.inv_keep = (p < 1.f) ? 1.0f / (1.0f - p) : 0.f;
+  d.Bg = h->c.global_batch_size; d.boff = h->c.batch_offset;
+  return d;
+}
+
+extern "C" {
+
+int recnet_abi_version(void) { return RECNET_ABI_VERSION; }
+const char* recnet_last_error(void) { return g_err.c_str(); }
+
+int recnet_create(const recnet_config* cfg, recnet_handle** out) {
+  if (!cfg || !out) return fail(RECNET_EINVAL, "null argument");
+  const recnet_config& c = *cfg;
+  if (c.batch_size <= 0 || c.encoder_output_len <= 0 || c.encoder_output_size <= 0 || c.embedding_size <= 0 ||
+      c.decoder_hidden_size <= 0 || c.decoder_attn_size <= 0 || c.n_vocabs <= 3 || c.caption_max_len <= 0)
+    return fail(RECNET_EINVAL, "non-positive dimension");
+  if (c.reconstructor_type < 0 || c.reconstructor_type > 2) return fail(RECNET_EINVAL, "unknown reconstructor_type");
+  if (c.precision != RECNET_PREC_F32 && c.precision != RECNET_PREC_BF16) return fail(RECNET_EINVAL, "unknown precision");
+  if (c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_hidden_size <= 0)
+    return fail(RECNET_EINVAL, "reconstructor_hidden_size");
+  if (c.reconstructor_type == RECNET_REC_LOCAL && c.reconstructor_hidden_size != c.encoder_output_size)
+    return fail(RECNET_EINVAL, "local reconstructor requires reconstructor_hidden_size == encoder_output_size (train.py:128)");
+  if (c.reconstructor_type == RECNET_REC_GLOBAL && c.reconstructor_hidden_size != c.encoder_output_size)
+    return fail(RECNET_EINVAL, "global reconstructor requires reconstructor_hidden_size == encoder_output_size (train.py:101)");
+  if (c.reconstructor_type == RECNET_REC_LOCAL && c.reconstructor_attn_size <= 0)
+    return fail(RECNET_EINVAL, "reconstructor_attn_size");
+  recnet_handle* h = new recnet_handle();
+  h->c = c;
+  if (h->c.global_batch_size <= 0) h->c.global_batch_size = c.batch_size;
+  h->B = c.batch_size; h->F = c.encoder_output_len; h->D = c.encoder_output_size; h->E = c.embedding_size;
+  h->H = c.decoder_hidden_size; h->A = c.decoder_attn_size; h->V = c.n_vocabs;
+  h->R = c.reconstructor_type ? c.reconstructor_hidden_size : 0;
+  h->RA = c.reconstructor_type == RECNET_REC_LOCAL ? c.reconstructor_attn_size : 0;
+  h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
+  h->kind = c.reconstructor_type; h->prec = c.precision;
+  h->need = carve(h, nullptr);
+  *out = h;
+  return RECNET_OK;
+}
+
+void recnet_destroy(recnet_handle* h) { delete h; }
+
+int recnet_set_shard(recnet_handle* h, int32_t global_batch_size, int32_t batch_offset) {
+  if (!h || global_batch_size < h->B || batch_offset < 0) return fail(RECNET_EINVAL, "bad shard");
+  h->c.global_batch_size = global_batch_size; h->c.batch_offset = batch_offset;
+  return RECNET_OK;
+}
+
+size_t recnet_workspace_bytes(const recnet_handle* h) { return h ? h->need : 0; }
+
+static int upload_tables(recnet_handle* h, int g) {
+  OptGroup& o = h->og[g];
+  if (!o.bound || !h->ws) return RECNET_OK;
+  HIPCHK(hipMemcpy(o.d_tab, o.tab.data(), o.tab.size() * sizeof(TensorDesc), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(o.d_chunks, o.chunks.data(), o.chunks.size() * sizeof(int2), hipMemcpyHostToDevice));
+  return RECNET_OK;
+}
+
+int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
+  if (!h || !workspace) return fail(RECNET_EINVAL, "null argument");
+  if (bytes < h->need) return fail(RECNET_EINVAL, "workspace too small");
+  if (((uintptr_t)workspace) % 256) return fail(RECNET_EINVAL, "workspace must be 256-byte aligned");
+  h->ws = (char*)workspace; h->ws_bytes = bytes;
+  carve(h, h->ws);
+  h->fwd_dec_done = h->fwd_rec_done = h->rec_bwd_done = 0;
+  int r = upload_tables(h, 0); if (r) return r;
+  return upload_tables(h, 1);
+}
+
+static void build_group(OptGroup& o, const std::vector<float*>& p, const std::vector<float*>& g,
+                        const std::vector<float*>& m, const std::vector<float*>& v, const std::vector<float*>& vm,
+                        const std::vector<size_t>& n) {
+  o.tab.clear(); o.chunks.clear();
+  for (size_t i = 0; i < p.size(); ++i) {
+    TensorDesc td;
+    td.p = p[i]; td.g = g[i]; td.m = m.empty() ? nullptr : m[i]; td.v = v.empty() ? nullptr : v[i];
+    td.vmax = vm.empty() ? nullptr : vm[i];
+    td.n = (int)n[i]; td.chunk0 = (int)o.chunks.size(); td.pad = 0;
+    int nc = 0;
+    for (size_t off = 0; off < n[i]; off += RN_CHUNK) { o.chunks.push_back(make_int2((int)i, (int)off)); ++nc; }
+    td.nchunks = nc;
+    o.tab.push_back(td);
+  }
+  o.ntens = (int)p.size(); o.nchunks = (int)o.chunks.size(); o.bound = true;
+}
+
+static std::vector<float*> dec_list(const recnet_decoder_tensors* t) {
+  if (!t) return {};
+  return {t->attn_b, t->embedding_weight, t->attn_W_weight, t->attn_U_weight, t->attn_w_weight, t->rnn_weight_ih_l0,
+          t->rnn_weight_hh_l0, t->rnn_bias_ih_l0, t->rnn_bias_hh_l0, t->out_weight, t->out_bias};
+}
+static std::vector<float*> rec_list(const recnet_reconstructor_tensors* t, bool local) {
+  if (!t) return {};
+  std::vector<float*> v;
+  if (local) { v.push_back(t->attn_b); v.push_back(t->attn_W_weight); v.push_back(t->attn_U_weight); v.push_back(t->attn_w_weight); }
+  v.push_back(t->rnn_weight_ih_l0); v.push_back(t->rnn_weight_hh_l0); v.push_back(t->rnn_bias_ih_l0);
+  v.push_back(t->rnn_bias_hh_l0); v.push_back(t->out_weight); v.push_back(t->out_bias);
+  return v;
+}
+static bool any_null(const std::vector<float*>& v) { for (auto p : v) if (!p) return true; return false; }
+
+int recnet_bind_decoder(recnet_handle* h, const recnet_decoder_tensors* param, const recnet_decoder_tensors* grad,
+                        const recnet_decoder_tensors* exp_avg, const recnet_decoder_tensors* exp_avg_sq,
+                        const recnet_decoder_tensors* max_exp_avg_sq) {
+  if (!h || !param) return fail(RECNET_EINVAL, "null argument");
+  auto P = dec_list(param);
+  if (any_null(P)) return fail(RECNET_EINVAL, "decoder parameter pointer is null");
+  h->dP = *param;
+  if (grad) h->dGd = *grad; else memset(&h->dGd, 0, sizeof(h->dGd));
+  const size_t V = h->V, E = h->E, H = h->H, A = h->A, D = h->D;
+  std::vector<size_t> n = {A, V * E, A * H, A * D, A, 4 * H * (E + D), 4 * H * H, 4 * H, 4 * H, V * H, V};
+  auto G = dec_list(grad);
+  if (G.empty()) G.assign(P.size(), nullptr);
+  auto M = dec_list(exp_avg), Vv = dec_list(exp_avg_sq), Vm = dec_list(max_exp_avg_sq);
+  if (!M.empty() && (any_null(M) || Vv.empty() || any_null(Vv))) return fail(RECNET_EINVAL, "Adam state pointer is null");
+  if (h->c.decoder_use_amsgrad && !M.empty() && (Vm.empty() || any_null(Vm)))
+    return fail(RECNET_EINVAL, "amsgrad needs max_exp_avg_sq");
+  build_group(h->og[0], P, G, M, Vv, Vm, n);
+  h->dec_bound = true;
+  return upload_tables(h, 0);
+}
+
+int recnet_bind_reconstructor(recnet_handle* h, const recnet_reconstructor_tensors* param,
+                              const recnet_reconstructor_tensors* grad, const recnet_reconstructor_tensors* exp_avg,
+                              const recnet_reconstructor_tensors* exp_avg_sq,
+                              const recnet_reconstructor_tensors* max_exp_avg_sq) {
+  if (!h || !param) return fail(RECNET_EINVAL, "null argument");
+  if (h->kind == RECNET_REC_NONE) return fail(RECNET_EINVAL, "handle was created without a reconstructor");
+  const bool local = h->kind == RECNET_REC_LOCAL;
+  auto P = rec_list(param, local);
+  if (any_null(P)) return fail(RECNET_EINVAL, "reconstructor parameter pointer is null");
+  h->rP = *param;
+  if (grad) h->rG = *grad; else memset(&h->rG, 0, sizeof(h->rG));
+  const size_t H = h->H, R = h->R, RA = h->RA;
+  std::vector<size_t> n;
+  if (local) { n = {RA, RA * R, RA * H, RA, 4 * R * H, 4 * R * R, 4 * R, 4 * R, R * R, R}; }
+  else { n = {4 * R * 2 * H, 4 * R * R, 4 * R, 4 * R, R * R, R}; }
+  auto G = rec_list(grad, local);
+  if (G.empty()) G.assign(P.size(), nullptr);
+  auto M = rec_list(exp_avg, local), Vv = rec_list(exp_avg_sq, local), Vm = rec_list(max_exp_avg_sq, local);
+  if (!M.empty() && (any_null(M) || Vv.empty() || any_null(Vv))) return fail(RECNET_EINVAL, "Adam state pointer is null");
+  if (h->c.reconstructor_use_amsgrad && !M.empty() && (Vm.empty() || any_null(Vm)))
+    return fail(RECNET_EINVAL, "amsgrad needs max_exp_avg_sq");
+  build_group(h->og[1], P, G, M, Vv, Vm, n);
+  h->rec_bound = true;
+  return upload_tables(h, 1);
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// internal helpers
+// ================================================================================================
+#define REQUIRE_WS(h) do { if (!(h) || !(h)->ws) return fail(RECNET_ESTATE, "workspace not bound"); } while (0)
+
+static void gemm(recnet_handle* h, const void* A, int a_bf16, int a_col, int lda, const void* Bm, int b_bf16, int b_col,
+                 int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha, int acc,
+                 hipStream_t st) {
+  // batched GEMM with automatic split-K (slabs reduced by splitk_reduce)
+  int s = rn_pick_splitk(h->prec, M, N, K, 32);
+  while (s > 1 && (size_t)s * M * N > h->gws_floats) s >>= 1;
+  rn_launch_gemm(h->prec, A, a_bf16, a_col, lda, Bm, b_bf16, b_col, ldb, C, ldc, bias, M, N, K, alpha, acc, s, h->gws, 1, st);
+}
+// recurrent-step GEMM: partial slabs only; returns the slab count the consumer must sum
+static int gemm_slabs(recnet_handle* h, const void* A, int a_col, int lda, const void* Bm, int b_bf16, int b_col, int ldb,
+                      int M, int N, int K, hipStream_t st) {
+  int s = rn_pick_splitk(h->prec, M, N, K, 32);
+  while (s > 1 && (size_t)s * M * N > h->slab_floats) s >>= 1;
+  if (s < 2) s = 2;  // always use the slab path so the consumer code is uniform
+  s = rn_effective_splitk(h->prec, K, s);
+  if (s < 2) {
+    // K fits one tile: write the single product into slab 0 through the direct epilogue
+    rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, h->slab, N, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0, st);
+    return 1;
+  }
+  rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, nullptr, N, nullptr, M, N, K, 1.f, 0, s, h->slab, 0, st);
+  return s;
+}
+static void colsum(const float* X, int rows, int cols, int ld, float* out, hipStream_t st) {
+  int rs = rows >= 512 ? 8 : 1;
+  if (rs > 1) hipMemsetAsync(out, 0, (size_t)cols * 4, st);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), rs), dim3(256), 0, st, X, rows, cols, ld, out, rs > 1 ? 1 : 0);
+}
+static void copyf(const float* x, float* y, size_t n, hipStream_t st) {
+  hipMemcpyAsync(y, x, n * 4, hipMemcpyDeviceToDevice, st);
+}
+static void param_norms(recnet_handle* h, int g, float* sum_out, hipStream_t st) {
+  OptGroup& o = h->og[g];
+  hipLaunchKernelGGL(sumsq_chunk_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, 0, (const float*)nullptr, 0.f, o.d_partial);
+  hipLaunchKernelGGL(tensor_norm_kernel, dim3(o.ntens), dim3(256), 0, st, o.d_tab, o.d_partial, o.d_pnorm);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, o.d_pnorm, o.ntens, 0.f, (float*)nullptr, (float*)nullptr, sum_out);
+}
+// out = a + k * b
+__global__ void axpb_kernel(const float* a, const float* b, float k, float* out) { *out = *a + k * *b; }
+__global__ void export_scalars_kernel(const float* scal, recnet_scalars* out) {
+  out->dec_ce = scal[0]; out->dec_reg = scal[1]; out->dec_loss = scal[2]; out->rec_mse = scal[3];
+  out->rec_reg = scal[4]; out->rec_loss = scal[5]; out->total_loss = scal[6]; out->dec_grad_norm = scal[7];
+}
+
+static int pack_weights(recnet_handle* h, hipStream_t st) {
+  const int H = h->H, D = h->D, E = h->E, R = h->R;
+  if (h->dec_bound) {
+    const size_t n = (size_t)4 * H * (D + H);
+    if (h->prec == RN_PREC_BF16)
+      hipLaunchKernelGGL(pack2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->Wch,
+                         h->dP.rnn_weight_ih_l0 + E, E + D, D, h->dP.rnn_weight_hh_l0, H, H, 4 * H);
+    else
+      hipLaunchKernelGGL(pack2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->Wch,
+                         h->dP.rnn_weight_ih_l0 + E, E + D, D, h->dP.rnn_weight_hh_l0, H, H, 4 * H);
+  }
+  if (h->rec_bound && h->kind == RECNET_REC_LOCAL) {
+    const size_t n = (size_t)4 * R * (H + R);
+    if (h->prec == RN_PREC_BF16)
+      hipLaunchKernelGGL(pack2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->Wihh,
+                         h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
+    else
+      hipLaunchKernelGGL(pack2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->Wihh,
+                         h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
+  }
+  return RECNET_OK;
+}
+
+static size_t dec_step_smem(const recnet_handle* h) { return (size_t)(h->H + h->A + h->F + 16) * 4; }
+
+// ---------------------------------------------------------------------------------------------- decoder forward
+static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw,
+                       int train, float* hiddens_out, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V;
+  const int pb = h->prec == RN_PREC_BF16;
+  param_norms(h, 0, h->scal + 1, st);
+  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, 4 * H);
+  // Uv = enc . U^T                                   (decoder.py:54, hoisted out of the time loop)
+  gemm(h, enc, 0, 0, D, h->dP.attn_U_weight, 0, 0, D, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
+  // all T teacher-forced input embeddings at once    (decoder.py:46-48, train.py:25,45)
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(T * B), dim3(128), 0, st, h->dP.embedding_weight, targets, (const int64_t*)nullptr,
+                     h->emb, B, E, V, h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), 0);
+  // Xe = emb . W_ih[:, :E]^T + b_ih + b_hh
+  gemm(h, h->emb, 0, 0, E, h->dP.rnn_weight_ih_l0, 0, 0, E + D, h->Xe, 4 * H, h->bsum_d, T * B, 4 * H, E, 1.f, 0, st);
+  DecStepArgs a;
+  a.B = B; a.F = F; a.D = D; a.H = H; a.A = A;
+  a.W = h->dP.attn_W_weight; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight; a.enc = enc;
+  a.h_in = nullptr; a.h_in_ld = H; a.xcat_ld = D + H;
+  const size_t sm = dec_step_smem(h);
+  int S = 0;
+  for (int t = 0; t <= T; ++t) {
+    a.t = t; a.S = S; a.do_lstm = t > 0; a.do_attn = t < T;
+    a.slab = h->slab;
+    a.Xe = t > 0 ? h->Xe + (size_t)(t - 1) * B * 4 * H : nullptr;
+    a.c_prev = t > 1 ? h->Cs + (size_t)(t - 2) * B * H : nullptr;
+    a.h_out = t > 0 ? h->Hs + (size_t)(t - 1) * B * H : nullptr;
+    a.c_out = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
+    a.acts = t > 0 ? h->acts + (size_t)(t - 1) * B * 4 * H : nullptr;
+    a.xcat = t < T ? h->Xcat + (size_t)t * B * (D + H) : nullptr;
+    a.Wh_out = t < T ? h->Wh + (size_t)t * B * A : nullptr;
+    a.att_out = t < T ? h->att + (size_t)t * B * F : nullptr;
+    hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
+    if (t < T)   // gates_t (minus Xe) = [ctx_t, h_{t-1}] . [W_ih[:,E:] | W_hh]^T as split-K slabs
+      S = gemm_slabs(h, h->Xcat + (size_t)t * B * (D + H), 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
+  }
+  // logits for all steps, then masked CE with logits dropout (decoder.py:68-69, train.py:54-68)
+  gemm(h, h->Hs, 0, 0, H, h->dP.out_weight, 0, 0, H, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
+  copyf(stepw, h->stepw, T, st);
+  hipLaunchKernelGGL(ce_kernel, dim3(T * B), dim3(256), 0, st, h->logits, targets, h->stepw, h->rowloss, B, V,
+                     mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train), 1.0f, 1);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, h->rowloss, T * B, h->scal + 0, 1.0f);
+  hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 0, h->scal + 1, h->c.decoder_lambda_reg, h->scal + 2);
+  hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 2, 0.f, h->scal + 6);
+  if (hiddens_out) copyf(h->Hs, hiddens_out, (size_t)T * B * H, st);
+  h->T_last = T; h->train_last = train; h->fwd_dec_done = 1; h->fwd_rec_done = 0; h->rec_bwd_done = 0;
+  return RECNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- decoder backward
+static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhid, float gscale,
+                       hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, T = h->T_last;
+  const int pb = h->prec == RN_PREC_BF16, train = h->train_last;
+  const int TB = T * B;
+  if (gscale != 1.0f) hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks((size_t)TB * V)), dim3(256), 0, st, h->logits, (size_t)TB * V, gscale);
+  // dHs = dhiddens (from the reconstructor) + dlogits . W_o
+  if (dhid) copyf(dhid, h->dHs, (size_t)TB * H, st); else hipMemsetAsync(h->dHs, 0, (size_t)TB * H * 4, st);
+  gemm(h, h->logits, 0, 0, V, h->dP.out_weight, 0, 1, H, h->dHs, H, nullptr, TB, H, V, 1.f, 1, st);
+  // dW_o = dlogits^T . Hs ; db_o = colsum(dlogits)
+  gemm(h, h->logits, 0, 1, V, h->Hs, 0, 1, H, h->dGd.out_weight, H, nullptr, V, H, TB, 1.f, 0, st);
+  colsum(h->logits, TB, V, V, h->dGd.out_bias, st);
+  // BPTT
+  DecBwdArgs a;
+  a.B = B; a.F = F; a.D = D; a.H = H; a.A = A;
+  a.enc = enc; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight; a.W = h->dP.attn_W_weight;
+  a.dUv = h->dUv; a.dwacc = h->dwacc; a.dc_carry = h->dc_carry; a.slab = h->slab;
+  const size_t sm = (size_t)(D + H + F + A + 16) * 4;
+  int S = 0;
+  for (int t = T; t >= 0; --t) {
+    a.t = t; a.S = S; a.do_attn = t < T; a.do_lstm = t > 0;
+    a.first_attn = (t == T - 1); a.first_lstm = (t == T);
+    a.Wh = t < T ? h->Wh + (size_t)t * B * A : nullptr;
+    a.dWh = t < T ? h->dWh + (size_t)t * B * A : nullptr;
+    if (t > 0) {
+      a.dHs = h->dHs + (size_t)(t - 1) * B * H;
+      a.acts = h->acts + (size_t)(t - 1) * B * 4 * H;
+      a.c = h->Cs + (size_t)(t - 1) * B * H;
+      a.c_prev = t > 1 ? h->Cs + (size_t)(t - 2) * B * H : nullptr;
+      a.dG = h->dG + (size_t)(t - 1) * B * 4 * H;
+    }
+    hipLaunchKernelGGL(dec_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
+    if (t > 0)   // d[ctx_{t-1}, h_{t-2}] = dG_{t-1} . [W_ih[:,E:] | W_hh]
+      S = gemm_slabs(h, h->dG + (size_t)(t - 1) * B * 4 * H, 0, 4 * H, h->Wch, pb, 1, D + H, B, D + H, 4 * H, st);
+  }
+  // deferred weight gradients (batched over all T steps)
+  gemm(h, h->dG, 0, 0, 4 * H, h->dP.rnn_weight_ih_l0, 0, 1, E + D, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
+  hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(TB), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
+                     h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train));
+  gemm(h, h->dG, 0, 1, 4 * H, h->emb, 0, 1, E, h->dGd.rnn_weight_ih_l0, E + D, nullptr, 4 * H, E, TB, 1.f, 0, st);
+  gemm(h, h->dG, 0, 1, 4 * H, h->Xcat, 0, 1, D + H, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, 4 * H, D, TB, 1.f, 0, st);
+  gemm(h, h->dG, 0, 1, 4 * H, h->Xcat + D, 0, 1, D + H, h->dGd.rnn_weight_hh_l0, H, nullptr, 4 * H, H, TB, 1.f, 0, st);
+  colsum(h->dG, TB, 4 * H, 4 * H, h->dGd.rnn_bias_ih_l0, st);
+  copyf(h->dGd.rnn_bias_ih_l0, h->dGd.rnn_bias_hh_l0, 4 * H, st);
+  gemm(h, h->dUv, 0, 1, A, enc, 0, 1, D, h->dGd.attn_U_weight, D, nullptr, A, D, B * F, 1.f, 0, st);
+  gemm(h, h->dWh, 0, 1, A, h->Xcat + D, 0, 1, D + H, h->dGd.attn_W_weight, H, nullptr, A, H, TB, 1.f, 0, st);
+  colsum(h->dWh, TB, A, A, h->dGd.attn_b, st);
+  colsum(h->dwacc, B, A, A, h->dGd.attn_w_weight, st);
+  return RECNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- global reconstructor
+static void lstm_pw(recnet_handle* h, int Hd, int S, int slab_ld, const float* X, int x_ld, const float* b1, const float* b2,
+                    const float* c_prev, float* h_out, int h_ld, float* h_out2, int h2_ld, float* c_out, float* acts,
+                    hipStream_t st) {
+  LstmPwArgs p;
+  p.B = h->B; p.Hd = Hd; p.S = S; p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld;
+  p.X = X; p.x_ld = x_ld; p.b1 = b1; p.b2 = b2; p.c_prev = c_prev; p.h_out = h_out; p.h_ld = h_ld;
+  p.h_out2 = h_out2; p.h2_ld = h2_ld; p.c_out = c_out; p.acts = acts;
+  hipLaunchKernelGGL(lstm_pw_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
+}
+
+static int fwd_rec_global(recnet_handle* h, const float* enc, const float* Hs, int T, int train, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R;
+  param_norms(h, 1, h->scal + 4, st);
+  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * R, 256)), dim3(256), 0, st, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, 4 * R);
+  // mean-pooled decoder states, rescaled by caption_max_len / T (global_reconstructor.py:33-37): (cml / T^2) sum_t h_t
+  const size_t nBH = (size_t)B * H;
+  hipLaunchKernelGGL(mean_over_t_kernel, dim3(ew_blocks(nBH)), dim3(256), 0, st, Hs, T, nBH, (float)h->cml / ((float)T * (float)T), h->mp);
+  hipLaunchKernelGGL(bcast_drop_kernel, dim3(ew_blocks((size_t)T * nBH)), dim3(256), 0, st, h->mp, h->mpd, T, B, H,
+                     mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train));
+  // Xg = [h_t ; drop_t(mp)] . W_ih^T + b_ih + b_hh, batched over T (only h_r . W_hh^T is recurrent)
+  gemm(h, Hs, 0, 0, H, h->rP.rnn_weight_ih_l0, 0, 0, 2 * H, h->Xg, 4 * R, h->bsum_r, T * B, 4 * R, H, 1.f, 0, st);
+  gemm(h, h->mpd, 0, 0, H, h->rP.rnn_weight_ih_l0 + H, 0, 0, 2 * H, h->Xg, 4 * R, nullptr, T * B, 4 * R, H, 1.f, 1, st);
+  for (int t = 0; t < T; ++t) {
+    int S = 0;
+    if (t > 0) S = gemm_slabs(h, h->Hr + (size_t)(t - 1) * B * R, 0, R, h->rP.rnn_weight_hh_l0, 0, 0, R, B, 4 * R, R, st);
+    lstm_pw(h, R, S, 4 * R, h->Xg + (size_t)t * B * 4 * R, 4 * R, nullptr, nullptr,
+            t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->Hr + (size_t)t * B * R, R, nullptr, 0,
+            h->Cr + (size_t)t * B * R, h->acts_r + (size_t)t * B * 4 * R, st);
+  }
+  // mean_t out_t = (mean_t hr_t) . W_o^T + b_o  (train.py:96-98; `out` is linear so the mean commutes)
+  const size_t nBR = (size_t)B * R;
+  hipLaunchKernelGGL(mean_over_t_kernel, dim3(ew_blocks(nBR)), dim3(256), 0, st, h->Hr, T, nBR, 1.0f / (float)T, h->hrmean);
+  gemm(h, h->hrmean, 0, 0, R, h->rP.out_weight, 0, 0, R, h->outm, R, h->rP.out_bias, B, R, R, 1.f, 0, st);
+  hipLaunchKernelGGL(mean_over_f_kernel, dim3(ew_blocks((size_t)B * D)), dim3(256), 0, st, enc, B, F, D, h->encmean);
+  const double cnt = (double)h->c.global_batch_size * R;
+  const int nb = 256;
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, h->outm, h->encmean, 1, B, R, (size_t)R, (size_t)0,
+                     (float)(2.0 / (cnt * T)), h->msep);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, h->msep, nb, h->scal + 3, (float)(1.0 / (cnt * T)));
+  return RECNET_OK;
+}
+
+static void lstm_bwd(recnet_handle* h, int Hd, int S, int slab_ld, int slab_col0, const float* dh_direct, int dhd_ld,
+                     float dh_scale, const float* acts, const float* c, const float* c_prev, float* dc_carry, int first,
+                     float* dG, hipStream_t st) {
+  LstmBwdArgs p;
+  p.B = h->B; p.Hd = Hd; p.S = S; p.dh_direct = dh_direct; p.dhd_ld = dhd_ld; p.dh_scale = dh_scale;
+  p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld; p.slab_col0 = slab_col0;
+  p.extra = nullptr; p.acts = acts; p.c = c; p.c_prev = c_prev; p.dc_carry = dc_carry; p.first = first; p.dG = dG;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
+}
+
+static int bwd_rec_global(recnet_handle* h, const float* Hs, float gscale, float* dhid_out, hipStream_t st) {
+  const int B = h->B, H = h->H, R = h->R, T = h->T_last, TB = T * B;
+  const int train = h->train_last;
+  if (gscale != 1.0f) hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks((size_t)B * R)), dim3(256), 0, st, h->outm, (size_t)B * R, gscale);
+  // out layer: dW_o = dout^T . hrmean ; db_o ; dhrmean = dout . W_o
+  gemm(h, h->outm, 0, 1, R, h->hrmean, 0, 1, R, h->rG.out_weight, R, nullptr, R, R, B, 1.f, 0, st);
+  colsum(h->outm, B, R, R, h->rG.out_bias, st);
+  gemm(h, h->outm, 0, 0, R, h->rP.out_weight, 0, 1, R, h->dhrmean, R, nullptr, B, R, R, 1.f, 0, st);
+  int S = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    lstm_bwd(h, R, S, R, 0, h->dhrmean, R, 1.0f / (float)T, h->acts_r + (size_t)t * B * 4 * R, h->Cr + (size_t)t * B * R,
+             t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->dcr_carry, t == T - 1, h->dGr + (size_t)t * B * 4 * R, st);
+    if (t > 0) S = gemm_slabs(h, h->dGr + (size_t)t * B * 4 * R, 0, 4 * R, h->rP.rnn_weight_hh_l0, 0, 1, R, B, R, 4 * R, st);
+  }
+  // input-side gradients, batched
+  gemm(h, h->dGr, 0, 0, 4 * R, h->rP.rnn_weight_ih_l0, 0, 1, 2 * H, dhid_out, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
+  gemm(h, h->dGr, 0, 0, 4 * R, h->rP.rnn_weight_ih_l0 + H, 0, 1, 2 * H, h->dmpd, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
+  const size_t nBH = (size_t)B * H;
+  hipLaunchKernelGGL(bcast_drop_bwd_kernel, dim3(ew_blocks(nBH)), dim3(256), 0, st, h->dmpd, h->dmp, T, B, H,
+                     mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train));
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(ew_blocks((size_t)T * nBH)), dim3(256), 0, st, dhid_out, h->dmp, T, nBH,
+                     (float)h->cml / ((float)T * (float)T), 1);
+  gemm(h, h->dGr, 0, 1, 4 * R, Hs, 0, 1, H, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
+  gemm(h, h->dGr, 0, 1, 4 * R, h->mpd, 0, 1, H, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
+  if (T > 1)
+    gemm(h, h->dGr + (size_t)B * 4 * R, 0, 1, 4 * R, h->Hr, 0, 1, R, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (T - 1) * B, 1.f, 0, st);
+  else
+    hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)4 * R * R * 4, st);
+  colsum(h->dGr, TB, 4 * R, 4 * R, h->rG.rnn_bias_ih_l0, st);
+  copyf(h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, 4 * R, st);
+  return RECNET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- local reconstructor
+static int fwd_rec_local(recnet_handle* h, const float* enc, const float* Hs, int T, int train, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R, RA = h->RA;
+  const int pb = h->prec == RN_PREC_BF16;
+  param_norms(h, 1, h->scal + 4, st);
+  // Ud = hiddens . U_r^T   (local_reconstructor.py:42, hoisted)
+  gemm(h, Hs, 0, 0, H, h->rP.attn_U_weight, 0, 0, H, h->Ud, RA, nullptr, T * B, RA, H, 1.f, 0, st);
+  hipMemsetAsync(h->Xcat_r, 0, (size_t)B * (H + R) * 4, st);   // hr_{-1} = 0
+  LocAttnArgs a;
+  a.B = B; a.T = T; a.H = H; a.A = RA; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight; a.Hs = Hs;
+  a.xcat_ld = H + R; a.dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
+  const size_t sm = (size_t)(RA + T + 16) * 4;
+  for (int s = 0; s < F; ++s) {
+    int Sa = 0;
+    if (s > 0) Sa = gemm_slabs(h, h->Hr + (size_t)(s - 1) * B * R, 0, R, h->rP.attn_W_weight, 0, 0, R, B, RA, R, st);
+    a.s = s; a.S = Sa; a.slab = s > 0 ? h->slab : nullptr;
+    a.Whr_out = h->Whr + (size_t)s * B * RA; a.beta_out = h->beta + (size_t)s * B * T;
+    a.xcat = h->Xcat_r + (size_t)s * B * (H + R);
+    hipLaunchKernelGGL(loc_attn_fwd_kernel, dim3(B), dim3(256), sm, st, a);
+    const int Sb = gemm_slabs(h, h->Xcat_r + (size_t)s * B * (H + R), 0, H + R, h->Wihh, pb, 0, H + R, B, 4 * R, H + R, st);
+    lstm_pw(h, R, Sb, 4 * R, nullptr, 0, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0,
+            s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->Hr + (size_t)s * B * R, R,
+            s + 1 < F ? h->Xcat_r + (size_t)(s + 1) * B * (H + R) + H : nullptr, H + R, h->Cr + (size_t)s * B * R,
+            h->acts_r + (size_t)s * B * 4 * R, st);
+  }
+  gemm(h, h->Hr, 0, 0, R, h->rP.out_weight, 0, 0, R, h->outl, R, h->rP.out_bias, F * B, R, R, 1.f, 0, st);
+  const double cnt = (double)h->c.global_batch_size * F * D;
+  const int nb = 512;
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, h->outl, enc, F, B, R, (size_t)F * D, (size_t)D,
+                     (float)(2.0 / cnt), h->msep);
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, h->msep, nb, h->scal + 3, (float)(1.0 / cnt));
+  return RECNET_OK;
+}
+
+static int bwd_rec_local(recnet_handle* h, const float* Hs, float gscale, float* dhid_out, hipStream_t st) {
+  const int B = h->B, F = h->F, H = h->H, R = h->R, RA = h->RA, T = h->T_last, TB = T * B, FB = F * B;
+  const int pb = h->prec == RN_PREC_BF16, train = h->train_last;
+  if (gscale != 1.0f) hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks((size_t)FB * R)), dim3(256), 0, st, h->outl, (size_t)FB * R, gscale);
+  gemm(h, h->outl, 0, 1, R, h->Hr, 0, 1, R, h->rG.out_weight, R, nullptr, R, R, FB, 1.f, 0, st);
+  colsum(h->outl, FB, R, R, h->rG.out_bias, st);
+  gemm(h, h->outl, 0, 0, R, h->rP.out_weight, 0, 1, R, h->dHr, R, nullptr, FB, R, R, 1.f, 0, st);
+  LocBwdArgs a;
+  a.B = B; a.T = T; a.H = H; a.R = R; a.A = RA;
+  a.Hs = Hs; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight; a.Wr = h->rP.attn_W_weight;
+  a.dHs = dhid_out; a.dUd = h->dUd; a.dwacc = h->dwacc_r; a.dc_carry = h->dcr_carry; a.slab = h->slab;
+  a.dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
+  const size_t sm = (size_t)(H + R + T + RA + 16) * 4;
+  int S = 0;
+  for (int s = F; s >= 0; --s) {
+    a.s = s; a.S = S; a.do_attn = s < F; a.do_lstm = s > 0;
+    a.first_attn = (s == F - 1); a.first_lstm = (s == F); a.prop_hr = s > 0;
+    a.Whr = s < F ? h->Whr + (size_t)s * B * RA : nullptr;
+    a.beta = s < F ? h->beta + (size_t)s * B * T : nullptr;
+    a.dWhr = s < F ? h->dWhr + (size_t)s * B * RA : nullptr;
+    if (s > 0) {
+      a.dHr = h->dHr + (size_t)(s - 1) * B * R;
+      a.acts = h->acts_r + (size_t)(s - 1) * B * 4 * R;
+      a.c = h->Cr + (size_t)(s - 1) * B * R;
+      a.c_prev = s > 1 ? h->Cr + (size_t)(s - 2) * B * R : nullptr;
+      a.dG = h->dGr + (size_t)(s - 1) * B * 4 * R;
+    }
+    hipLaunchKernelGGL(loc_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
+    if (s > 0) S = gemm_slabs(h, h->dGr + (size_t)(s - 1) * B * 4 * R, 0, 4 * R, h->Wihh, pb, 1, H + R, B, H + R, 4 * R, st);
+  }
+  // deferred, batched
+  gemm(h, h->dUd, 0, 1, RA, Hs, 0, 1, H, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
+  gemm(h, h->dUd, 0, 0, RA, h->rP.attn_U_weight, 0, 1, H, dhid_out, H, nullptr, TB, H, RA, 1.f, 1, st);
+  if (F > 1)
+    gemm(h, h->dWhr + (size_t)B * RA, 0, 1, RA, h->Hr, 0, 1, R, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
+  else
+    hipMemsetAsync(h->rG.attn_W_weight, 0, (size_t)RA * R * 4, st);
+  colsum(h->dWhr, FB, RA, RA, h->rG.attn_b, st);
+  colsum(h->dwacc_r, B, RA, RA, h->rG.attn_w_weight, st);
+  gemm(h, h->dGr, 0, 1, 4 * R, h->Xcat_r, 0, 1, H + R, h->rG.rnn_weight_ih_l0, H, nullptr, 4 * R, H, FB, 1.f, 0, st);
+  gemm(h, h->dGr, 0, 1, 4 * R, h->Xcat_r + H, 0, 1, H + R, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, FB, 1.f, 0, st);
+  colsum(h->dGr, FB, 4 * R, 4 * R, h->rG.rnn_bias_ih_l0, st);
+  copyf(h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, 4 * R, st);
+  return RECNET_OK;
+}
+
+static int fwd_rec(recnet_handle* h, const float* enc, const float* hid, int T, int train, hipStream_t st) {
+  const float* Hs = hid ? hid : h->Hs;
+  int r = h->kind == RECNET_REC_GLOBAL ? fwd_rec_global(h, enc, Hs, T, train, st) : fwd_rec_local(h, enc, Hs, T, train, st);
+  if (r) return r;
+  // rec_loss = mse + lambda_reg * reg ; total = dec_loss + lambda_recon * rec_loss
+  hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 3, h->scal + 4, h->c.reconstructor_lambda_reg, h->scal + 5);
+  hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 5, h->c.lambda_recon, h->scal + 6);
+  h->T_last = T; h->train_last = train; h->fwd_rec_done = 1;
+  return RECNET_OK;
+}
+
+static int optimizer_step(recnet_handle* h, int flags, hipStream_t st) {
+  // decoder: total grad norm (incl. the regulariser gradient), clip coefficient, AMSGrad step
+  const int include_reg = flags & RECNET_OPT_REG;
+  for (int g = 0; g < 2; ++g) {
+    OptGroup& o = h->og[g];
+    if (!o.bound) continue;
+    if (g == 0 && (flags & RECNET_OPT_SKIP_DECODER)) continue;
+    if (g == 1 && ((flags & RECNET_OPT_SKIP_RECONSTRUCTOR) || h->kind == RECNET_REC_NONE)) continue;
+    if (!o.tab[0].m || !o.tab[0].g) return fail(RECNET_ESTATE, "gradients / Adam state not bound");
+    const float lam = g == 0 ? h->c.decoder_lambda_reg : h->c.reconstructor_lambda_reg;
+    const float coef = include_reg ? lam * (g == 0 ? 1.0f : h->c.lambda_recon) : 0.f;
+    const float* clip = nullptr;
+    if (g == 0 && (flags & RECNET_OPT_CLIP) && h->c.gradient_clip > 0.f) {
+      hipLaunchKernelGGL(sumsq_chunk_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, 1, o.d_pnorm, coef, o.d_partial);
+      hipLaunchKernelGGL(tensor_norm_kernel, dim3(o.ntens), dim3(256), 0, st, o.d_tab, o.d_partial, o.d_gnorm);
+      hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, o.d_gnorm, o.ntens, h->c.gradient_clip, h->scal + 7, h->scal + 8, (float*)nullptr);
+      clip = h->scal + 8;
+    }
+    AdamHyper hp;
+    hp.lr = g == 0 ? h->c.decoder_learning_rate : h->c.reconstructor_learning_rate;
+    hp.wd = (float)(g == 0 ? h->c.decoder_weight_decay : h->c.reconstructor_weight_decay);
+    hp.beta1 = h->c.adam_beta1; hp.beta2 = h->c.adam_beta2; hp.eps = (float)h->c.adam_eps;
+    hp.one_m_b1 = (float)(1.0 - h->c.adam_beta1); hp.beta2f = (float)h->c.adam_beta2; hp.one_m_b2 = (float)(1.0 - h->c.adam_beta2);
+    hp.amsgrad = g == 0 ? h->c.decoder_use_amsgrad : h->c.reconstructor_use_amsgrad;
+    hp.reg_coef = coef;
+    hipLaunchKernelGGL(adam_chunk_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, hp, o.d_pnorm, clip,
+                       (const int32_t*)(h->ctrl + 1));
+  }
+  return pack_weights(h, st);
+}
+
+// ================================================================================================
+extern "C" {
+
+int recnet_pack_weights(recnet_handle* h, void* stream) {
+  REQUIRE_WS(h);
+  int r = pack_weights(h, (hipStream_t)stream); if (r) return r;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_in, const float* c_in,
+                        const float* enc, float* logits, float* h_out, float* c_out, int32_t train,
+                        uint32_t seed, int32_t t, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
+  if (!tokens || !enc || !logits || !h_out || !c_out) return fail(RECNET_EINVAL, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V;
+  const int pb = h->prec == RN_PREC_BF16;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
+  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, 4 * H);
+  gemm(h, enc, 0, 0, D, h->dP.attn_U_weight, 0, 0, D, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(B), dim3(128), 0, st, h->dP.embedding_weight, (const int64_t*)nullptr, tokens,
+                     h->emb, B, E, V, h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), t);
+  gemm(h, h->emb, 0, 0, E, h->dP.rnn_weight_ih_l0, 0, 0, E + D, h->Xe, 4 * H, h->bsum_d, B, 4 * H, E, 1.f, 0, st);
+  DecStepArgs a;
+  a.t = t; a.B = B; a.F = F; a.D = D; a.H = H; a.A = A; a.S = 0; a.do_lstm = 0; a.do_attn = 1;
+  a.slab = nullptr; a.Xe = nullptr; a.c_prev = nullptr; a.h_out = nullptr; a.c_out = nullptr; a.acts = nullptr;
+  a.h_in = h_in; a.h_in_ld = H; a.xcat = h->Xcat; a.xcat_ld = D + H;
+  a.W = h->dP.attn_W_weight; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight; a.enc = enc;
+  a.Wh_out = nullptr; a.att_out = nullptr;
+  const size_t sm = dec_step_smem(h);
+  hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
+  int S = gemm_slabs(h, h->Xcat, 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
+  a.S = S; a.do_lstm = 1; a.do_attn = 0; a.slab = h->slab; a.Xe = h->Xe; a.c_prev = c_in; a.h_out = h_out; a.c_out = c_out;
+  a.xcat = nullptr;
+  hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
+  gemm(h, h_out, 0, 0, H, h->dP.out_weight, 0, 0, H, logits, V, h->dP.out_bias, B, V, H, 1.f, 0, st);
+  if (train && h->c.decoder_out_dropout > 0.f)
+    hipLaunchKernelGGL(logits_drop_kernel, dim3(ew_blocks((size_t)B * V)), dim3(256), 0, st, logits, B, V,
+                       mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train), t);
+  h->fwd_dec_done = 0;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+static int check_T(const recnet_handle* h, int T) { return (T >= 1 && T <= h->Tm) ? 0 : 1; }
+
+int recnet_forward_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                           const float* step_weight, int32_t train, uint32_t seed, float* hiddens_out,
+                           recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
+  if (!enc || !targets || !step_weight) return fail(RECNET_EINVAL, "null argument");
+  if (check_T(h, T)) return fail(RECNET_EINVAL, "T out of range");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
+  int r = fwd_decoder(h, enc, targets, T, step_weight, train, hiddens_out, st); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_forward_reconstructor(recnet_handle* h, const float* enc, const float* hiddens, int32_t T,
+                                 int32_t train, uint32_t seed, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  if (h->kind == RECNET_REC_NONE || !h->rec_bound) return fail(RECNET_ESTATE, "reconstructor not bound");
+  if (!enc) return fail(RECNET_EINVAL, "null argument");
+  if (check_T(h, T)) return fail(RECNET_EINVAL, "T out of range");
+  if (!hiddens && (!h->fwd_dec_done || h->T_last != T)) return fail(RECNET_ESTATE, "no decoder hidden states for this T");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
+  if (hiddens) copyf(hiddens, h->Hs, (size_t)T * h->B * h->H, st);
+  int r = fwd_rec(h, enc, nullptr, T, train, st); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_backward_reconstructor(recnet_handle* h, const float* enc, float grad_scale, float* dhiddens_out, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->fwd_rec_done) return fail(RECNET_ESTATE, "backward_reconstructor before forward_reconstructor");
+  if (!h->rG.out_weight) return fail(RECNET_ESTATE, "reconstructor gradients not bound");
+  hipStream_t st = (hipStream_t)stream;
+  float* dh = dhiddens_out ? dhiddens_out : h->dHsrec;
+  int r = h->kind == RECNET_REC_GLOBAL ? bwd_rec_global(h, h->Hs, grad_scale, dh, st) : bwd_rec_local(h, h->Hs, grad_scale, dh, st);
+  if (r) return r;
+  if (dhiddens_out) copyf(dhiddens_out, h->dHsrec, (size_t)h->T_last * h->B * h->H, st);
+  h->rec_bwd_done = 1;
+  (void)enc;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_backward_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhiddens,
+                            float grad_scale, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->fwd_dec_done) return fail(RECNET_ESTATE, "backward_decoder before forward_decoder");
+  if (!h->dGd.out_weight) return fail(RECNET_ESTATE, "decoder gradients not bound");
+  if (!enc || !targets) return fail(RECNET_EINVAL, "null argument");
+  int r = bwd_decoder(h, enc, targets, dhiddens, grad_scale, (hipStream_t)stream); if (r) return r;
+  h->fwd_dec_done = 0;   // dlogits were consumed in place
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_add_reg_grad(recnet_handle* h, int32_t which, float grad_scale, void* stream) {
+  REQUIRE_WS(h);
+  if (which < 0 || which > 1 || !h->og[which].bound) return fail(RECNET_EINVAL, "model not bound");
+  OptGroup& o = h->og[which];
+  const float lam = which == 0 ? h->c.decoder_lambda_reg : h->c.reconstructor_lambda_reg;
+  hipLaunchKernelGGL(add_reg_grad_kernel, dim3(o.nchunks), dim3(256), 0, (hipStream_t)stream, o.d_tab, o.d_chunks, o.d_pnorm, lam * grad_scale);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_clip_grad_norm(recnet_handle* h, int32_t which, float max_norm, float* total_norm_out, void* stream) {
+  REQUIRE_WS(h);
+  if (which < 0 || which > 1 || !h->og[which].bound || !h->og[which].tab[0].g) return fail(RECNET_EINVAL, "gradients not bound");
+  OptGroup& o = h->og[which];
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_chunk_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, 1, o.d_pnorm, 0.f, o.d_partial);
+  hipLaunchKernelGGL(tensor_norm_kernel, dim3(o.ntens), dim3(256), 0, st, o.d_tab, o.d_partial, o.d_gnorm);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, o.d_gnorm, o.ntens, max_norm, h->scal + 7, h->scal + 8, (float*)nullptr);
+  hipLaunchKernelGGL(scale_grads_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, h->scal + 8);
+  if (total_norm_out) copyf(h->scal + 7, total_norm_out, 1, st);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_optimizer_step(recnet_handle* h, int32_t step, int32_t flags, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  if (step < 1) return fail(RECNET_EINVAL, "step must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl + 1, (uint32_t)step);
+  int r = optimizer_step(h, flags, st); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st) {
+  int r = fwd_decoder(h, enc, targets, T, stepw, 1, nullptr, st); if (r) return r;
+  const float* dh = nullptr;
+  if (h->kind != RECNET_REC_NONE) {
+    r = fwd_rec(h, enc, nullptr, T, 1, st); if (r) return r;
+    r = h->kind == RECNET_REC_GLOBAL ? bwd_rec_global(h, h->Hs, h->c.lambda_recon, h->dHsrec, st)
+                                     : bwd_rec_local(h, h->Hs, h->c.lambda_recon, h->dHsrec, st);
+    if (r) return r;
+    dh = h->dHsrec;
+  }
+  return bwd_decoder(h, enc, targets, dh, 1.0f, st);
+}
+
+int recnet_train_step_fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                              const float* step_weight, uint32_t seed, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound || (h->kind != RECNET_REC_NONE && !h->rec_bound)) return fail(RECNET_ESTATE, "models not bound");
+  if (!h->dGd.out_weight || (h->kind != RECNET_REC_NONE && !h->rG.out_weight)) return fail(RECNET_ESTATE, "gradients not bound");
+  if (!enc || !targets || !step_weight) return fail(RECNET_EINVAL, "null argument");
+  if (check_T(h, T)) return fail(RECNET_EINVAL, "T out of range");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
+  int r = fwd_bwd(h, enc, targets, T, step_weight, st); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  h->fwd_dec_done = 0;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_train_step(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                      const float* step_weight, uint32_t seed, int32_t step, recnet_scalars* scalars, void* stream) {
+  int r = recnet_train_step_fwd_bwd(h, enc, targets, T, step_weight, seed, nullptr, stream); if (r) return r;
+  return recnet_optimizer_step(h, step, RECNET_OPT_REG | RECNET_OPT_CLIP, scalars, stream);
+}
+
+int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, const float* B, int32_t b_col,
+                int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K,
+                float alpha, int32_t accumulate, int32_t splitk, float* splitk_ws, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return fail(RECNET_EINVAL, "bad gemm argument");
+  if (splitk > 1 && !splitk_ws) return fail(RECNET_EINVAL, "split-K needs a workspace");
+  rn_launch_gemm(precision, A, 0, a_col, lda, B, 0, b_col, ldb, C, ldc, bias, M, N, K, alpha, accumulate, splitk, splitk_ws, 1,
+                 (hipStream_t)stream);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which) {
+  if (!h) return 0;
+  const double wb = h->prec == RN_PREC_BF16 ? 2.0 : 4.0;
+  if (which == 0) return (double)4 * h->H * (h->D + h->H) * wb + (double)h->B * (h->D + h->H) * 4 + (double)h->B * 4 * h->H * 4;
+  if (h->kind == RECNET_REC_GLOBAL) return (double)4 * h->R * h->R * 4.0 + (double)h->B * h->R * 4 + (double)h->B * 4 * h->R * 4;
+  if (h->kind == RECNET_REC_LOCAL) return (double)4 * h->R * (h->H + h->R) * wb + (double)h->B * (h->H + h->R) * 4 + (double)h->B * 4 * h->R * 4;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Host-side dispatch of the MFMA GEMM template (gemm.hpp).
+#include "gemm.hpp"
+#include "launch.hpp"
+
+namespace {
+template <typename CT, typename TA, typename TB>
+void launch_layout(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream_t st) {
+  if (!a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false>), grid, dim3(256), 0, st, a);
+  else if (!a_col && b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true>), grid, dim3(256), 0, st, a);
+  else if (a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, false>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, true>), grid, dim3(256), 0, st, a);
+}
+inline int vec_ok(const void* p, int ld, int elem) {
+  return (((uintptr_t)p) % 16 == 0) && (((size_t)ld * elem) % 16 == 0);
+}
+}  // namespace
+
+int rn_gemm_bk(int prec) { return prec == RN_PREC_BF16 ? GemmCfg<bf16_t>::BK : GemmCfg<float>::BK; }
+
+// Picks a split-K factor so that a small-M (recurrent) GEMM still fills the chip: ~256 workgroups.
+int rn_pick_splitk(int prec, int M, int N, int K, int max_split) {
+  const int tiles = ((M + GEMM_TILE - 1) / GEMM_TILE) * ((N + GEMM_TILE - 1) / GEMM_TILE);
+  const int bk = rn_gemm_bk(prec);
+  int nkt = (K + bk - 1) / bk;
+  int s = 1;
+  while (s * 2 <= max_split && tiles * s * 2 <= 320 && nkt / (s * 2) >= 1) s *= 2;
+  return s;
+}
+
+void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
+                    int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st) {
+  if (M <= 0 || N <= 0) return;
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.alpha = alpha; a.accumulate = accumulate;
+  const int bk = rn_gemm_bk(prec);
+  if (splitk < 1) splitk = 1;
+  int nkt = (K + bk - 1) / bk;
+  if (nkt < 1) nkt = 1;
+  if (splitk > nkt) splitk = nkt;
+  int per = (nkt + splitk - 1) / splitk;
+  splitk = (nkt + per - 1) / per;   // no empty slices
+  a.splitk = splitk; a.kchunk = per * bk; a.ws = ws;
+  a.a_vec = vec_ok(A, lda, a_bf16 ? 2 : 4);
+  a.b_vec = vec_ok(B, ldb, b_bf16 ? 2 : 4);
+  dim3 grid((N + GEMM_TILE - 1) / GEMM_TILE, (M + GEMM_TILE - 1) / GEMM_TILE, splitk);
+  if (prec == RN_PREC_BF16) {
+    if (!a_bf16 && !b_bf16) launch_layout<bf16_t, float, float>(a, a_col, b_col, grid, st);
+    else if (!a_bf16 && b_bf16) launch_layout<bf16_t, float, bf16_t>(a, a_col, b_col, grid, st);
+    else if (a_bf16 && b_bf16) launch_layout<bf16_t, bf16_t, bf16_t>(a, a_col, b_col, grid, st);
+    else launch_layout<bf16_t, bf16_t, float>(a, a_col, b_col, grid, st);
+  } else {
+    launch_layout<float, float, float>(a, a_col, b_col, grid, st);
+  }
+  if (splitk > 1 && reduce_after) {
+    size_t total = (size_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, splitk, M, N, C, ldc, bias, alpha,
+                       accumulate);
+  }
+}
+
+// effective split count rn_launch_gemm will use (the fused consumers need it to sum the slabs)
+int rn_effective_splitk(int prec, int K, int splitk) {
+  const int bk = rn_gemm_bk(prec);
+  int nkt = (K + bk - 1) / bk;
+  if (nkt < 1) nkt = 1;
+  if (splitk < 1) splitk = 1;
+  if (splitk > nkt) splitk = nkt;
+  int per = (nkt + splitk - 1) / splitk;
+  return (nkt + per - 1) / per;
+}

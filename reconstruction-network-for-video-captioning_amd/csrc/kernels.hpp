@@ -1,0 +1,748 @@
+// Hand-written gfx950 kernels of the RecNet train step other than the MFMA GEMM (gemm.hpp):
+// embedding gather, the fused per-caption recurrent-step kernels (LSTM gate pointwise + Bahdanau
+// attention with the caption's encoder states streamed once per step), masked cross-entropy with
+// logits dropout, reconstruction MSE, their backward mirrors, norms and the multi-tensor Adam.
+// All arithmetic here is fp32; only GEMM operands are ever rounded to bf16.
+#pragma once
+#include "common.hpp"
+#include "launch.hpp"
+
+// =============================================================================================
+// small utilities
+// =============================================================================================
+__global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+__global__ void set_f32_kernel(float* p, float v) { *p = v; }
+// step counter += 1; seed slot = seed_base + step (graph-replay friendly train step)
+__global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t seed_base) {
+  int s = *step + 1; *step = s; *seed_slot = seed_base + (uint32_t)s;
+}
+
+__device__ __forceinline__ uint32_t drop_key(const DropDesc& dd) { return rn_site_key(*dd.seed, dd.site); }
+__device__ __forceinline__ float drop_at(const DropDesc& dd, uint32_t key, int t, int b, int N, int j) {
+  const uint32_t idx = ((uint32_t)t * (uint32_t)dd.Bg + (uint32_t)(dd.boff + b)) * (uint32_t)N + (uint32_t)j;
+  return rn_drop_scale(key, dd.thr, dd.inv_keep, idx);
+}
+
+// out[i] = scale * sum_j x[j]   (single block; deterministic order)
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float* out, float scale) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) *out = s * scale;
+}
+
+// out[c] (+)= sum_r X[r*ld + c].  grid (ceil(cols/64), RS); with RS > 1 `out` must be pre-zeroed (atomics).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int rows, int cols, int ld,
+                                                     float* __restrict__ out, int use_atomic) {
+  __shared__ float sm[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int rs = gridDim.y, per = (rows + rs - 1) / rs;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + rg; r < r1; r += 4) s += X[(size_t)r * ld + c];
+  sm[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (use_atomic) atomicAdd(out + c, s); else out[c] = s;
+  }
+}
+
+// out[i] = a[i] + b[i]  (biases b_ih + b_hh)
+__global__ void add2_kernel(const float* a, const float* b, float* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+__global__ void scale_kernel(float* x, size_t n, float s) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+__global__ void copy_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i];
+}
+
+// dst[r][0:c1) = src1[r*ld1 + 0:c1), dst[r][c1:c1+c2) = src2[r*ld2 + 0:c2)   (packed weight images)
+template <typename DT>
+__global__ void pack2_kernel(DT* __restrict__ dst, const float* __restrict__ src1, int ld1, int c1,
+                             const float* __restrict__ src2, int ld2, int c2, int rows) {
+  const int W = c1 + c2;
+  const size_t total = (size_t)rows * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / W), c = (int)(i % W);
+    const float v = c < c1 ? src1[(size_t)r * ld1 + c] : src2[(size_t)r * ld2 + (c - c1)];
+    dst[i] = (DT)v;
+  }
+}
+
+// =============================================================================================
+// LSTM gate math (torch.nn.LSTM order i, f, g, o)
+// =============================================================================================
+struct LstmOut { float i, f, g, o, c, h; };
+__device__ __forceinline__ LstmOut lstm_point(float gi, float gf, float gg, float go, float c_prev) {
+  LstmOut r;
+  r.i = 1.0f / (1.0f + expf(-gi));
+  r.f = 1.0f / (1.0f + expf(-gf));
+  r.g = tanhf(gg);
+  r.o = 1.0f / (1.0f + expf(-go));
+  r.c = r.f * c_prev + r.i * r.g;
+  r.h = r.o * tanhf(r.c);
+  return r;
+}
+struct LstmGrad { float di, df, dg, d_o, dc_prev; };
+__device__ __forceinline__ LstmGrad lstm_point_bwd(float dh, float dc_in, float i, float f, float g, float o,
+                                                   float c, float c_prev) {
+  const float tc = tanhf(c);
+  const float dc = dc_in + dh * o * (1.f - tc * tc);
+  LstmGrad r;
+  r.d_o = dh * tc * o * (1.f - o);
+  r.di = dc * g * i * (1.f - i);
+  r.df = dc * c_prev * f * (1.f - f);
+  r.dg = dc * i * (1.f - g * g);
+  r.dc_prev = dc * f;
+  return r;
+}
+
+// =============================================================================================
+// embedding  (decoder.py:46-48)
+// =============================================================================================
+// emb[row, :] = scale * Emb[token(row), :] * dropmask ; row = (t - t0) * B + b
+__global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict__ Emb, const int64_t* __restrict__ targets,
+                                                        const int64_t* __restrict__ tokens, float* __restrict__ emb,
+                                                        int B, int E, int V, float scale, DropDesc dd, int t0) {
+  const int row = blockIdx.x, t = t0 + row / B, b = row % B;
+  long tok = tokens ? tokens[b] : (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
+  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+  const uint32_t key = drop_key(dd);
+  const float* src = Emb + (size_t)tok * E;
+  float* dst = emb + (size_t)row * E;
+  for (int j = threadIdx.x; j < E; j += 128) dst[j] = src[j] * scale * drop_at(dd, key, t, b, E, j);
+}
+// dEmb[token(row), :] += scale * dropmask * demb[row, :]   (dEmb pre-zeroed)
+__global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
+                                                        const float* __restrict__ demb, int B, int E, int V,
+                                                        float scale, DropDesc dd) {
+  const int row = blockIdx.x, t = row / B, b = row % B;
+  long tok = (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
+  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+  const uint32_t key = drop_key(dd);
+  const float* src = demb + (size_t)row * E;
+  float* dst = dEmb + (size_t)tok * E;
+  for (int j = threadIdx.x; j < E; j += 128) {
+    const float m = drop_at(dd, key, t, b, E, j);
+    if (m != 0.f) atomicAdd(dst + j, src[j] * scale * m);
+  }
+}
+
+// =============================================================================================
+// decoder recurrent step, forward: one workgroup per caption
+//   phase 1 (do_lstm): gates of step t-1 = Xe[t-1] + sum_z slab_z  -> h_{t-1}, c_{t-1}
+//   phase 2 (do_attn): Wh = W h ; a[f] = w . tanh(Wh + Uv[b,f] + b) ; ctx = (1/F) sum_f a[f] enc[b,f]
+//                      (decoder.py:50-61: un-normalised scores, MEAN over frames)
+// =============================================================================================
+struct DecStepArgs {
+  int t, B, F, D, H, A, S;
+  int do_lstm, do_attn;
+  const float* slab;      // [S][B][4H] split-K partials of [ctx, h] . [W_c | W_hh]^T for step t-1
+  const float* Xe;        // [B][4H]  emb . W_e^T + b_ih + b_hh for step t-1
+  const float* c_prev;    // [B][H] or nullptr (zeros)
+  float* h_out;           // [B][H] (step t-1)
+  float* c_out;           // [B][H]
+  float* acts;            // [B][4H] post-activation gates (saved for backward) or nullptr
+  const float* h_in;      // !do_lstm: hidden state to attend with, [B][h_in_ld] or nullptr (zeros)
+  int h_in_ld;
+  float* xcat;            // [B][xcat_ld]: ctx -> [0,D), h -> [D,D+H) of step t's GEMM input (nullptr: skip)
+  int xcat_ld;
+  const float* W;         // [A][H]
+  const float* Uv;        // [B][F][A]
+  const float* ab;        // [A]
+  const float* w;         // [A]
+  const float* enc;       // [B][F][D]
+  float* Wh_out;          // [B][A] or nullptr
+  float* att_out;         // [B][F] or nullptr
+};
+
+__global__ __launch_bounds__(256) void dec_step_kernel(const DecStepArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sh = smem;              // [H]
+  float* swh = sh + p.H;         // [A]
+  float* sa = swh + p.A;         // [F]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H;
+
+  if (p.do_lstm) {
+    const size_t zs = (size_t)p.B * 4 * H;
+    for (int u = tid; u < H; u += 256) {
+      float g[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t o = (size_t)b * 4 * H + q * H + u;
+        float v = p.Xe[o];
+        for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + o];
+        g[q] = v;
+      }
+      const float cp = p.c_prev ? p.c_prev[(size_t)b * H + u] : 0.f;
+      const LstmOut r = lstm_point(g[0], g[1], g[2], g[3], cp);
+      p.h_out[(size_t)b * H + u] = r.h;
+      p.c_out[(size_t)b * H + u] = r.c;
+      if (p.acts) {
+        float* a = p.acts + (size_t)b * 4 * H + u;
+        a[0] = r.i; a[H] = r.f; a[2 * H] = r.g; a[3 * H] = r.o;
+      }
+      sh[u] = r.h;
+    }
+  } else {
+    for (int u = tid; u < H; u += 256) sh[u] = p.h_in ? p.h_in[(size_t)b * p.h_in_ld + u] : 0.f;
+  }
+  if (!p.do_attn) return;
+  if (p.xcat)
+    for (int u = tid; u < H; u += 256) p.xcat[(size_t)b * p.xcat_ld + p.D + u] = sh[u];
+  __syncthreads();
+
+  // Wh[k] = sum_u W[k,u] h[u]: one wave per k, lanes stride over u (coalesced rows of W)
+  for (int k = wave; k < p.A; k += 4) {
+    const float* wr = p.W + (size_t)k * H;
+    float s = 0.f;
+    for (int u = lane; u < H; u += 64) s += wr[u] * sh[u];
+    s = wave_sum(s);
+    if (lane == 0) { swh[k] = s; if (p.Wh_out) p.Wh_out[(size_t)b * p.A + k] = s; }
+  }
+  __syncthreads();
+  // a[f] = sum_k w[k] tanh(Wh[k] + Uv[b,f,k] + ab[k]): one wave per frame, wavefront reduction
+  for (int f = wave; f < p.F; f += 4) {
+    const float* uv = p.Uv + ((size_t)b * p.F + f) * p.A;
+    float s = 0.f;
+    for (int k = lane; k < p.A; k += 64) s += p.w[k] * tanhf(swh[k] + uv[k] + p.ab[k]);
+    s = wave_sum(s);
+    if (lane == 0) { sa[f] = s; if (p.att_out) p.att_out[(size_t)b * p.F + f] = s; }
+  }
+  __syncthreads();
+  // ctx[d] = (1/F) sum_f a[f] enc[b,f,d]
+  const float* e = p.enc + (size_t)b * p.F * p.D;
+  const float invF = 1.0f / (float)p.F;
+  for (int d = tid; d < p.D; d += 256) {
+    float s = 0.f;
+    for (int f = 0; f < p.F; ++f) s += sa[f] * e[(size_t)f * p.D + d];
+    p.xcat[(size_t)b * p.xcat_ld + d] = s * invF;
+  }
+}
+
+// =============================================================================================
+// decoder recurrent step, backward: one workgroup per caption
+//   phase A (do_attn): attention backward of step t from dXcat_t = dG_t . [W_c | W_hh] (split-K slabs)
+//   phase B (do_lstm): LSTM pointwise backward of step t-1
+// =============================================================================================
+struct DecBwdArgs {
+  int t, B, F, D, H, A, S;
+  int do_attn, do_lstm;
+  const float* slab;     // [S][B][D+H]
+  const float* enc; const float* Uv; const float* ab; const float* w; const float* W;
+  const float* Wh;       // [B][A] of step t
+  float* dUv;            // [B][F][A] accumulated over t
+  float* dWh;            // [B][A] of step t (saved for the deferred dW = dWh^T h_prev GEMM)
+  float* dwacc;          // [B][A] accumulated over t: sum_f da[f] tanh(z[f,k])
+  int first_attn;        // initialise dUv / dwacc instead of accumulating
+  const float* dHs;      // [B][H] direct gradient of h_{t-1} (vocabulary projection + reconstructor)
+  const float* acts;     // [B][4H] of step t-1
+  const float* c;        // [B][H] c_{t-1}
+  const float* c_prev;   // [B][H] c_{t-2} or nullptr
+  float* dc_carry;       // [B][H]
+  int first_lstm;        // dc_carry starts at zero
+  float* dG;             // [B][4H] of step t-1
+};
+
+__global__ __launch_bounds__(256) void dec_bwd_step_kernel(const DecBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sdctx = smem;            // [D]
+  float* sdh = sdctx + p.D;       // [H]
+  float* sda = sdh + p.H;         // [F]
+  float* sdWh = sda + p.F;        // [A]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, D = p.D, A = p.A, F = p.F;
+
+  if (p.do_attn) {
+    const int W2 = D + H;
+    const size_t zs = (size_t)p.B * W2;
+    for (int j = tid; j < W2; j += 256) {
+      float v = 0.f;
+      for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * W2 + j];
+      if (j < D) sdctx[j] = v; else sdh[j - D] = v;
+    }
+    __syncthreads();
+    // da[f] = (1/F) dctx . enc[b,f,:]
+    const float* e = p.enc + (size_t)b * F * D;
+    const float invF = 1.0f / (float)F;
+    for (int f = wave; f < F; f += 4) {
+      float s = 0.f;
+      for (int d = lane; d < D; d += 64) s += sdctx[d] * e[(size_t)f * D + d];
+      s = wave_sum(s);
+      if (lane == 0) sda[f] = s * invF;
+    }
+    __syncthreads();
+    for (int k = tid; k < A; k += 256) {
+      const float whk = p.Wh[(size_t)b * A + k] + p.ab[k];
+      const float wk = p.w[k];
+      float dwh = 0.f, dw = 0.f;
+      for (int f = 0; f < F; ++f) {
+        const size_t o = ((size_t)b * F + f) * A + k;
+        const float tz = tanhf(whk + p.Uv[o]);
+        const float ds = sda[f] * wk * (1.f - tz * tz);
+        dw += sda[f] * tz;
+        dwh += ds;
+        p.dUv[o] = p.first_attn ? ds : p.dUv[o] + ds;
+      }
+      sdWh[k] = dwh;
+      p.dWh[(size_t)b * A + k] = dwh;
+      const size_t o2 = (size_t)b * A + k;
+      p.dwacc[o2] = p.first_attn ? dw : p.dwacc[o2] + dw;
+    }
+    __syncthreads();
+    // dh_{t-1} += dWh . W   (threads over u: coalesced rows of W)
+    for (int u = tid; u < H; u += 256) {
+      float s = 0.f;
+      for (int k = 0; k < A; ++k) s += sdWh[k] * p.W[(size_t)k * H + u];
+      sdh[u] += s;
+    }
+    __syncthreads();
+  } else {
+    for (int u = tid; u < H; u += 256) sdh[u] = 0.f;
+    __syncthreads();
+  }
+  if (!p.do_lstm) return;
+  for (int u = tid; u < H; u += 256) {
+    const size_t o = (size_t)b * H + u;
+    const float dh = p.dHs[o] + sdh[u];
+    const float* a = p.acts + (size_t)b * 4 * H + u;
+    const float dc_in = p.first_lstm ? 0.f : p.dc_carry[o];
+    const LstmGrad g = lstm_point_bwd(dh, dc_in, a[0], a[H], a[2 * H], a[3 * H], p.c[o],
+                                      p.c_prev ? p.c_prev[o] : 0.f);
+    float* dg = p.dG + (size_t)b * 4 * H + u;
+    dg[0] = g.di; dg[H] = g.df; dg[2 * H] = g.dg; dg[3 * H] = g.d_o;
+    p.dc_carry[o] = g.dc_prev;
+  }
+}
+
+// =============================================================================================
+// generic element-wise LSTM step (reconstructors: hidden size R)
+// =============================================================================================
+struct LstmPwArgs {
+  int B, Hd, S;
+  const float* slab; size_t slab_stride; int slab_ld;   // [S] x [B][slab_ld], gate columns at [0, 4Hd)
+  const float* X; int x_ld;                              // optional pre-computed input part [B][x_ld]
+  const float* b1; const float* b2;                      // optional bias vectors [4Hd]
+  const float* c_prev;                                   // [B][Hd] or nullptr
+  float* h_out; int h_ld;                                // [B][h_ld]
+  float* h_out2; int h2_ld;                              // optional second destination (next step's GEMM input)
+  float* c_out; float* acts;
+};
+__global__ __launch_bounds__(256) void lstm_pw_kernel(const LstmPwArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * p.Hd) return;
+  const int b = i / p.Hd, u = i % p.Hd, Hd = p.Hd;
+  float g[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = q * Hd + u;
+    float v = p.X ? p.X[(size_t)b * p.x_ld + col] : 0.f;
+    if (p.b1) v += p.b1[col];
+    if (p.b2) v += p.b2[col];
+    for (int z = 0; z < p.S; ++z) v += p.slab[z * p.slab_stride + (size_t)b * p.slab_ld + col];
+    g[q] = v;
+  }
+  const float cp = p.c_prev ? p.c_prev[(size_t)b * Hd + u] : 0.f;
+  const LstmOut r = lstm_point(g[0], g[1], g[2], g[3], cp);
+  p.h_out[(size_t)b * p.h_ld + u] = r.h;
+  if (p.h_out2) p.h_out2[(size_t)b * p.h2_ld + u] = r.h;
+  p.c_out[(size_t)b * Hd + u] = r.c;
+  float* a = p.acts + (size_t)b * 4 * Hd + u;
+  a[0] = r.i; a[Hd] = r.f; a[2 * Hd] = r.g; a[3 * Hd] = r.o;
+}
+
+struct LstmBwdArgs {
+  int B, Hd, S;
+  const float* dh_direct; int dhd_ld; float dh_scale;    // optional [B][dhd_ld]
+  const float* slab; size_t slab_stride; int slab_ld; int slab_col0;   // recurrent part: sum_z slab[z][b][col0+u]
+  const float* extra;                                     // optional [B][Hd]
+  const float* acts; const float* c; const float* c_prev;
+  float* dc_carry; int first;
+  float* dG;                                              // [B][4Hd]
+};
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * p.Hd) return;
+  const int b = i / p.Hd, u = i % p.Hd, Hd = p.Hd;
+  float dh = p.dh_direct ? p.dh_scale * p.dh_direct[(size_t)b * p.dhd_ld + u] : 0.f;
+  for (int z = 0; z < p.S; ++z) dh += p.slab[z * p.slab_stride + (size_t)b * p.slab_ld + p.slab_col0 + u];
+  if (p.extra) dh += p.extra[(size_t)b * Hd + u];
+  const size_t o = (size_t)b * Hd + u;
+  const float* a = p.acts + (size_t)b * 4 * Hd + u;
+  const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_carry[o], a[0], a[Hd], a[2 * Hd], a[3 * Hd], p.c[o],
+                                    p.c_prev ? p.c_prev[o] : 0.f);
+  float* dg = p.dG + (size_t)b * 4 * Hd + u;
+  dg[0] = g.di; dg[Hd] = g.df; dg[2 * Hd] = g.dg; dg[3 * Hd] = g.d_o;
+  p.dc_carry[o] = g.dc_prev;
+}
+
+// =============================================================================================
+// masked cross-entropy with logits dropout (decoder.py:69, train.py:54-56,68) — forward + dlogits
+//   rowloss[t,b] = [tgt>0] * cw[t] * CE(drop(logits[t,b,:]), tgt) ; logits overwritten by
+//   d loss / d logits = [tgt>0] * cw[t] * gscale * (softmax - onehot) * dropmask
+// =============================================================================================
+__global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                 const float* __restrict__ cw, float* __restrict__ rowloss, int B,
+                                                 int V, DropDesc dd, float gscale, int write_grad) {
+  __shared__ float sm[4];
+  const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+  float* x = logits + (size_t)row * V;
+  const long tgt = targets[(size_t)t * B + b];
+  if (tgt <= 0 || tgt >= V) {
+    if (tid == 0) rowloss[row] = 0.f;
+    if (write_grad) for (int v = tid; v < V; v += 256) x[v] = 0.f;
+    return;
+  }
+  const uint32_t key = drop_key(dd);
+  float mx = -3.0e38f;
+  for (int v = tid; v < V; v += 256) mx = fmaxf(mx, x[v] * drop_at(dd, key, t, b, V, v));
+  mx = block_max256(mx, sm);
+  float s = 0.f;
+  for (int v = tid; v < V; v += 256) s += expf(x[v] * drop_at(dd, key, t, b, V, v) - mx);
+  s = block_sum256(s, sm);
+  const float lse = mx + logf(s);
+  const float wgt = cw[t];
+  if (tid == 0) rowloss[row] = wgt * (lse - x[tgt] * drop_at(dd, key, t, b, V, (int)tgt));
+  if (write_grad) {
+    __syncthreads();
+    const float k = wgt * gscale;
+    for (int v = tid; v < V; v += 256) {
+      const float m = drop_at(dd, key, t, b, V, v);
+      const float pr = expf(x[v] * m - lse);
+      x[v] = k * (pr - (v == tgt ? 1.f : 0.f)) * m;
+    }
+  }
+}
+// logits *= dropmask (step API, train mode)
+__global__ void logits_drop_kernel(float* __restrict__ logits, int B, int V, DropDesc dd, int t) {
+  const uint32_t key = drop_key(dd);
+  const size_t total = (size_t)B * V;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / V), v = (int)(i % V);
+    logits[i] *= drop_at(dd, key, t, b, V, v);
+  }
+}
+
+// =============================================================================================
+// global reconstructor helpers (global_reconstructor.py:33-41, train.py:96-102)
+// =============================================================================================
+// out[i] = scale * sum_t X[t*n + i]
+__global__ void mean_over_t_kernel(const float* __restrict__ X, int T, size_t n, float scale, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += X[(size_t)t * n + i];
+    out[i] = s * scale;
+  }
+}
+// mpd[t,b,h] = mp[b,h] * dropmask(t,b,h)
+__global__ void bcast_drop_kernel(const float* __restrict__ mp, float* __restrict__ mpd, int T, int B, int H, DropDesc dd) {
+  const uint32_t key = drop_key(dd);
+  const size_t total = (size_t)T * B * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H), b = (int)((i / H) % B), t = (int)(i / ((size_t)H * B));
+    mpd[i] = mp[(size_t)b * H + h] * drop_at(dd, key, t, b, H, h);
+  }
+}
+// dmp[b,h] = sum_t dmpd[t,b,h] * dropmask(t,b,h)
+__global__ void bcast_drop_bwd_kernel(const float* __restrict__ dmpd, float* __restrict__ dmp, int T, int B, int H, DropDesc dd) {
+  const uint32_t key = drop_key(dd);
+  const size_t n = (size_t)B * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H), b = (int)(i / H);
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += dmpd[(size_t)t * n + i] * drop_at(dd, key, t, b, H, h);
+    dmp[i] = s;
+  }
+}
+// Y[t*n + i] (+)= c * x[i]
+__global__ void add_bcast_kernel(float* __restrict__ Y, const float* __restrict__ x, int T, size_t n, float c, int accumulate) {
+  const size_t total = (size_t)T * n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = c * x[i % n];
+    Y[i] = accumulate ? Y[i] + v : v;
+  }
+}
+// encmean[b,d] = (1/F) sum_f enc[b,f,d]
+__global__ void mean_over_f_kernel(const float* __restrict__ enc, int B, int F, int D, float* __restrict__ out) {
+  const size_t n = (size_t)B * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / D), d = (int)(i % D);
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += enc[((size_t)b * F + f) * D + d];
+    out[i] = s / (float)F;
+  }
+}
+// diff = out - ref(b, s, :);  partial[block] = sum diff^2 ; out <- gcoef * diff   (d loss / d out)
+//   ref indexing: ref[b*ref_bstride + s*ref_sstride + r], out rows ordered (s, b)
+__global__ __launch_bounds__(256) void mse_kernel(float* __restrict__ out, const float* __restrict__ ref, int Sn, int B,
+                                                  int R, size_t ref_bstride, size_t ref_sstride,
+                                                  float gcoef, float* __restrict__ partial) {
+  __shared__ float sm[4];
+  const size_t total = (size_t)Sn * B * R;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i % R), b = (int)((i / R) % B), s = (int)(i / ((size_t)R * B));
+    const float d = out[i] - ref[(size_t)b * ref_bstride + (size_t)s * ref_sstride + r];
+    acc += d * d;
+    out[i] = gcoef * d;
+  }
+  acc = block_sum256(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// =============================================================================================
+// local reconstructor attention (local_reconstructor.py:38-50), one workgroup per caption
+//   beta[t'] = w . tanh(W hr + U h_t' + b)  (no softmax);  x = drop((1/T) sum_t' beta[t'] h_t')
+// =============================================================================================
+struct LocAttnArgs {
+  int s, B, T, H, A, S;
+  const float* slab;      // [S][B][A] split-K partials of hr_{s-1} . W_r^T  (nullptr at s = 0: zeros)
+  const float* Ud;        // [T][B][A]
+  const float* ab; const float* w;
+  const float* Hs;        // [T][B][H] decoder hidden states
+  float* Whr_out;         // [B][A]
+  float* beta_out;        // [B][T]
+  float* xcat; int xcat_ld;   // x -> [0,H) of the step's GEMM input row
+  DropDesc dd;
+};
+__global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* swh = smem;            // [A]
+  float* sbeta = swh + p.A;     // [T]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t zs = (size_t)p.B * p.A;
+  for (int k = tid; k < p.A; k += 256) {
+    float v = 0.f;
+    if (p.slab) for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * p.A + k];
+    swh[k] = v;
+    p.Whr_out[(size_t)b * p.A + k] = v;
+  }
+  __syncthreads();
+  for (int t = wave; t < p.T; t += 4) {
+    const float* ud = p.Ud + ((size_t)t * p.B + b) * p.A;
+    float s = 0.f;
+    for (int k = lane; k < p.A; k += 64) s += p.w[k] * tanhf(swh[k] + ud[k] + p.ab[k]);
+    s = wave_sum(s);
+    if (lane == 0) { sbeta[t] = s; p.beta_out[(size_t)b * p.T + t] = s; }
+  }
+  __syncthreads();
+  const uint32_t key = drop_key(p.dd);
+  const float invT = 1.0f / (float)p.T;
+  for (int h = tid; h < p.H; h += 256) {
+    float s = 0.f;
+    for (int t = 0; t < p.T; ++t) s += sbeta[t] * p.Hs[((size_t)t * p.B + b) * p.H + h];
+    p.xcat[(size_t)b * p.xcat_ld + h] = s * invT * drop_at(p.dd, key, p.s, b, p.H, h);
+  }
+}
+
+struct LocBwdArgs {
+  int s, B, T, H, R, A, S;
+  int do_attn, do_lstm;
+  const float* slab;      // [S][B][H+R] = dGr_s . [W_ih | W_hh]
+  const float* Hs; const float* Ud; const float* ab; const float* w; const float* Wr;  // Wr [A][R]
+  const float* Whr;       // [B][A] of step s
+  const float* beta;      // [B][T] of step s
+  float* dHs;             // [T][B][H] accumulated over s
+  float* dUd;             // [T][B][A] accumulated over s
+  float* dWhr;            // [B][A] of step s
+  float* dwacc;           // [B][A]
+  int first_attn;
+  int prop_hr;            // s > 0: propagate dWhr . W_r into hr_{s-1}
+  DropDesc dd;
+  // LSTM backward of step s-1
+  const float* dHr;       // [B][R] direct gradient of hr_{s-1}
+  const float* acts; const float* c; const float* c_prev;
+  float* dc_carry; int first_lstm;
+  float* dG;              // [B][4R]
+};
+__global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sdx = smem;            // [H]
+  float* sdh = sdx + p.H;       // [R]
+  float* sdb = sdh + p.R;       // [T]
+  float* sdWh = sdb + p.T;      // [A]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, R = p.R, A = p.A, T = p.T;
+  if (p.do_attn) {
+    const int W2 = H + R;
+    const size_t zs = (size_t)p.B * W2;
+    const uint32_t key = drop_key(p.dd);
+    for (int j = tid; j < W2; j += 256) {
+      float v = 0.f;
+      for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * W2 + j];
+      if (j < H) sdx[j] = v * drop_at(p.dd, key, p.s, b, H, j); else sdh[j - H] = v;
+    }
+    __syncthreads();
+    const float invT = 1.0f / (float)T;
+    for (int t = wave; t < T; t += 4) {
+      const float* hs = p.Hs + ((size_t)t * p.B + b) * H;
+      float s = 0.f;
+      for (int h = lane; h < H; h += 64) s += sdx[h] * hs[h];
+      s = wave_sum(s);
+      if (lane == 0) sdb[t] = s * invT;
+    }
+    // dHs[t',b,:] += (1/T) beta[t'] dx
+    for (int t = 0; t < T; ++t) {
+      const float bt = p.beta[(size_t)b * T + t] * invT;
+      float* dst = p.dHs + ((size_t)t * p.B + b) * H;
+      for (int h = tid; h < H; h += 256) dst[h] = p.first_attn ? bt * sdx[h] : dst[h] + bt * sdx[h];
+    }
+    __syncthreads();
+    for (int k = tid; k < A; k += 256) {
+      const float whk = p.Whr[(size_t)b * A + k] + p.ab[k];
+      const float wk = p.w[k];
+      float dwh = 0.f, dw = 0.f;
+      for (int t = 0; t < T; ++t) {
+        const size_t o = ((size_t)t * p.B + b) * A + k;
+        const float tz = tanhf(whk + p.Ud[o]);
+        const float dz = sdb[t] * wk * (1.f - tz * tz);
+        dw += sdb[t] * tz;
+        dwh += dz;
+        p.dUd[o] = p.first_attn ? dz : p.dUd[o] + dz;
+      }
+      sdWh[k] = dwh;
+      p.dWhr[(size_t)b * A + k] = dwh;
+      const size_t o2 = (size_t)b * A + k;
+      p.dwacc[o2] = p.first_attn ? dw : p.dwacc[o2] + dw;
+    }
+    __syncthreads();
+    if (p.prop_hr) {
+      for (int r = tid; r < R; r += 256) {
+        float s = 0.f;
+        for (int k = 0; k < A; ++k) s += sdWh[k] * p.Wr[(size_t)k * R + r];
+        sdh[r] += s;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int r = tid; r < R; r += 256) sdh[r] = 0.f;
+    __syncthreads();
+  }
+  if (!p.do_lstm) return;
+  for (int u = tid; u < R; u += 256) {
+    const size_t o = (size_t)b * R + u;
+    const float dh = p.dHr[o] + sdh[u];
+    const float* a = p.acts + (size_t)b * 4 * R + u;
+    const LstmGrad g = lstm_point_bwd(dh, p.first_lstm ? 0.f : p.dc_carry[o], a[0], a[R], a[2 * R], a[3 * R],
+                                      p.c[o], p.c_prev ? p.c_prev[o] : 0.f);
+    float* dg = p.dG + (size_t)b * 4 * R + u;
+    dg[0] = g.di; dg[R] = g.df; dg[2 * R] = g.dg; dg[3 * R] = g.d_o;
+    p.dc_carry[o] = g.dc_prev;
+  }
+}
+
+// =============================================================================================
+// norms, clipping and multi-tensor Adam (train.py:69,103,129,149,186,270-273)
+// =============================================================================================
+struct TensorDesc { float* p; float* g; float* m; float* v; float* vmax; int n; int chunk0; int nchunks; int pad; };
+#define RN_CHUNK 8192
+
+// partial[chunk] = sum over the chunk of p^2 (mode 0) or (g + coef * p / ||p||)^2 (mode 1)
+__global__ __launch_bounds__(256) void sumsq_chunk_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                          int mode, const float* __restrict__ pnorm, float coef,
+                                                          float* __restrict__ partial) {
+  __shared__ float sm[4];
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  float k = 0.f;
+  if (mode == 1) { const float nrm = pnorm[ch.x]; k = nrm > 0.f ? coef / nrm : 0.f; }
+  float s = 0.f;
+  for (int i = ch.y + threadIdx.x; i < end; i += 256) {
+    const float x = mode == 0 ? td.p[i] : td.g[i] + k * td.p[i];
+    s += x * x;
+  }
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// one block per tensor: out[tensor] = sqrt(sum of its chunk partials)   (deterministic order)
+__global__ __launch_bounds__(256) void tensor_norm_kernel(const TensorDesc* __restrict__ tab, const float* __restrict__ partial,
+                                                          float* __restrict__ out_norm) {
+  __shared__ float sm[4];
+  const TensorDesc td = tab[blockIdx.x];
+  float s = 0.f;
+  for (int c = threadIdx.x; c < td.nchunks; c += 256) s += partial[td.chunk0 + c];
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) out_norm[blockIdx.x] = sqrtf(s);
+}
+// total = sqrt(sum_i norms[i]^2), clip coefficient of torch.nn.utils.clip_grad_norm_; also sum of norms.
+__global__ void norm_finalize_kernel(const float* __restrict__ norms, int n, float max_norm, float* total_out,
+                                     float* clip_out, float* sum_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float ss = 0.f, sn = 0.f;
+  for (int i = 0; i < n; ++i) { ss += norms[i] * norms[i]; sn += norms[i]; }
+  const float tot = sqrtf(ss);
+  if (total_out) *total_out = tot;
+  if (sum_out) *sum_out = sn;
+  if (clip_out) {
+    float c = 1.f;
+    if (max_norm > 0.f) { c = max_norm / (tot + 1e-6f); if (c > 1.f) c = 1.f; }
+    *clip_out = c;
+  }
+}
+// g += coef * p / ||p||   (autograd-compatible path: the regulariser's gradient, train.py:69-70)
+__global__ __launch_bounds__(256) void add_reg_grad_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                           const float* __restrict__ pnorm, float coef) {
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  const float nrm = pnorm[ch.x];
+  const float k = nrm > 0.f ? coef / nrm : 0.f;
+  for (int i = ch.y + threadIdx.x; i < end; i += 256) td.g[i] += k * td.p[i];
+}
+
+// g *= *clip   (clip_grad_norm_ in place)
+__global__ __launch_bounds__(256) void scale_grads_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                          const float* __restrict__ clip) {
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  const float c = *clip;
+  if (c == 1.f) return;
+  for (int i = ch.y + threadIdx.x; i < end; i += 256) td.g[i] *= c;
+}
+
+struct AdamHyper { double lr, beta1, beta2; float eps, wd, one_m_b1, beta2f, one_m_b2; int amsgrad; float reg_coef; };
+// torch.optim.Adam (single-tensor form of torch 2.10): g' = clip * (g + reg) + wd * p ;
+// m <- lerp(m, g', 1-b1) ; v <- b2 v + (1-b2) g'^2 ; [vmax <- max(vmax, v)] ;
+// p <- p - (lr / bc1) * m / (sqrt(v̂) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                         AdamHyper hp, const float* __restrict__ pnorm,
+                                                         const float* __restrict__ clip, const int32_t* __restrict__ step_ptr) {
+  __shared__ float sc[2];
+  if (threadIdx.x == 0) {
+    const double st = (double)(*step_ptr);
+    const double bc1 = 1.0 - pow(hp.beta1, st);
+    const double bc2 = 1.0 - pow(hp.beta2, st);
+    sc[0] = (float)(hp.lr / bc1);
+    sc[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = sc[0], bc2s = sc[1];
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  const float nrm = pnorm ? pnorm[ch.x] : 0.f;
+  const float k = (nrm > 0.f) ? hp.reg_coef / nrm : 0.f;
+  const float cl = clip ? *clip : 1.f;
+  for (int i = ch.y + threadIdx.x; i < end; i += 256) {
+    const float p = td.p[i];
+    float g = (td.g[i] + k * p) * cl;
+    g = g + hp.wd * p;
+    float m = td.m[i];
+    m = m + hp.one_m_b1 * (g - m);
+    float v = td.v[i] * hp.beta2f + hp.one_m_b2 * g * g;
+    td.m[i] = m; td.v[i] = v;
+    float vh = v;
+    if (hp.amsgrad) { vh = fmaxf(td.vmax[i], v); td.vmax[i] = vh; }
+    const float denom = sqrtf(vh) / bc2s + hp.eps;
+    td.p[i] = p - step_size * (m / denom);
+  }
+}

@@ -1,0 +1,28 @@
+// Host-side declarations shared by the translation units of librecnet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RN_PREC_F32 0
+#define RN_PREC_BF16 1
+
+// ---- gemm.hip
+int rn_gemm_bk(int prec);
+int rn_pick_splitk(int prec, int M, int N, int K, int max_split);
+int rn_effective_splitk(int prec, int K, int splitk);
+// a_bf16 / b_bf16: operand memory holds bf16 (pre-packed) instead of fp32.  reduce_after: when splitk > 1,
+// run the slab reduction (otherwise the caller's fused consumer sums ws[z][M][N] itself).
+void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
+                    int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st);
+
+// ---- dropout descriptor handed to kernels: seed lives in device memory so a captured graph can be
+// replayed with a new seed.
+struct DropDesc {
+  const uint32_t* seed;   // device
+  uint32_t site;
+  uint32_t thr;           // floor(p * 2^32); 0 = disabled
+  float inv_keep;         // 1 / (1 - p)
+  int Bg;                 // global batch size
+  int boff;               // global index of local caption 0
+};

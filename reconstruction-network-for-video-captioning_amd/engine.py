@@ -1,0 +1,283 @@
+"""Engine: one recnet_handle (C ABI) plus the device memory it works in.
+
+PyTorch is used here for what the task allows it for — device allocations, the current stream
+and (in dp.py) torch.distributed.  Every computation is a call into librecnet_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import DECODER_KEYS, REC_KEYS
+
+_KIND = {None: _lib.REC_NONE, "none": _lib.REC_NONE, "global": _lib.REC_GLOBAL, "local": _lib.REC_LOCAL}
+_PREC = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_tensor(t, shape, dtype, name):
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (HIP) tensor — the RecNet HIP path has no CPU fallback" % name)
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+        raise RuntimeError("%s: expected contiguous %s %s, got %s %s" % (name, dtype, tuple(shape), t.dtype,
+                                                                          tuple(t.shape)))
+
+
+class FlatState:
+    """A set of named fp32 tensors carved out of ONE flat device buffer (so a data-parallel
+    all-reduce is a single collective over `flat`)."""
+
+    def __init__(self, shapes, device):
+        self.shapes = dict(shapes)
+        n = 0
+        self.offsets = {}
+        for k, s in self.shapes.items():
+            self.offsets[k] = n
+            cnt = 1
+            for d in s:
+                cnt *= d
+            n += (cnt + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.views = {}
+        for k, s in self.shapes.items():
+            cnt = 1
+            for d in s:
+                cnt *= d
+            self.views[k] = self.flat[self.offsets[k]:self.offsets[k] + cnt].view(s)
+
+    def struct(self, cls, keys):
+        st = cls()
+        for k in keys:
+            setattr(st, k.replace(".", "_"), self.views[k].data_ptr() if k in self.views else None)
+        return st
+
+
+def _struct_from(cls, keys, tensors):
+    st = cls()
+    for k in keys:
+        t = tensors.get(k)
+        setattr(st, k.replace(".", "_"), None if t is None else t.data_ptr())
+    return st
+
+
+class Engine:
+    """dims: dict with B,F,D,E,H,A,V and (optional) R, RA.  kind: None | 'global' | 'local'."""
+
+    def __init__(self, dims, kind=None, precision="bf16", hyper=None, device=None, global_batch=None,
+                 batch_offset=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("RecNet HIP engine needs a GPU (torch.cuda.is_available() is False)")
+        self.device = torch.device(device if device is not None else "cuda")
+        hy = dict(embedding_scale=1.0, embedding_dropout=0.5, decoder_out_dropout=0.5,
+                  reconstructor_decoder_dropout=0.5, decoder_learning_rate=1e-5, reconstructor_learning_rate=1e-6,
+                  decoder_weight_decay=1e-5, reconstructor_weight_decay=1e-5, decoder_use_amsgrad=True,
+                  reconstructor_use_amsgrad=False, gradient_clip=50.0, decoder_lambda_reg=1e-3,
+                  reconstructor_lambda_reg=1e-2, lambda_recon=1.0, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8,
+                  caption_max_len=30)
+        hy.update(hyper or {})
+        self.hyper = hy
+        self.dims = dict(dims)
+        self.kind = kind if kind not in ("none",) else None
+        self.precision = precision
+        c = _lib.Config()
+        c.batch_size = dims["B"]; c.encoder_output_len = dims["F"]; c.encoder_output_size = dims["D"]
+        c.embedding_size = dims["E"]; c.decoder_hidden_size = dims["H"]; c.decoder_attn_size = dims["A"]
+        c.n_vocabs = dims["V"]
+        c.reconstructor_hidden_size = dims.get("R", dims["D"]) if self.kind else 0
+        c.reconstructor_attn_size = dims.get("RA", 0) if self.kind == "local" else 0
+        c.caption_max_len = hy["caption_max_len"]
+        c.reconstructor_type = _KIND[self.kind]
+        c.precision = _PREC[precision]
+        c.global_batch_size = global_batch if global_batch else dims["B"]
+        c.batch_offset = batch_offset
+        c.decoder_use_amsgrad = int(bool(hy["decoder_use_amsgrad"]))
+        c.reconstructor_use_amsgrad = int(bool(hy["reconstructor_use_amsgrad"]))
+        for k in ("embedding_scale", "embedding_dropout", "decoder_out_dropout", "reconstructor_decoder_dropout",
+                  "decoder_lambda_reg", "reconstructor_lambda_reg", "lambda_recon", "decoder_learning_rate",
+                  "reconstructor_learning_rate", "decoder_weight_decay", "reconstructor_weight_decay", "adam_beta1",
+                  "adam_beta2", "adam_eps"):
+            setattr(c, k, float(hy[k]))
+        c.gradient_clip = float(hy["gradient_clip"] or 0.0)
+        self.cfg = c
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.recnet_create(C.byref(c), C.byref(self.handle)), "recnet_create")
+        nbytes = self.lib.recnet_workspace_bytes(self.handle)
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            off = (-self.workspace.data_ptr()) % 256
+            self._ws_ptr = self.workspace.data_ptr() + off
+            _lib.check(self.lib.recnet_bind_workspace(self.handle, C.c_void_p(self._ws_ptr), C.c_size_t(nbytes)),
+                       "recnet_bind_workspace")
+            self.scalars = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._keep = []
+        self.T = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) is not None and self.handle.value:
+                self.lib.recnet_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ binding
+    def decoder_shapes(self):
+        d = self.dims
+        return {"attn_b": (d["A"],), "embedding.weight": (d["V"], d["E"]), "attn_W.weight": (d["A"], d["H"]),
+                "attn_U.weight": (d["A"], d["D"]), "attn_w.weight": (1, d["A"]),
+                "rnn.weight_ih_l0": (4 * d["H"], d["E"] + d["D"]), "rnn.weight_hh_l0": (4 * d["H"], d["H"]),
+                "rnn.bias_ih_l0": (4 * d["H"],), "rnn.bias_hh_l0": (4 * d["H"],),
+                "out.weight": (d["V"], d["H"]), "out.bias": (d["V"],)}
+
+    def rec_shapes(self):
+        d = self.dims
+        R, H = d.get("R", d["D"]), d["H"]
+        s = {}
+        if self.kind == "local":
+            RA = d["RA"]
+            s.update({"attn_b": (RA,), "attn_W.weight": (RA, R), "attn_U.weight": (RA, H), "attn_w.weight": (1, RA)})
+        s.update({"rnn.weight_ih_l0": (4 * R, H if self.kind == "local" else 2 * H), "rnn.weight_hh_l0": (4 * R, R),
+                  "rnn.bias_ih_l0": (4 * R,), "rnn.bias_hh_l0": (4 * R,), "out.weight": (R, R), "out.bias": (R,)})
+        return s
+
+    def bind_decoder(self, params, grads=None, exp_avg=None, exp_avg_sq=None, max_exp_avg_sq=None):
+        """params etc.: dict key -> CUDA fp32 tensor (state_dict names)."""
+        shp = self.decoder_shapes()
+        for k in DECODER_KEYS:
+            _chk_tensor(params[k], shp[k], torch.float32, "decoder." + k)
+        sts = [_struct_from(_lib.DecoderTensors, DECODER_KEYS, params)]
+        for grp in (grads, exp_avg, exp_avg_sq, max_exp_avg_sq):
+            if grp is not None:
+                for k in DECODER_KEYS:
+                    _chk_tensor(grp[k], shp[k], torch.float32, "decoder state " + k)
+            sts.append(None if grp is None else _struct_from(_lib.DecoderTensors, DECODER_KEYS, grp))
+        self._keep.append((params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq))
+        args = [C.byref(s) if s is not None else None for s in sts]
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.recnet_bind_decoder(self.handle, *args), "recnet_bind_decoder")
+
+    def bind_reconstructor(self, params, grads=None, exp_avg=None, exp_avg_sq=None, max_exp_avg_sq=None):
+        shp = self.rec_shapes()
+        for k in shp:
+            _chk_tensor(params[k], shp[k], torch.float32, "reconstructor." + k)
+        sts = [_struct_from(_lib.ReconstructorTensors, REC_KEYS, params)]
+        for grp in (grads, exp_avg, exp_avg_sq, max_exp_avg_sq):
+            if grp is not None:
+                for k in shp:
+                    _chk_tensor(grp[k], shp[k], torch.float32, "reconstructor state " + k)
+            sts.append(None if grp is None else _struct_from(_lib.ReconstructorTensors, REC_KEYS, grp))
+        self._keep.append((params, grads, exp_avg, exp_avg_sq, max_exp_avg_sq))
+        args = [C.byref(s) if s is not None else None for s in sts]
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.recnet_bind_reconstructor(self.handle, *args), "recnet_bind_reconstructor")
+
+    def set_shard(self, global_batch, batch_offset):
+        _lib.check(self.lib.recnet_set_shard(self.handle, global_batch, batch_offset), "recnet_set_shard")
+
+    # ------------------------------------------------------------------ hot path
+    def pack_weights(self):
+        _lib.check(self.lib.recnet_pack_weights(self.handle, _stream()), "recnet_pack_weights")
+
+    def decoder_step(self, tokens, h_in, c_in, enc, train=False, seed=0, t=0):
+        d = self.dims
+        B = d["B"]
+        _chk_tensor(tokens, (B,), torch.int64, "tokens")
+        _chk_tensor(enc, (B, d["F"], d["D"]), torch.float32, "encoder_outputs")
+        logits = torch.empty(B, d["V"], dtype=torch.float32, device=self.device)
+        h_out = torch.empty(B, d["H"], dtype=torch.float32, device=self.device)
+        c_out = torch.empty_like(h_out)
+        _lib.check(self.lib.recnet_decoder_step(self.handle, _ptr(tokens), _ptr(h_in), _ptr(c_in), _ptr(enc),
+                                                _ptr(logits), _ptr(h_out), _ptr(c_out), int(train), seed & 0xFFFFFFFF,
+                                                int(t), _stream()), "recnet_decoder_step")
+        return logits, h_out, c_out
+
+    def forward_decoder(self, enc, targets, T, step_weight, train=True, seed=0, want_hiddens=True):
+        d = self.dims
+        B = d["B"]
+        _chk_tensor(enc, (B, d["F"], d["D"]), torch.float32, "encoder_outputs")
+        _chk_tensor(targets, (self.hyper["caption_max_len"] + 1, B), torch.int64, "targets")
+        _chk_tensor(step_weight, (T,), torch.float32, "step_weight")
+        hid = torch.empty(T, 1, B, d["H"], dtype=torch.float32, device=self.device) if want_hiddens else None
+        _lib.check(self.lib.recnet_forward_decoder(self.handle, _ptr(enc), _ptr(targets), int(T), _ptr(step_weight),
+                                                   int(train), seed & 0xFFFFFFFF, _ptr(hid), _ptr(self.scalars),
+                                                   _stream()), "recnet_forward_decoder")
+        self.T = T
+        return hid
+
+    def forward_reconstructor(self, enc, hiddens, T, train=True, seed=0):
+        d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
+        if hiddens is not None:
+            _chk_tensor(hiddens, (T, 1, d["B"], d["H"]), torch.float32, "decoder_hiddens")
+        _lib.check(self.lib.recnet_forward_reconstructor(self.handle, _ptr(enc), _ptr(hiddens), int(T), int(train),
+                                                         seed & 0xFFFFFFFF, _ptr(self.scalars), _stream()),
+                   "recnet_forward_reconstructor")
+        self.T = T
+
+    def backward_reconstructor(self, enc, grad_scale=1.0, want_dhiddens=True):
+        d = self.dims
+        dh = torch.empty(self.T, 1, d["B"], d["H"], dtype=torch.float32, device=self.device) if want_dhiddens else None
+        _lib.check(self.lib.recnet_backward_reconstructor(self.handle, _ptr(enc), float(grad_scale), _ptr(dh),
+                                                          _stream()), "recnet_backward_reconstructor")
+        return dh
+
+    def backward_decoder(self, enc, targets, dhiddens=None, grad_scale=1.0):
+        if dhiddens is not None:
+            d = self.dims
+            _chk_tensor(dhiddens, (self.T, 1, d["B"], d["H"]), torch.float32, "dhiddens")
+        _lib.check(self.lib.recnet_backward_decoder(self.handle, _ptr(enc), _ptr(targets), _ptr(dhiddens),
+                                                    float(grad_scale), _stream()), "recnet_backward_decoder")
+
+    def add_reg_grad(self, which, grad_scale=1.0):
+        _lib.check(self.lib.recnet_add_reg_grad(self.handle, int(which), float(grad_scale), _stream()),
+                   "recnet_add_reg_grad")
+
+    def clip_grad_norm(self, which, max_norm):
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.recnet_clip_grad_norm(self.handle, int(which), float(max_norm), _ptr(out), _stream()),
+                   "recnet_clip_grad_norm")
+        return out
+
+    def optimizer_step(self, step, flags):
+        _lib.check(self.lib.recnet_optimizer_step(self.handle, int(step), int(flags), _ptr(self.scalars), _stream()),
+                   "recnet_optimizer_step")
+
+    def train_step_fwd_bwd(self, enc, targets, T, step_weight, seed):
+        _lib.check(self.lib.recnet_train_step_fwd_bwd(self.handle, _ptr(enc), _ptr(targets), int(T),
+                                                      _ptr(step_weight), seed & 0xFFFFFFFF, _ptr(self.scalars),
+                                                      _stream()), "recnet_train_step_fwd_bwd")
+        self.T = T
+
+    def train_step(self, enc, targets, T, step_weight, seed, step):
+        _lib.check(self.lib.recnet_train_step(self.handle, _ptr(enc), _ptr(targets), int(T), _ptr(step_weight),
+                                              seed & 0xFFFFFFFF, int(step), _ptr(self.scalars), _stream()),
+                   "recnet_train_step")
+        self.T = T
+
+    def scalar_dict(self):
+        """Host copy of the device scalars (synchronises)."""
+        v = self.scalars.tolist()
+        return dict(zip(_lib.SCALAR_NAMES, v))
+
+    def gemm(self, A, B, a_col=False, b_col=False, bias=None, alpha=1.0, C_out=None, accumulate=False, splitk=1,
+             M=None, N=None, K=None):
+        """Test hook: C[M,N] (+)= alpha * op(A) op(B)^T + bias through the MFMA GEMM."""
+        if M is None:
+            M = A.shape[1] if a_col else A.shape[0]
+            K = A.shape[0] if a_col else A.shape[1]
+            N = B.shape[1] if b_col else B.shape[0]
+        if C_out is None:
+            C_out = torch.zeros(M, N, dtype=torch.float32, device=A.device)
+        ws = torch.empty(max(1, splitk) * M * N, dtype=torch.float32, device=A.device) if splitk > 1 else None
+        _lib.check(self.lib.recnet_gemm(_PREC[self.precision], _ptr(A), int(a_col), A.stride(0), _ptr(B), int(b_col),
+                                        B.stride(0), _ptr(C_out), C_out.stride(0), _ptr(bias), M, N, K, float(alpha),
+                                        int(accumulate), int(splitk), _ptr(ws), _stream()), "recnet_gemm")
+        return C_out

@@ -1,0 +1,166 @@
+"""Host-side mirrors of the reference's three nn.Modules (same class names, constructor keywords,
+`forward` step signatures and state_dict keys/shapes — SURVEY.md §8b), so that
+`load_state_dict(checkpoint['dec'])` (eval.py:204) works in both directions.
+
+They hold only the fp32 master parameters.  `forward` is the reference's per-time-step API and is
+served by the HIP library (recnet_decoder_step); the train step does not go through it — it uses the
+sequence-level entry points in api.py.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+
+
+class _Weights(nn.Module):
+    """A bag of named parameters (gives state_dict keys like 'rnn.weight_ih_l0')."""
+
+    def __init__(self, **shapes):
+        super().__init__()
+        for name, shape in shapes.items():
+            self.register_parameter(name, nn.Parameter(torch.empty(*shape)))
+
+
+def _uniform(t, k):
+    with torch.no_grad():
+        t.uniform_(-k, k)
+
+
+def _lstm_only(model_name, n_layers, what):
+    if model_name != "LSTM":
+        raise NotImplementedError("%s: the HIP path implements model_name='LSTM' (got %r); GRU is a SURVEY §8f "
+                                  "follow-up" % (what, model_name))
+    if n_layers != 1:
+        raise NotImplementedError("%s: n_layers must be 1 (got %r)" % (what, n_layers))
+
+
+class Decoder(nn.Module):
+    """models/decoder.py:6-70."""
+
+    def __init__(self, model_name, n_layers, encoder_size, embedding_size, embedding_scale, hidden_size,
+                 attn_size, output_size, embedding_dropout, dropout, out_dropout, precision="bf16"):
+        super().__init__()
+        _lstm_only(model_name, n_layers, "Decoder")
+        self.model_name, self.n_layers = model_name, n_layers
+        self.encoder_size, self.embedding_size, self.embedding_scale = encoder_size, embedding_size, embedding_scale
+        self.hidden_size, self.attn_size, self.output_size = hidden_size, attn_size, output_size
+        self.embedding_dropout_p, self.dropout_p, self.out_dropout_p = embedding_dropout, dropout, out_dropout
+        self.precision = precision
+        H, E, D, A, V = hidden_size, embedding_size, encoder_size, attn_size, output_size
+        # registration order == the reference's, so parameters() / state_dict() enumerate identically
+        self.attn_b = nn.Parameter(torch.ones(A))                       # decoder.py:27
+        self.embedding = _Weights(weight=(V, E))
+        self.attn_W = _Weights(weight=(A, H))
+        self.attn_U = _Weights(weight=(A, D))
+        self.attn_w = _Weights(weight=(1, A))
+        self.rnn = _Weights(weight_ih_l0=(4 * H, E + D), weight_hh_l0=(4 * H, H), bias_ih_l0=(4 * H,),
+                            bias_hh_l0=(4 * H,))
+        self.out = _Weights(weight=(V, H), bias=(V,))
+        self.reset_parameters()
+        self._step_engines = {}
+        self._calls = 0
+        self.dropout_seed = 42
+
+    def reset_parameters(self):
+        """torch's default initialisers for Embedding / Linear / LSTM."""
+        H = self.hidden_size
+        with torch.no_grad():
+            self.attn_b.fill_(1.0)
+            self.embedding.weight.normal_(0, 1)
+        _uniform(self.attn_W.weight, 1 / math.sqrt(H))
+        _uniform(self.attn_U.weight, 1 / math.sqrt(self.encoder_size))
+        _uniform(self.attn_w.weight, 1 / math.sqrt(self.attn_size))
+        for p in self.rnn.parameters():
+            _uniform(p, 1 / math.sqrt(H))
+        _uniform(self.out.weight, 1 / math.sqrt(H))
+        _uniform(self.out.bias, 1 / math.sqrt(H))
+
+    def dims(self, B, F):
+        return dict(B=B, F=F, D=self.encoder_size, E=self.embedding_size, H=self.hidden_size, A=self.attn_size,
+                    V=self.output_size)
+
+    def hyper(self):
+        return dict(embedding_scale=self.embedding_scale, embedding_dropout=self.embedding_dropout_p,
+                    decoder_out_dropout=self.out_dropout_p)
+
+    def named_tensors(self):
+        return {k: v for k, v in self.named_parameters()}
+
+    def forward(self, input, hidden, encoder_outputs):
+        """One decode step — Decoder.forward, decoder.py:45-70.  input [1,B] int64, hidden=(h,c) each
+        [1,B,H], encoder_outputs [B,F,D] -> (logits [B,V], (h',c'))."""
+        B, F = encoder_outputs.shape[0], encoder_outputs.shape[1]
+        key = (B, F, encoder_outputs.device)
+        eng = self._step_engines.get(key)
+        if eng is None:
+            eng = Engine(self.dims(B, F), None, self.precision, self.hyper(), device=encoder_outputs.device)
+            eng.bind_decoder({k: v.data for k, v in self.named_tensors().items()})
+            self._step_engines[key] = eng
+        eng.pack_weights()          # parameters may have been updated since the last call
+        h, c = hidden
+        logits, h2, c2 = eng.decoder_step(input.reshape(-1).contiguous(), h[-1].contiguous(), c[-1].contiguous(),
+                                          encoder_outputs.contiguous(), train=self.training,
+                                          seed=self.dropout_seed, t=self._calls)
+        self._calls += 1
+        return logits, (h2.unsqueeze(0), c2.unsqueeze(0))
+
+
+class _Reconstructor(nn.Module):
+    kind = None
+
+    def named_tensors(self):
+        return {k: v for k, v in self.named_parameters()}
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(
+            "the per-step reconstructor API is only used inside the reference's own time loops "
+            "(train.py:93-94,122-123); use forward_global_reconstructor / forward_local_reconstructor")
+
+
+class GlobalReconstructor(_Reconstructor):
+    """models/global_reconstructor.py:6-46."""
+    kind = "global"
+
+    def __init__(self, model_name, n_layers, decoder_hidden_size, hidden_size, dropout, decoder_dropout,
+                 caption_max_len, precision="bf16"):
+        super().__init__()
+        _lstm_only(model_name, n_layers, "GlobalReconstructor")
+        self.model_name, self.n_layers = model_name, n_layers
+        self.decoder_hidden_size, self.hidden_size = decoder_hidden_size, hidden_size
+        self.dropout_p, self.decoder_dropout_p, self.caption_max_len = dropout, decoder_dropout, caption_max_len
+        self.precision = precision
+        H, R = decoder_hidden_size, hidden_size
+        self.rnn = _Weights(weight_ih_l0=(4 * R, 2 * H), weight_hh_l0=(4 * R, R), bias_ih_l0=(4 * R,),
+                            bias_hh_l0=(4 * R,))
+        self.out = _Weights(weight=(R, R), bias=(R,))
+        for p in self.parameters():
+            _uniform(p, 1 / math.sqrt(R))
+
+
+class LocalReconstructor(_Reconstructor):
+    """models/local_reconstructor.py:6-55."""
+    kind = "local"
+
+    def __init__(self, model_name, n_layers, decoder_hidden_size, hidden_size, dropout, decoder_dropout, attn_size,
+                 precision="bf16"):
+        super().__init__()
+        _lstm_only(model_name, n_layers, "LocalReconstructor")
+        self.model_name, self.n_layers = model_name, n_layers
+        self.decoder_hidden_size, self.hidden_size = decoder_hidden_size, hidden_size
+        self.dropout_p, self.decoder_dropout_p, self.attn_size = dropout, decoder_dropout, attn_size
+        self.precision = precision
+        H, R, A = decoder_hidden_size, hidden_size, attn_size
+        self.attn_b = nn.Parameter(torch.ones(A))                       # local_reconstructor.py:19
+        self.attn_W = _Weights(weight=(A, R))
+        self.attn_U = _Weights(weight=(A, H))
+        self.attn_w = _Weights(weight=(1, A))
+        self.rnn = _Weights(weight_ih_l0=(4 * R, H), weight_hh_l0=(4 * R, R), bias_ih_l0=(4 * R,),
+                            bias_hh_l0=(4 * R,))
+        self.out = _Weights(weight=(R, R), bias=(R,))
+        _uniform(self.attn_W.weight, 1 / math.sqrt(R))
+        _uniform(self.attn_U.weight, 1 / math.sqrt(H))
+        _uniform(self.attn_w.weight, 1 / math.sqrt(A))
+        for p in list(self.rnn.parameters()) + list(self.out.parameters()):
+            _uniform(p, 1 / math.sqrt(R))

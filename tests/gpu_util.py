@@ -1,0 +1,67 @@
+"""Shared helpers for the -m gpu parity tests: build the product's models from golden / formula
+parameters and compare against the CPU oracle."""
+import numpy as np
+import torch
+
+import recnet_amd as R
+from oracle import recnet_oracle as O
+from tests import golden_util as GU
+
+TOL = {
+    # precision: (loss rel, hidden abs, per-tensor grad ||d||/||g||, param abs after steps)
+    "f32": dict(loss=2e-5, hid=2e-5, grad=2e-4, param=2e-6),
+    "bf16": dict(loss=3e-3, hid=1.5e-2, grad=4e-2, param=2e-5),
+}
+
+
+def make_models(dims, kind, precision, decP, recP, device="cuda", batch=None):
+    B, F, D, V, E, H, A, RA = dims
+    C = R.make_config(batch_size=B, encoder_output_len=F, encoder_output_size=D, embedding_size=E,
+                      decoder_hidden_size=H, decoder_attn_size=A, use_recon=kind is not None,
+                      reconstructor_type=kind or "local", reconstructor_hidden_size=D,
+                      reconstructor_attn_size=RA, precision=precision, device=device)
+    dec = R.build_decoder(V, C)
+    dec["model"].load_state_dict({k: v.clone() for k, v in decP.items()})
+    rec = None
+    if kind:
+        rec = R.build_reconstructor(C)
+        rec["model"].load_state_dict({k: v.clone() for k, v in recP.items()})
+    return C, dec, rec
+
+
+def load_case(name):
+    g = GU.load(name)
+    dims = [int(x) for x in g["meta_dims"]]
+    B, F, D, V, E, H, A, RA = dims
+    kind = "global" if "global" in name else ("local" if "local" in name else None)
+    fs = int(g["meta_formula_seed"])
+    if fs >= 0:
+        decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), fs)
+        recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), fs + 1) if kind else None
+        enc, targets = GU.make_batch(B, F, D, V, g["meta_lens"], int(g["meta_batch_seed"]))
+    else:
+        decP, recP = GU.group(g, "dec_init"), (GU.group(g, "rec_init") if kind else None)
+        enc, targets = torch.from_numpy(g["enc"]), torch.from_numpy(g["targets"])
+    return g, dims, kind, decP, recP, enc, targets
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
+
+
+def oracle_grads(decP, recP, kind, enc, targets, train, seed, B_global=None, b_offset=0):
+    """Reference gradients (incl. the regulariser term) from the CPU oracle's autograd."""
+    st = O.TrainState(decP, recP, kind)
+    drop = O.Dropper("hash", seed=seed) if train else O.Dropper("eval")
+    masks = targets > 0
+    dl, rl, hid, ce, mse = st.losses(enc, targets, masks, drop)
+    loss = dl if rl is None else dl + rl
+    loss.backward()
+    out = dict(dec_loss=float(dl), dec_ce=float(ce), hiddens=hid.detach().numpy(),
+               dec_grad={k: v.grad.numpy().copy() for k, v in st.dec.items()})
+    if rl is not None:
+        out.update(rec_loss=float(rl), rec_mse=float(mse),
+                   rec_grad={k: v.grad.numpy().copy() for k, v in st.rec.items()})
+    return out

@@ -1,0 +1,162 @@
+"""Parity of the HIP train-step path (through the C ABI) with
+  (a) the golden vectors produced by the reference itself (tests/golden/*.npz) and
+  (b) the CPU oracle on the same seeded inputs.
+Tolerances per precision are in tests/gpu_util.TOL (fp32-MFMA path: tight; bf16-MFMA path: the
+bf16 operand-rounding bars of SURVEY.md §8d)."""
+import numpy as np
+import pytest
+import torch
+
+import recnet_amd as R
+from oracle import recnet_oracle as O
+from tests import golden_util as GU
+from tests.gpu_util import TOL, load_case, make_models, oracle_grads, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SMALL = ["dec_eval", "dec_train", "dec_T31", "dec_T4_samelen", "global_train", "global_eval", "local_train",
+         "local_eval", "local_T31"]
+FULL = ["full_dec_B8", "full_global_B8", "full_local_B8"]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("name", SMALL + FULL)
+def test_step_api_matches_reference(name, prec):
+    """Decoder.forward (decoder.py:45-70) step by step: logits and (h, c) against the golden vectors."""
+    g, dims, kind, decP, recP, enc, targets = load_case(name)
+    C, dec, _ = make_models(dims, None, prec, decP, None)
+    model = dec["model"]
+    train = bool(int(g["meta_train_mode"]))
+    model.train(train)
+    model.dropout_seed = int(g["meta_drop_seed"])
+    B, H = dims[0], dims[5]
+    encd = enc.cuda()
+    tok = torch.full((1, B), 1, dtype=torch.long, device="cuda")
+    hid = (torch.zeros(1, B, H, device="cuda"), torch.zeros(1, B, H, device="cuda"))
+    tol = TOL[prec]
+    for t in range(int(g["T"])):
+        logits, hid = model(tok, hid, encd)
+        tok = targets[t].view(1, -1).cuda()
+        assert np.abs(hid[0][0].cpu().numpy() - g["step_h"][t]).max() <= tol["hid"], t
+        assert np.abs(hid[1][0].cpu().numpy() - g["step_c"][t]).max() <= 2 * tol["hid"], t
+        if "step_logits" in g:
+            ref = g["step_logits"][t]
+            assert np.abs(logits.cpu().numpy() - ref).max() <= tol["hid"] * 4 * max(1.0, np.abs(ref).max()), t
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("name", SMALL + FULL)
+def test_autograd_api_losses_and_grads(name, prec):
+    """forward_decoder / forward_*_reconstructor + loss.backward() (train.py:250-268) against the goldens:
+    losses, hidden states, every parameter gradient (norm-regulariser term included)."""
+    g, dims, kind, decP, recP, enc, targets = load_case(name)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP)
+    train = bool(int(g["meta_train_mode"]))
+    seed = int(g["meta_drop_seed"])
+    dec["model"].train(train)
+    encd, tg = enc.cuda(), targets.cuda()
+    dl, hid, _ = R.forward_decoder(dec, encd, tg, tg > 0, 1.0, seed=seed)
+    loss = dl
+    if kind:
+        rec["model"].train(train)
+        fwd = R.forward_global_reconstructor if kind == "global" else R.forward_local_reconstructor
+        rl = fwd(hid, encd, rec, seed=seed)
+        loss = dl + 1.0 * rl
+    dec["optimizer"].zero_grad()
+    if kind:
+        rec["optimizer"].zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    tol = TOL[prec]
+    assert hid.shape[0] == int(g["T"])
+    assert np.abs(hid.detach().cpu().numpy() - g["hiddens"]).max() <= tol["hid"]
+    assert abs(float(dl) - float(g["dec_loss"])) <= tol["loss"] * abs(float(g["dec_loss"]))
+    sc = dec["_state"].engines[("dec", dims[0], dims[1])].scalar_dict()
+    assert abs(sc["dec_ce"] - float(g["dec_ce"])) <= tol["loss"] * max(abs(float(g["dec_ce"])), 1e-3)
+    if kind:
+        assert abs(float(rl) - float(g["rec_loss"])) <= tol["loss"] * abs(float(g["rec_loss"]))
+    bad = []
+    for grp, md in (("dec", dec), ("rec", rec)):
+        if md is None:
+            continue
+        for k, p in md["model"].named_parameters():
+            gg = p.grad.detach().cpu().numpy()
+            ref_n = float(g["%s_gnorm/%s" % (grp, k)])
+            key = "%s_grad/%s" % (grp, k)
+            if key in g:
+                e = rel_err(gg, g[key])
+            else:
+                e = abs(np.linalg.norm(gg.astype(np.float64)) - ref_n) / max(ref_n, 1e-12)
+                sl = g["%s_gslice/%s" % (grp, k)]
+                e = max(e, float(np.abs(gg.reshape(-1)[:64] - sl).max() / max(np.abs(sl).max(), 1e-12)) * 0.25)
+            if e > tol["grad"]:
+                bad.append((grp, k, e))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["dec_train", "global_train", "local_train"])
+def test_fused_train_steps_match_reference_optimizer(name, prec):
+    """TrainStep (train.py:248-273 fused: fwd, bwd, regulariser, clip, AMSGrad + Adam) for 3 iterations:
+    parameters and Adam state against what the reference produced."""
+    g, dims, kind, decP, recP, enc, targets = load_case(name)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP)
+    step = R.TrainStep(dec, rec)
+    encd, tg = enc.cuda(), targets.cuda()
+    T, w = step.prepare(targets.numpy())
+    assert T == int(g["T"])
+    seed0 = int(g["meta_drop_seed"])
+    tol = TOL[prec]
+    n = int(g["meta_n_steps"])
+    for it in range(n):
+        sc = step(encd, tg, T, w, seed=seed0 + it)
+        total = float(sc[6])
+        assert abs(total - float(g["loss_step%d" % it])) <= tol["loss"] * abs(float(g["loss_step%d" % it])), it
+        if it == 0:
+            assert abs(float(sc[7]) - float(g["dec_grad_norm"])) <= max(tol["grad"], 1e-4) * float(g["dec_grad_norm"])
+    for grp, md in (("dec", dec), ("rec", rec)):
+        if md is None:
+            continue
+        for k, v in GU.group(g, "%s_after%d" % (grp, n)).items():
+            got = md["model"].state_dict()[k].cpu().numpy()
+            assert np.abs(got - v.numpy()).max() <= tol["param"], (grp, k)
+    fl = dec["_state"].flat()
+    for k in decP:
+        assert rel_err(fl["exp_avg"].views[k].cpu().numpy(), g["dec_opt/exp_avg/" + k]) <= max(tol["grad"], 1e-4) * 2
+        assert rel_err(fl["exp_avg_sq"].views[k].cpu().numpy(), g["dec_opt/exp_avg_sq/" + k]) <= max(tol["grad"], 1e-4) * 4
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("kind", [None, "global", "local"])
+def test_fused_step_vs_oracle_ragged_shapes(kind, prec):
+    """Shapes that are multiples of nothing (B=7, V=101, E=18, D=R=88, H=36, A=20, F=5), train mode with
+    dropout: fused fwd+bwd gradients against the CPU oracle's autograd."""
+    dims = [7, 5, 88, 101, 18, 36, 20, 12]
+    B, F, D, V, E, H, A, RA = dims
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 11)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 12) if kind else None
+    enc, targets = GU.make_batch(B, F, D, V, [9, 2, 5, 12, 1, 7, 4], 77)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP)
+    step = R.TrainStep(dec, rec)
+    T, w = step.prepare(targets.numpy())
+    step.fwd_bwd(enc.cuda(), targets.cuda(), T, w, seed=5)
+    step.engine.add_reg_grad(0, 1.0)
+    if kind:
+        step.engine.add_reg_grad(1, 1.0)
+    torch.cuda.synchronize()
+    ref = oracle_grads(decP, recP, kind, enc, targets, True, 5)
+    sc = step.engine.scalar_dict()
+    tol = TOL[prec]
+    assert abs(sc["dec_loss"] - ref["dec_loss"]) <= tol["loss"] * abs(ref["dec_loss"])
+    if kind:
+        assert abs(sc["rec_loss"] - ref["rec_loss"]) <= tol["loss"] * abs(ref["rec_loss"])
+    bad = []
+    for grp, md in (("dec", dec), ("rec", rec)):
+        if md is None:
+            continue
+        gv = md["_state"].flat()["grad"].views
+        for k in gv:
+            e = rel_err(gv[k].cpu().numpy(), ref[grp + "_grad"][k])
+            if e > tol["grad"]:
+                bad.append((grp, k, e))
+    assert not bad, bad
