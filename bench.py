@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Benchmark of the RecNet train step (train.py:248-273) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): decoder + GLOBAL reconstructor, B=100 captions per GPU, 28x1536
+features, V=4188, E=468, H=512, A=128, R=1536, LSTM/LSTM, 30-token cap with caption 0 at full length
+(T = 31 decoder steps), dropout 0.5 active, clip 50, AMSGrad/Adam — bf16 MFMA operands, fp32
+accumulate/state.  Synthetic features, random-init weights.  Weak scaling: every rank keeps B=100,
+gradients are SUM-all-reduced over RCCL.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_models(R, cfg_over, V):
+    import torch
+    C = R.make_config(**cfg_over)
+    torch.manual_seed(0)
+    dec = R.build_decoder(V, C)
+    rec = R.build_reconstructor(C) if C.use_recon else None
+    return C, dec, rec
+
+
+def cpu_baseline(kind, B, F, D, V, steps, warmup):
+    """The oracle (CPU port of the reference algorithm, oracle/recnet_oracle.py) timed on this host."""
+    import torch
+    from oracle import recnet_oracle as O
+    torch.manual_seed(0)
+    decP = O.init_decoder_params(V, D=D)
+    recP = O.init_rec_params(kind, R=D) if kind else None
+    st = O.TrainState(decP, recP, kind)
+    enc, targets, masks = O.synthetic_batch(B, F, D, V)
+    drop = O.Dropper("rng")
+    ts = []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        st.step(enc, targets, masks, drop)
+        if i >= warmup:
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return B / med, torch.get_num_threads(), med
+
+
+def roofline(eng, run_step, kind, precision, iters=5):
+    """Dominant kernel = the reconstructor's recurrent-step GEMM (forward form): T-1 dependent launches per
+    step, each streaming the packed recurrent weights once for a 100-row activation block.  `achieved` =
+    algorithmic bytes of one launch / its average duration, measured with hipEvents on the launch stream;
+    bound = HBM (weight streaming; the weights are cache-resident across steps, so this is the
+    conservative bound SURVEY.md §8d names)."""
+    import torch
+    site = 3 if kind else 1
+    torch.cuda.synchronize()
+    n, ms = eng.profile_site(site, run_step, iters)
+    bytes_launch = eng.recurrent_step_bytes(1 if kind else 0)
+    achieved = bytes_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    peak = 8000.0
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": "gemm_kernel<..., TAG=%d> (recurrent-step GEMM, %s)" % (site, "reconstructor fwd" if kind else "decoder fwd"),
+            "launches_timed": n, "avg_launch_us": round(ms * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=100, help="captions per GPU")
+    ap.add_argument("--rec", default="global", choices=["global", "local", "none"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    args = ap.parse_args()
+
+    import torch
+    import recnet_amd as R
+    from recnet_amd.synthetic import synthetic_features, synthetic_targets
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, F, D, V = args.batch, 28, 1536, 4188
+    kind = None if args.rec == "none" else args.rec
+    C, dec, rec = build_models(R, dict(batch_size=B, use_recon=kind is not None, reconstructor_type=kind or "global",
+                                       precision=args.precision, device=str(dev)), V)
+    Bg = B * world
+    targets_g = synthetic_targets(Bg, V, seed=1234)
+    lo, hi = R.shard_bounds(Bg, world, rank)
+    enc = synthetic_features(hi - lo, F, D, seed=1234 + rank).to(dev)
+    targets = targets_g[:, lo:hi].contiguous().to(dev)
+    step = R.DataParallelTrainStep(dec, rec, Bg, rank, world, n_frames=F)
+    T, w = step.prepare(targets_g.numpy())
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    runner = lambda: step(enc, targets, T, w)
+    if args.graph:
+        runner = R.GraphedStep(step, enc, targets, T, w)
+    for _ in range(args.warmup):
+        runner()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner()
+    sync_all()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t)
+    ms = el / args.steps * 1e3
+    sc = step.step_impl.engine.scalar_dict()
+
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel, measured live with HIP events around its launches
+        prof = roofline(step.step_impl.engine, lambda: step(enc, targets, T, w), kind, args.precision)
+        out = {
+            "metric": "captions/sec (train step) MSVD bs=100 28x1536 feats", "value": round(Bg * 1e3 / ms, 1),
+            "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=28, "
+                                   "D=R=1536, V=4188, E=468, H=512, A=128, T=31, dropout 0.5" % (args.rec, B),
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph),
+                       "loss": round(sc["total_loss"], 5)},
+            "roofline": prof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            v, cores, med = cpu_baseline(kind, B, F, D, V, args.cpu_steps, 1)
+            out["cpu_baseline"] = {"value": round(v, 2), "unit": "captions/s", "cores": cores, "kind": "port",
+                                   "sample": "1 warm-up + %d timed train steps of the same workload (B=%d, T=31) by "
+                                             "oracle/recnet_oracle.py on torch-CPU; median %.2f s/step" % (args.cpu_steps, B, med)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

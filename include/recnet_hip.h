@@ -196,7 +196,25 @@ int recnet_train_step(recnet_handle* h, const float* enc, const int64_t* targets
                       const float* step_weight, uint32_t seed, int32_t step, recnet_scalars* scalars,
                       void* stream);
 
+/* hipGraph-replay-friendly forms: the optimiser step count and the dropout seed live in device memory.
+ * recnet_set_step initialises the counter; *_fwd_bwd_dev first does step += 1, seed = seed_base + step
+ * on the device, so replaying a captured graph advances both; *_optimizer_step_dev reads the counter. */
+int recnet_set_step(recnet_handle* h, int32_t step, void* stream);
+int recnet_train_step_fwd_bwd_dev(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                                  const float* step_weight, uint32_t seed_base, recnet_scalars* scalars, void* stream);
+int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* scalars, void* stream);
+
 /* ---- plumbing exposed for tests and profiling */
+/* Between begin and end every recurrent-step GEMM launch of one site (the dependent-chain kernels: one
+ * per decoder / reconstructor time step) is bracketed by hipEvents on its stream; end() synchronises and
+ * returns the launch count and summed duration.  Not for use under graph capture. */
+#define RECNET_SITE_DEC_FWD 1   /* gates_t   = [ctx_t, h_{t-1}] . [W_ih[:,E:] | W_hh]^T       */
+#define RECNET_SITE_DEC_BWD 2   /* d[ctx, h] = dgates_t . [W_ih[:,E:] | W_hh]                   */
+#define RECNET_SITE_REC_FWD 3   /* reconstructor gates (global: hr . W_hh^T; local: [x, hr] . [W_ih | W_hh]^T) */
+#define RECNET_SITE_REC_BWD 4
+#define RECNET_SITE_REC_ATT 5   /* local reconstructor: hr . attn_W^T                           */
+int recnet_profile_begin(recnet_handle* h, int32_t site);
+int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms);
 /* C[M,N] (+)= alpha * op(A) op(B)^T + bias.  a_col / b_col: operand stored with the contraction index
  * as the ROW index (see csrc/gemm.hpp).  All fp32 device pointers. */
 int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, const float* B, int32_t b_col,

@@ -12,6 +12,6 @@ All compute goes through csrc/librecnet_hip.so (C ABI: include/recnet_hip.h).
 from .config import TrainConfig, make_config  # noqa: F401
 from .modules import Decoder, GlobalReconstructor, LocalReconstructor  # noqa: F401
 from .api import (build_decoder, build_reconstructor, forward_decoder, forward_global_reconstructor,  # noqa: F401
-                  forward_local_reconstructor, clip_grad_norm_, TrainStep, FusedAdam, decode_len,
+                  forward_local_reconstructor, clip_grad_norm_, TrainStep, GraphedStep, FusedAdam, decode_len,
                   step_weights)
 from .dp import DataParallelTrainStep, shard_bounds  # noqa: F401

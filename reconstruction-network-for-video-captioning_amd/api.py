@@ -387,3 +387,62 @@ class TrainStep:
             self.reconstructor["_state"].step = ms.step
         self.engine.train_step(enc, targets, T, step_weight, seed, ms.step)
         return self.engine.scalars
+
+
+class GraphedStep:
+    """Replays the train step from captured hipGraphs (one per fixed T): the step is ~300 dependent
+    launches, so eager launching is host-bound; a graph removes the launch overhead.  The optimiser
+    step count and the dropout seed advance on the device (recnet_train_step_fwd_bwd_dev), so every
+    replay is a new training step.  With world_size > 1 the gradient all-reduce runs between two graphs
+    (fwd+bwd | RCCL all-reduce | optimiser)."""
+
+    def __init__(self, dp_step, enc, targets, T, step_weight, warmup=2):
+        self.dp = dp_step
+        st = dp_step.step_impl
+        self.eng = st.engine
+        self.enc, self.targets, self.T, self.w = enc, targets, T, step_weight
+        self.ms = st.decoder["_state"]
+        self.rs = st.reconstructor["_state"] if st.reconstructor else None
+        self.seed_base = st.seed_base
+        self.flags = _lib.OPT_REG | _lib.OPT_CLIP
+        eng = self.eng
+        eng.set_step(self.ms.step)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up outside capture (lazy module loading)
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
+            if dp_step.world == 1:
+                eng.optimizer_step_dev(self.flags)
+        self.g2 = None
+        if dp_step.world > 1:
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2):
+                eng.optimizer_step_dev(self.flags)
+
+    def _eager(self):
+        self.eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
+        if self.dp.world > 1:
+            from .dp import allreduce_sum_
+            allreduce_sum_(self.dp.grad_buffers(), self.dp.group)
+        self.eng.optimizer_step_dev(self.flags)
+        self._bump()
+
+    def _bump(self):
+        self.ms.step += 1
+        if self.rs:
+            self.rs.step = self.ms.step
+
+    def __call__(self):
+        self.g1.replay()
+        if self.g2 is not None:
+            from .dp import allreduce_sum_
+            allreduce_sum_(self.dp.grad_buffers(), self.dp.group)
+            self.g2.replay()
+        self._bump()
+        return self.eng.scalars

@@ -57,6 +57,8 @@ struct recnet_handle {
   OptGroup og[2];
   // state between forward and backward
   int T_last = 0, train_last = 0, fwd_dec_done = 0, fwd_rec_done = 0, rec_bwd_done = 0;
+  // optional per-launch timing of the recurrent-step GEMM (recnet_profile_*)
+  int prof_on = 0; std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -176,7 +178,11 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   return RECNET_OK;
 }
 
-void recnet_destroy(recnet_handle* h) { delete h; }
+void recnet_destroy(recnet_handle* h) {
+  if (!h) return;
+  for (auto e : h->prof_ev) hipEventDestroy(e);
+  delete h;
+}
 
 int recnet_set_shard(recnet_handle* h, int32_t global_batch_size, int32_t batch_offset) {
   if (!h || global_batch_size < h->B || batch_offset < 0) return fail(RECNET_EINVAL, "bad shard");
@@ -300,18 +306,29 @@ static void gemm(recnet_handle* h, const void* A, int a_bf16, int a_col, int lda
   rn_launch_gemm(h->prec, A, a_bf16, a_col, lda, Bm, b_bf16, b_col, ldb, C, ldc, bias, M, N, K, alpha, acc, s, h->gws, 1, st);
 }
 // recurrent-step GEMM: partial slabs only; returns the slab count the consumer must sum
-static int gemm_slabs(recnet_handle* h, const void* A, int a_col, int lda, const void* Bm, int b_bf16, int b_col, int ldb,
+static int gemm_slabs(recnet_handle* h, int tag, const void* A, int a_col, int lda, const void* Bm, int b_bf16, int b_col, int ldb,
                       int M, int N, int K, hipStream_t st) {
   int s = rn_pick_splitk(h->prec, M, N, K, 32);
   while (s > 1 && (size_t)s * M * N > h->slab_floats) s >>= 1;
   if (s < 2) s = 2;  // always use the slab path so the consumer code is uniform
   s = rn_effective_splitk(h->prec, K, s);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->prof_on == tag) {
+    if (h->prof_used + 2 > h->prof_ev.size()) {
+      hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+      h->prof_ev.push_back(a); h->prof_ev.push_back(b);
+    }
+    e0 = h->prof_ev[h->prof_used++]; e1 = h->prof_ev[h->prof_used++];
+    hipEventRecord(e0, st);
+  }
   if (s < 2) {
     // K fits one tile: write the single product into slab 0 through the direct epilogue
-    rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, h->slab, N, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0, st);
-    return 1;
+    rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, h->slab, N, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0, st, tag);
+    s = 1;
+  } else {
+    rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, nullptr, N, nullptr, M, N, K, 1.f, 0, s, h->slab, 0, st, tag);
   }
-  rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, nullptr, N, nullptr, M, N, K, 1.f, 0, s, h->slab, 0, st);
+  if (e1) hipEventRecord(e1, st);
   return s;
 }
 static void colsum(const float* X, int rows, int cols, int ld, float* out, hipStream_t st) {
@@ -393,7 +410,7 @@ static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
     a.att_out = t < T ? h->att + (size_t)t * B * F : nullptr;
     hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
     if (t < T)   // gates_t (minus Xe) = [ctx_t, h_{t-1}] . [W_ih[:,E:] | W_hh]^T as split-K slabs
-      S = gemm_slabs(h, h->Xcat + (size_t)t * B * (D + H), 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
+      S = gemm_slabs(h, RN_TAG_DEC_FWD, h->Xcat + (size_t)t * B * (D + H), 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
   }
   // logits for all steps, then masked CE with logits dropout (decoder.py:68-69, train.py:54-68)
   gemm(h, h->Hs, 0, 0, H, h->dP.out_weight, 0, 0, H, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
@@ -442,7 +459,7 @@ static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
     }
     hipLaunchKernelGGL(dec_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
     if (t > 0)   // d[ctx_{t-1}, h_{t-2}] = dG_{t-1} . [W_ih[:,E:] | W_hh]
-      S = gemm_slabs(h, h->dG + (size_t)(t - 1) * B * 4 * H, 0, 4 * H, h->Wch, pb, 1, D + H, B, D + H, 4 * H, st);
+      S = gemm_slabs(h, RN_TAG_DEC_BWD, h->dG + (size_t)(t - 1) * B * 4 * H, 0, 4 * H, h->Wch, pb, 1, D + H, B, D + H, 4 * H, st);
   }
   // deferred weight gradients (batched over all T steps)
   gemm(h, h->dG, 0, 0, 4 * H, h->dP.rnn_weight_ih_l0, 0, 1, E + D, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
@@ -486,7 +503,7 @@ static int fwd_rec_global(recnet_handle* h, const float* enc, const float* Hs, i
   gemm(h, h->mpd, 0, 0, H, h->rP.rnn_weight_ih_l0 + H, 0, 0, 2 * H, h->Xg, 4 * R, nullptr, T * B, 4 * R, H, 1.f, 1, st);
   for (int t = 0; t < T; ++t) {
     int S = 0;
-    if (t > 0) S = gemm_slabs(h, h->Hr + (size_t)(t - 1) * B * R, 0, R, h->rP.rnn_weight_hh_l0, 0, 0, R, B, 4 * R, R, st);
+    if (t > 0) S = gemm_slabs(h, RN_TAG_REC_FWD, h->Hr + (size_t)(t - 1) * B * R, 0, R, h->rP.rnn_weight_hh_l0, 0, 0, R, B, 4 * R, R, st);
     lstm_pw(h, R, S, 4 * R, h->Xg + (size_t)t * B * 4 * R, 4 * R, nullptr, nullptr,
             t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->Hr + (size_t)t * B * R, R, nullptr, 0,
             h->Cr + (size_t)t * B * R, h->acts_r + (size_t)t * B * 4 * R, st);
@@ -526,7 +543,7 @@ static int bwd_rec_global(recnet_handle* h, const float* Hs, float gscale, float
   for (int t = T - 1; t >= 0; --t) {
     lstm_bwd(h, R, S, R, 0, h->dhrmean, R, 1.0f / (float)T, h->acts_r + (size_t)t * B * 4 * R, h->Cr + (size_t)t * B * R,
              t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->dcr_carry, t == T - 1, h->dGr + (size_t)t * B * 4 * R, st);
-    if (t > 0) S = gemm_slabs(h, h->dGr + (size_t)t * B * 4 * R, 0, 4 * R, h->rP.rnn_weight_hh_l0, 0, 1, R, B, R, 4 * R, st);
+    if (t > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, h->dGr + (size_t)t * B * 4 * R, 0, 4 * R, h->rP.rnn_weight_hh_l0, 0, 1, R, B, R, 4 * R, st);
   }
   // input-side gradients, batched
   gemm(h, h->dGr, 0, 0, 4 * R, h->rP.rnn_weight_ih_l0, 0, 1, 2 * H, dhid_out, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
@@ -561,12 +578,12 @@ static int fwd_rec_local(recnet_handle* h, const float* enc, const float* Hs, in
   const size_t sm = (size_t)(RA + T + 16) * 4;
   for (int s = 0; s < F; ++s) {
     int Sa = 0;
-    if (s > 0) Sa = gemm_slabs(h, h->Hr + (size_t)(s - 1) * B * R, 0, R, h->rP.attn_W_weight, 0, 0, R, B, RA, R, st);
+    if (s > 0) Sa = gemm_slabs(h, RN_TAG_REC_ATT, h->Hr + (size_t)(s - 1) * B * R, 0, R, h->rP.attn_W_weight, 0, 0, R, B, RA, R, st);
     a.s = s; a.S = Sa; a.slab = s > 0 ? h->slab : nullptr;
     a.Whr_out = h->Whr + (size_t)s * B * RA; a.beta_out = h->beta + (size_t)s * B * T;
     a.xcat = h->Xcat_r + (size_t)s * B * (H + R);
     hipLaunchKernelGGL(loc_attn_fwd_kernel, dim3(B), dim3(256), sm, st, a);
-    const int Sb = gemm_slabs(h, h->Xcat_r + (size_t)s * B * (H + R), 0, H + R, h->Wihh, pb, 0, H + R, B, 4 * R, H + R, st);
+    const int Sb = gemm_slabs(h, RN_TAG_REC_FWD, h->Xcat_r + (size_t)s * B * (H + R), 0, H + R, h->Wihh, pb, 0, H + R, B, 4 * R, H + R, st);
     lstm_pw(h, R, Sb, 4 * R, nullptr, 0, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0,
             s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->Hr + (size_t)s * B * R, R,
             s + 1 < F ? h->Xcat_r + (size_t)(s + 1) * B * (H + R) + H : nullptr, H + R, h->Cr + (size_t)s * B * R,
@@ -609,7 +626,7 @@ static int bwd_rec_local(recnet_handle* h, const float* Hs, float gscale, float*
       a.dG = h->dGr + (size_t)(s - 1) * B * 4 * R;
     }
     hipLaunchKernelGGL(loc_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
-    if (s > 0) S = gemm_slabs(h, h->dGr + (size_t)(s - 1) * B * 4 * R, 0, 4 * R, h->Wihh, pb, 1, H + R, B, H + R, 4 * R, st);
+    if (s > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, h->dGr + (size_t)(s - 1) * B * 4 * R, 0, 4 * R, h->Wihh, pb, 1, H + R, B, H + R, 4 * R, st);
   }
   // deferred, batched
   gemm(h, h->dUd, 0, 1, RA, Hs, 0, 1, H, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
@@ -702,7 +719,7 @@ int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_
   a.Wh_out = nullptr; a.att_out = nullptr;
   const size_t sm = dec_step_smem(h);
   hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
-  int S = gemm_slabs(h, h->Xcat, 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
+  int S = gemm_slabs(h, RN_TAG_DEC_FWD, h->Xcat, 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
   a.S = S; a.do_lstm = 1; a.do_attn = 0; a.slab = h->slab; a.Xe = h->Xe; a.c_prev = c_in; a.h_out = h_out; a.c_out = c_out;
   a.xcat = nullptr;
   hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
@@ -843,6 +860,59 @@ int recnet_train_step(recnet_handle* h, const float* enc, const int64_t* targets
                       const float* step_weight, uint32_t seed, int32_t step, recnet_scalars* scalars, void* stream) {
   int r = recnet_train_step_fwd_bwd(h, enc, targets, T, step_weight, seed, nullptr, stream); if (r) return r;
   return recnet_optimizer_step(h, step, RECNET_OPT_REG | RECNET_OPT_CLIP, scalars, stream);
+}
+
+int recnet_set_step(recnet_handle* h, int32_t step, void* stream) {
+  REQUIRE_WS(h);
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, h->ctrl + 1, (uint32_t)step);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_train_step_fwd_bwd_dev(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                                  const float* step_weight, uint32_t seed_base, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound || (h->kind != RECNET_REC_NONE && !h->rec_bound)) return fail(RECNET_ESTATE, "models not bound");
+  if (!h->dGd.out_weight || (h->kind != RECNET_REC_NONE && !h->rG.out_weight)) return fail(RECNET_ESTATE, "gradients not bound");
+  if (!enc || !targets || !step_weight) return fail(RECNET_EINVAL, "null argument");
+  if (check_T(h, T)) return fail(RECNET_EINVAL, "T out of range");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, (int32_t*)(h->ctrl + 1), h->ctrl, seed_base);
+  int r = fwd_bwd(h, enc, targets, T, step_weight, st); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  h->fwd_dec_done = 0;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  hipStream_t st = (hipStream_t)stream;
+  int r = optimizer_step(h, flags, st); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_profile_begin(recnet_handle* h, int32_t site) {
+  if (!h || site < 1 || site > 5) return fail(RECNET_EINVAL, "bad profile site");
+  h->prof_on = site; h->prof_used = 0;
+  return RECNET_OK;
+}
+
+int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms) {
+  if (!h || !n_launches || !total_ms) return fail(RECNET_EINVAL, "null argument");
+  h->prof_on = 0;
+  double tot = 0; int n = 0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    HIPCHK(hipEventSynchronize(h->prof_ev[i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+    tot += ms; ++n;
+  }
+  *n_launches = n; *total_ms = tot;
+  h->prof_used = 0;
+  return RECNET_OK;
 }
 
 int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, const float* B, int32_t b_col,

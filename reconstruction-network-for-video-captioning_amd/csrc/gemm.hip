@@ -4,11 +4,21 @@
 
 namespace {
 template <typename CT, typename TA, typename TB>
-void launch_layout(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream_t st) {
-  if (!a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false>), grid, dim3(256), 0, st, a);
-  else if (!a_col && b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true>), grid, dim3(256), 0, st, a);
-  else if (a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, false>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, true>), grid, dim3(256), 0, st, a);
+void launch_layout(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream_t st, int tag) {
+  // tag > 0: the recurrent-step launches (A = fp32 activations, row layout; the tag fixes B's layout).  Each
+  // tag is its own kernel symbol so a rocprofv3 kernel trace separates the dependent-chain GEMMs by site.
+  switch (tag) {
+    case RN_TAG_DEC_FWD: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false, RN_TAG_DEC_FWD>), grid, dim3(256), 0, st, a); return;
+    case RN_TAG_DEC_BWD: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true, RN_TAG_DEC_BWD>), grid, dim3(256), 0, st, a); return;
+    case RN_TAG_REC_FWD: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false, RN_TAG_REC_FWD>), grid, dim3(256), 0, st, a); return;
+    case RN_TAG_REC_BWD: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true, RN_TAG_REC_BWD>), grid, dim3(256), 0, st, a); return;
+    case RN_TAG_REC_ATT: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false, RN_TAG_REC_ATT>), grid, dim3(256), 0, st, a); return;
+    default: break;
+  }
+  if (!a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false, 0>), grid, dim3(256), 0, st, a);
+  else if (!a_col && b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true, 0>), grid, dim3(256), 0, st, a);
+  else if (a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, false, 0>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, true, 0>), grid, dim3(256), 0, st, a);
 }
 inline int vec_ok(const void* p, int ld, int elem) {
   return (((uintptr_t)p) % 16 == 0) && (((size_t)ld * elem) % 16 == 0);
@@ -29,7 +39,7 @@ int rn_pick_splitk(int prec, int M, int N, int K, int max_split) {
 
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
-                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st) {
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag) {
   if (M <= 0 || N <= 0) return;
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
@@ -47,12 +57,11 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
   a.b_vec = vec_ok(B, ldb, b_bf16 ? 2 : 4);
   dim3 grid((N + GEMM_TILE - 1) / GEMM_TILE, (M + GEMM_TILE - 1) / GEMM_TILE, splitk);
   if (prec == RN_PREC_BF16) {
-    if (!a_bf16 && !b_bf16) launch_layout<bf16_t, float, float>(a, a_col, b_col, grid, st);
-    else if (!a_bf16 && b_bf16) launch_layout<bf16_t, float, bf16_t>(a, a_col, b_col, grid, st);
-    else if (a_bf16 && b_bf16) launch_layout<bf16_t, bf16_t, bf16_t>(a, a_col, b_col, grid, st);
-    else launch_layout<bf16_t, bf16_t, float>(a, a_col, b_col, grid, st);
+    if (!a_bf16 && !b_bf16) launch_layout<bf16_t, float, float>(a, a_col, b_col, grid, st, tag);
+    else if (!a_bf16 && b_bf16) launch_layout<bf16_t, float, bf16_t>(a, a_col, b_col, grid, st, tag);
+    else launch_layout<bf16_t, bf16_t, bf16_t>(a, a_col, b_col, grid, st, 0);   // bf16 activations (no tagged form)
   } else {
-    launch_layout<float, float, float>(a, a_col, b_col, grid, st);
+    launch_layout<float, float, float>(a, a_col, b_col, grid, st, tag);
   }
   if (splitk > 1 && reduce_after) {
     size_t total = (size_t)M * N;

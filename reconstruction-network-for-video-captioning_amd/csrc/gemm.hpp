@@ -152,7 +152,9 @@ template <typename CT> struct FragT;
 template <> struct FragT<bf16_t> { typedef bf16x8 type; static constexpr int KSTEP = 32; };
 template <> struct FragT<float> { typedef float type; static constexpr int KSTEP = 4; };
 
-template <typename CT, typename TA, typename TB, bool ACOL, bool BCOL>
+// TAG only changes the symbol name: 0 = batched GEMM, 1..5 = the recurrent-step GEMM sites (launch.hpp), so that
+// rocprofv3 --stats reports each dependent-chain launch site separately from the big batched GEMMs.
+template <typename CT, typename TA, typename TB, bool ACOL, bool BCOL, int TAG>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   typedef GemmCfg<CT> G;
   typedef typename FragT<CT>::type frag_t;

@@ -6,6 +6,13 @@
 #define RN_PREC_F32 0
 #define RN_PREC_BF16 1
 
+// kernel-symbol tags of the recurrent-step GEMM launches (see gemm.hip)
+#define RN_TAG_DEC_FWD 1
+#define RN_TAG_DEC_BWD 2
+#define RN_TAG_REC_FWD 3
+#define RN_TAG_REC_BWD 4
+#define RN_TAG_REC_ATT 5
+
 // ---- gemm.hip
 int rn_gemm_bk(int prec);
 int rn_pick_splitk(int prec, int M, int N, int K, int max_split);
@@ -14,7 +21,7 @@ int rn_effective_splitk(int prec, int K, int splitk);
 // run the slab reduction (otherwise the caller's fused consumer sums ws[z][M][N] itself).
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
-                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st);
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag = 0);
 
 // ---- dropout descriptor handed to kernels: seed lives in device memory so a captured graph can be
 // replayed with a new seed.

@@ -262,6 +262,35 @@ class Engine:
                    "recnet_train_step")
         self.T = T
 
+    # ---- hipGraph-replay-friendly forms (step counter and dropout seed live on the device)
+    def set_step(self, step):
+        _lib.check(self.lib.recnet_set_step(self.handle, int(step), _stream()), "recnet_set_step")
+
+    def train_step_fwd_bwd_dev(self, enc, targets, T, step_weight, seed_base):
+        _lib.check(self.lib.recnet_train_step_fwd_bwd_dev(self.handle, _ptr(enc), _ptr(targets), int(T),
+                                                          _ptr(step_weight), seed_base & 0xFFFFFFFF,
+                                                          _ptr(self.scalars), _stream()),
+                   "recnet_train_step_fwd_bwd_dev")
+        self.T = T
+
+    def optimizer_step_dev(self, flags):
+        _lib.check(self.lib.recnet_optimizer_step_dev(self.handle, int(flags), _ptr(self.scalars), _stream()),
+                   "recnet_optimizer_step_dev")
+
+    # ---- live measurement of one recurrent-step GEMM site with HIP events on its own stream
+    def profile_site(self, site, fn, iters=3):
+        """Runs fn() `iters` times with hipEvents around every launch of `site` (1 dec fwd, 2 dec bwd, 3 rec
+        fwd, 4 rec bwd, 5 local-attention); returns (launches, average ms per launch)."""
+        _lib.check(self.lib.recnet_profile_begin(self.handle, int(site)), "recnet_profile_begin")
+        for _ in range(iters):
+            fn()
+        n, ms = C.c_int32(0), C.c_double(0.0)
+        _lib.check(self.lib.recnet_profile_end(self.handle, C.byref(n), C.byref(ms)), "recnet_profile_end")
+        return n.value, (ms.value / n.value if n.value else 0.0)
+
+    def recurrent_step_bytes(self, which):
+        return float(self.lib.recnet_recurrent_step_bytes(self.handle, int(which)))
+
     def scalar_dict(self):
         """Host copy of the device scalars (synchronises)."""
         v = self.scalars.tolist()

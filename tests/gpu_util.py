@@ -10,7 +10,7 @@ from tests import golden_util as GU
 TOL = {
     # precision: (loss rel, hidden abs, per-tensor grad ||d||/||g||, param abs after steps)
     "f32": dict(loss=2e-5, hid=2e-5, grad=2e-4, param=2e-6),
-    "bf16": dict(loss=3e-3, hid=1.5e-2, grad=4e-2, param=2e-5),
+    "bf16": dict(loss=3e-3, hid=1.5e-2, grad=4e-2, param=6e-5),   # 3 Adam steps of lr 1e-5: a sign flip of a tiny gradient moves a parameter by up to 2*lr per step
 }
 
 
