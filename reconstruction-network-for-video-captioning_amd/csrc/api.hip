@@ -41,9 +41,10 @@ struct recnet_handle {
   // ---- carved regions
   uint32_t* ctrl;        // [0] seed slot, [1] step slot (int32)
   float* scal;           // internal scalars: [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
-  float *bsum_d, *Uv, *emb, *Xe, *Xcat, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws;
-  float *dG, *dHs, *dc_carry, *dWh, *dUv, *dwacc, *demb, *stepw;
-  void* Wch;             // packed [4H][D+H] (bf16 or f32)
+  float *bsum_d, *Uv, *emb, *Xe, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws;
+  float *dGx, *dHs, *dc_carry, *dUv, *dwacc, *demb, *stepw, *ctxall;
+  void* P;               // [B][F][4H] = enc . W_ih[:, E:]^T (bf16 in the bf16 path, else fp32)
+  void* Wcomb;           // packed [4H + A][H] = [W_hh ; attn_W] (bf16 or f32)
   // reconstructor
   float *bsum_r, *mp, *mpd, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dGr, *dmpd, *dmp, *dcr_carry, *msep;
   float *dHsrec;
@@ -77,7 +78,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->Uv = take(B * F * A);
   h->emb = take(Tm * B * E);
   h->Xe = take(Tm * B * 4 * H);
-  h->Xcat = take(Tm * B * (D + H));
+  h->P = take(B * F * 4 * H);
   h->Hs = take(Tm * B * H);
   h->Cs = take(Tm * B * H);
   h->acts = take(Tm * B * 4 * H);
@@ -85,17 +86,16 @@ static size_t carve(recnet_handle* h, char* base) {
   h->att = take(Tm * B * F);
   h->logits = take(Tm * B * V);
   h->rowloss = take(Tm * B);
-  h->dG = take(Tm * B * 4 * H);
+  h->dGx = take(Tm * B * (4 * H + A));
+  h->ctxall = take(Tm * B * D);
   h->dHs = take(Tm * B * H);
   h->dHsrec = take(Tm * B * H);
   h->dc_carry = take(B * H);
-  h->dWh = take(Tm * B * A);
   h->dUv = take(B * F * A);
   h->dwacc = take(B * A);
   h->demb = take(Tm * B * E);
-  h->Wch = take(4 * H * (D + H));
-  size_t maxN = 4 * H;
-  if (D + H > maxN) maxN = D + H;
+  h->Wcomb = take((4 * H + A) * H);
+  size_t maxN = 4 * H + A;
   if (h->kind != RECNET_REC_NONE) {
     if (4 * R > maxN) maxN = 4 * R;
     if (H + R > maxN) maxN = H + R;
@@ -353,15 +353,15 @@ __global__ void export_scalars_kernel(const float* scal, recnet_scalars* out) {
 }
 
 static int pack_weights(recnet_handle* h, hipStream_t st) {
-  const int H = h->H, D = h->D, E = h->E, R = h->R;
+  const int H = h->H, R = h->R;
   if (h->dec_bound) {
-    const size_t n = (size_t)4 * H * (D + H);
+    const size_t n1 = (size_t)4 * H * H, n2 = (size_t)h->A * H;
     if (h->prec == RN_PREC_BF16)
-      hipLaunchKernelGGL(pack2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->Wch,
-                         h->dP.rnn_weight_ih_l0 + E, E + D, D, h->dP.rnn_weight_hh_l0, H, H, 4 * H);
+      hipLaunchKernelGGL(packv_kernel<bf16_t>, dim3(ew_blocks(n1 + n2)), dim3(256), 0, st, (bf16_t*)h->Wcomb,
+                         h->dP.rnn_weight_hh_l0, n1, h->dP.attn_W_weight, n2);
     else
-      hipLaunchKernelGGL(pack2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->Wch,
-                         h->dP.rnn_weight_ih_l0 + E, E + D, D, h->dP.rnn_weight_hh_l0, H, H, 4 * H);
+      hipLaunchKernelGGL(packv_kernel<float>, dim3(ew_blocks(n1 + n2)), dim3(256), 0, st, (float*)h->Wcomb,
+                         h->dP.rnn_weight_hh_l0, n1, h->dP.attn_W_weight, n2);
   }
   if (h->rec_bound && h->kind == RECNET_REC_LOCAL) {
     const size_t n = (size_t)4 * R * (H + R);
@@ -375,7 +375,20 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
   return RECNET_OK;
 }
 
-static size_t dec_step_smem(const recnet_handle* h) { return (size_t)(h->H + h->A + h->F + 16) * 4; }
+static size_t dec_cell_smem(const recnet_handle* h) { return (size_t)(h->A + h->F + 4 * RN_UC + 16) * 4; }
+static void launch_dec_cell(recnet_handle* h, const DecCellArgs& a, hipStream_t st) {
+  dim3 grid(h->B, cdiv(h->H, RN_UC));
+  if (h->prec == RN_PREC_BF16) hipLaunchKernelGGL(dec_cell_kernel<bf16_t>, grid, dim3(256), dec_cell_smem(h), st, a);
+  else hipLaunchKernelGGL(dec_cell_kernel<float>, grid, dim3(256), dec_cell_smem(h), st, a);
+}
+// loop-invariant products of the decoder: Uv = enc . U^T (decoder.py:54) and P = enc . W_ih[:, E:]^T
+static void dec_invariants(recnet_handle* h, const float* enc, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A;
+  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, 4 * H);
+  gemm(h, enc, 0, 0, D, h->dP.attn_U_weight, 0, 0, D, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
+  rn_launch_gemm(h->prec, enc, 0, 0, D, h->dP.rnn_weight_ih_l0 + E, 0, 0, E + D, (float*)h->P, 4 * H, nullptr, B * F, 4 * H, D,
+                 1.f, 0, 1, nullptr, 0, st, 0, h->prec == RN_PREC_BF16);
+}
 
 // ---------------------------------------------------------------------------------------------- decoder forward
 static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw,
@@ -383,34 +396,26 @@ static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
   const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V;
   const int pb = h->prec == RN_PREC_BF16;
   param_norms(h, 0, h->scal + 1, st);
-  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, 4 * H);
-  // Uv = enc . U^T                                   (decoder.py:54, hoisted out of the time loop)
-  gemm(h, enc, 0, 0, D, h->dP.attn_U_weight, 0, 0, D, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
+  dec_invariants(h, enc, st);
   // all T teacher-forced input embeddings at once    (decoder.py:46-48, train.py:25,45)
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(T * B), dim3(128), 0, st, h->dP.embedding_weight, targets, (const int64_t*)nullptr,
                      h->emb, B, E, V, h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), 0);
   // Xe = emb . W_ih[:, :E]^T + b_ih + b_hh
   gemm(h, h->emb, 0, 0, E, h->dP.rnn_weight_ih_l0, 0, 0, E + D, h->Xe, 4 * H, h->bsum_d, T * B, 4 * H, E, 1.f, 0, st);
-  DecStepArgs a;
-  a.B = B; a.F = F; a.D = D; a.H = H; a.A = A;
-  a.W = h->dP.attn_W_weight; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight; a.enc = enc;
-  a.h_in = nullptr; a.h_in_ld = H; a.xcat_ld = D + H;
-  const size_t sm = dec_step_smem(h);
-  int S = 0;
-  for (int t = 0; t <= T; ++t) {
-    a.t = t; a.S = S; a.do_lstm = t > 0; a.do_attn = t < T;
-    a.slab = h->slab;
-    a.Xe = t > 0 ? h->Xe + (size_t)(t - 1) * B * 4 * H : nullptr;
-    a.c_prev = t > 1 ? h->Cs + (size_t)(t - 2) * B * H : nullptr;
-    a.h_out = t > 0 ? h->Hs + (size_t)(t - 1) * B * H : nullptr;
-    a.c_out = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
-    a.acts = t > 0 ? h->acts + (size_t)(t - 1) * B * 4 * H : nullptr;
-    a.xcat = t < T ? h->Xcat + (size_t)t * B * (D + H) : nullptr;
-    a.Wh_out = t < T ? h->Wh + (size_t)t * B * A : nullptr;
-    a.att_out = t < T ? h->att + (size_t)t * B * F : nullptr;
-    hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
-    if (t < T)   // gates_t (minus Xe) = [ctx_t, h_{t-1}] . [W_ih[:,E:] | W_hh]^T as split-K slabs
-      S = gemm_slabs(h, RN_TAG_DEC_FWD, h->Xcat + (size_t)t * B * (D + H), 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
+  DecCellArgs a;
+  a.B = B; a.F = F; a.H = H; a.A = A;
+  a.P = h->P; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
+  for (int t = 0; t < T; ++t) {
+    int S = 0;
+    if (t > 0)   // h_{t-1} . [W_hh ; attn_W]^T  -> recurrent gate part + Wh of the attention
+      S = gemm_slabs(h, RN_TAG_DEC_FWD, h->Hs + (size_t)(t - 1) * B * H, 0, H, h->Wcomb, pb, 0, H, B, 4 * H + A, H, st);
+    a.t = t; a.S = S; a.slab = t > 0 ? h->slab : nullptr;
+    a.Xe = h->Xe + (size_t)t * B * 4 * H;
+    a.c_prev = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
+    a.h_out = h->Hs + (size_t)t * B * H; a.c_out = h->Cs + (size_t)t * B * H;
+    a.acts = h->acts + (size_t)t * B * 4 * H;
+    a.Wh_out = h->Wh + (size_t)t * B * A; a.att_out = h->att + (size_t)t * B * F;
+    launch_dec_cell(h, a, st);
   }
   // logits for all steps, then masked CE with logits dropout (decoder.py:68-69, train.py:54-68)
   gemm(h, h->Hs, 0, 0, H, h->dP.out_weight, 0, 0, H, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
@@ -430,7 +435,7 @@ static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
                        hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, T = h->T_last;
   const int pb = h->prec == RN_PREC_BF16, train = h->train_last;
-  const int TB = T * B;
+  const int TB = T * B, WS = 4 * H + A;
   if (gscale != 1.0f) hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks((size_t)TB * V)), dim3(256), 0, st, h->logits, (size_t)TB * V, gscale);
   // dHs = dhiddens (from the reconstructor) + dlogits . W_o
   if (dhid) copyf(dhid, h->dHs, (size_t)TB * H, st); else hipMemsetAsync(h->dHs, 0, (size_t)TB * H * 4, st);
@@ -438,42 +443,50 @@ static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
   // dW_o = dlogits^T . Hs ; db_o = colsum(dlogits)
   gemm(h, h->logits, 0, 1, V, h->Hs, 0, 1, H, h->dGd.out_weight, H, nullptr, V, H, TB, 1.f, 0, st);
   colsum(h->logits, TB, V, V, h->dGd.out_bias, st);
-  // BPTT
-  DecBwdArgs a;
-  a.B = B; a.F = F; a.D = D; a.H = H; a.A = A;
-  a.enc = enc; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight; a.W = h->dP.attn_W_weight;
-  a.dUv = h->dUv; a.dwacc = h->dwacc; a.dc_carry = h->dc_carry; a.slab = h->slab;
-  const size_t sm = (size_t)(D + H + F + A + 16) * 4;
+  // BPTT: per step one fused per-caption kernel + one split-K GEMM (dgates_t | dWh_t) . [W_hh ; W]
+  DecCellBwdArgs a;
+  a.B = B; a.F = F; a.H = H; a.A = A;
+  a.P = h->P; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
+  a.dUv = h->dUv; a.dwacc = h->dwacc; a.dc_carry = h->dc_carry;
+  const size_t sm = (size_t)(4 * H + F + 16) * 4;
   int S = 0;
-  for (int t = T; t >= 0; --t) {
-    a.t = t; a.S = S; a.do_attn = t < T; a.do_lstm = t > 0;
-    a.first_attn = (t == T - 1); a.first_lstm = (t == T);
-    a.Wh = t < T ? h->Wh + (size_t)t * B * A : nullptr;
-    a.dWh = t < T ? h->dWh + (size_t)t * B * A : nullptr;
-    if (t > 0) {
-      a.dHs = h->dHs + (size_t)(t - 1) * B * H;
-      a.acts = h->acts + (size_t)(t - 1) * B * 4 * H;
-      a.c = h->Cs + (size_t)(t - 1) * B * H;
-      a.c_prev = t > 1 ? h->Cs + (size_t)(t - 2) * B * H : nullptr;
-      a.dG = h->dG + (size_t)(t - 1) * B * 4 * H;
-    }
-    hipLaunchKernelGGL(dec_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
-    if (t > 0)   // d[ctx_{t-1}, h_{t-2}] = dG_{t-1} . [W_ih[:,E:] | W_hh]
-      S = gemm_slabs(h, RN_TAG_DEC_BWD, h->dG + (size_t)(t - 1) * B * 4 * H, 0, 4 * H, h->Wch, pb, 1, D + H, B, D + H, 4 * H, st);
+  for (int t = T - 1; t >= 0; --t) {
+    a.t = t; a.S = S; a.slab = (t < T - 1) ? h->slab : nullptr; a.first = (t == T - 1);
+    a.dHs = h->dHs + (size_t)t * B * H;
+    a.acts = h->acts + (size_t)t * B * 4 * H;
+    a.c = h->Cs + (size_t)t * B * H;
+    a.c_prev = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
+    a.dGx = h->dGx + (size_t)t * B * WS;
+    a.Wh = h->Wh + (size_t)t * B * A;
+    if (pb) hipLaunchKernelGGL(dec_cell_bwd_kernel<bf16_t>, dim3(B), dim3(512), sm, st, a);
+    else hipLaunchKernelGGL(dec_cell_bwd_kernel<float>, dim3(B), dim3(512), sm, st, a);
+    if (t > 0)
+      S = gemm_slabs(h, RN_TAG_DEC_BWD, h->dGx + (size_t)t * B * WS, 0, WS, h->Wcomb, pb, 1, H, B, H, WS, st);
   }
-  // deferred weight gradients (batched over all T steps)
-  gemm(h, h->dG, 0, 0, 4 * H, h->dP.rnn_weight_ih_l0, 0, 1, E + D, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
+  // deferred weight gradients (batched over all T steps); dgates live in columns [0,4H) of dGx, dWh in [4H,4H+A)
+  gemm(h, h->dGx, 0, 0, WS, h->dP.rnn_weight_ih_l0, 0, 1, E + D, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
   hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(TB), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
                      h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train));
-  gemm(h, h->dG, 0, 1, 4 * H, h->emb, 0, 1, E, h->dGd.rnn_weight_ih_l0, E + D, nullptr, 4 * H, E, TB, 1.f, 0, st);
-  gemm(h, h->dG, 0, 1, 4 * H, h->Xcat, 0, 1, D + H, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, 4 * H, D, TB, 1.f, 0, st);
-  gemm(h, h->dG, 0, 1, 4 * H, h->Xcat + D, 0, 1, D + H, h->dGd.rnn_weight_hh_l0, H, nullptr, 4 * H, H, TB, 1.f, 0, st);
-  colsum(h->dG, TB, 4 * H, 4 * H, h->dGd.rnn_bias_ih_l0, st);
+  gemm(h, h->dGx, 0, 1, WS, h->emb, 0, 1, E, h->dGd.rnn_weight_ih_l0, E + D, nullptr, 4 * H, E, TB, 1.f, 0, st);
+  // ctx_t = (1/F) sum_f a_t[f] enc[b,f] for every step (only needed here), then dW_ih[:, E:] = dgates^T . ctx
+  if (h->Tm <= 32)
+    hipLaunchKernelGGL(ctx_all_kernel, dim3(B, cdiv(D, 256)), dim3(256), (size_t)32 * F * 4, st, h->att, enc, h->ctxall, T, B, F, D);
+  else
+    hipLaunchKernelGGL(ctx_all_slow_kernel, dim3(B, cdiv(D, 256)), dim3(256), 0, st, h->att, enc, h->ctxall, T, B, F, D);
+  gemm(h, h->dGx, 0, 1, WS, h->ctxall, 0, 1, D, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, 4 * H, D, TB, 1.f, 0, st);
+  // dW_hh = sum_{t>=1} dgates_t^T h_{t-1} ; dW_attn = sum_{t>=1} dWh_t^T h_{t-1}   (h_{-1} = 0)
+  if (T > 1) {
+    gemm(h, h->dGx + (size_t)B * WS, 0, 1, WS, h->Hs, 0, 1, H, h->dGd.rnn_weight_hh_l0, H, nullptr, 4 * H, H, (T - 1) * B, 1.f, 0, st);
+    gemm(h, h->dGx + (size_t)B * WS + 4 * H, 0, 1, WS, h->Hs, 0, 1, H, h->dGd.attn_W_weight, H, nullptr, A, H, (T - 1) * B, 1.f, 0, st);
+  } else {
+    hipMemsetAsync(h->dGd.rnn_weight_hh_l0, 0, (size_t)4 * H * H * 4, st);
+    hipMemsetAsync(h->dGd.attn_W_weight, 0, (size_t)A * H * 4, st);
+  }
+  colsum(h->dGx, TB, 4 * H, WS, h->dGd.rnn_bias_ih_l0, st);
   copyf(h->dGd.rnn_bias_ih_l0, h->dGd.rnn_bias_hh_l0, 4 * H, st);
   gemm(h, h->dUv, 0, 1, A, enc, 0, 1, D, h->dGd.attn_U_weight, D, nullptr, A, D, B * F, 1.f, 0, st);
-  gemm(h, h->dWh, 0, 1, A, h->Xcat + D, 0, 1, D + H, h->dGd.attn_W_weight, H, nullptr, A, H, TB, 1.f, 0, st);
-  colsum(h->dWh, TB, A, A, h->dGd.attn_b, st);
+  colsum(h->dGx + 4 * H, TB, A, WS, h->dGd.attn_b, st);
   colsum(h->dwacc, B, A, A, h->dGd.attn_w_weight, st);
   return RECNET_OK;
 }
@@ -706,23 +719,17 @@ int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_
   const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V;
   const int pb = h->prec == RN_PREC_BF16;
   hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
-  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, 4 * H);
-  gemm(h, enc, 0, 0, D, h->dP.attn_U_weight, 0, 0, D, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
+  dec_invariants(h, enc, st);   // the reference recomputes attn_U(encoder_outputs) on every call too (decoder.py:54)
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(B), dim3(128), 0, st, h->dP.embedding_weight, (const int64_t*)nullptr, tokens,
                      h->emb, B, E, V, h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), t);
   gemm(h, h->emb, 0, 0, E, h->dP.rnn_weight_ih_l0, 0, 0, E + D, h->Xe, 4 * H, h->bsum_d, B, 4 * H, E, 1.f, 0, st);
-  DecStepArgs a;
-  a.t = t; a.B = B; a.F = F; a.D = D; a.H = H; a.A = A; a.S = 0; a.do_lstm = 0; a.do_attn = 1;
-  a.slab = nullptr; a.Xe = nullptr; a.c_prev = nullptr; a.h_out = nullptr; a.c_out = nullptr; a.acts = nullptr;
-  a.h_in = h_in; a.h_in_ld = H; a.xcat = h->Xcat; a.xcat_ld = D + H;
-  a.W = h->dP.attn_W_weight; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight; a.enc = enc;
-  a.Wh_out = nullptr; a.att_out = nullptr;
-  const size_t sm = dec_step_smem(h);
-  hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
-  int S = gemm_slabs(h, RN_TAG_DEC_FWD, h->Xcat, 0, D + H, h->Wch, pb, 0, D + H, B, 4 * H, D + H, st);
-  a.S = S; a.do_lstm = 1; a.do_attn = 0; a.slab = h->slab; a.Xe = h->Xe; a.c_prev = c_in; a.h_out = h_out; a.c_out = c_out;
-  a.xcat = nullptr;
-  hipLaunchKernelGGL(dec_step_kernel, dim3(B), dim3(256), sm, st, a);
+  int S = 0;
+  if (h_in) S = gemm_slabs(h, RN_TAG_DEC_FWD, h_in, 0, H, h->Wcomb, pb, 0, H, B, 4 * H + A, H, st);
+  DecCellArgs a;
+  a.t = t; a.B = B; a.F = F; a.H = H; a.A = A; a.S = S; a.slab = h_in ? h->slab : nullptr;
+  a.Xe = h->Xe; a.P = h->P; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
+  a.c_prev = c_in; a.h_out = h_out; a.c_out = c_out; a.acts = nullptr; a.Wh_out = nullptr; a.att_out = nullptr;
+  launch_dec_cell(h, a, st);
   gemm(h, h_out, 0, 0, H, h->dP.out_weight, 0, 0, H, logits, V, h->dP.out_bias, B, V, H, 1.f, 0, st);
   if (train && h->c.decoder_out_dropout > 0.f)
     hipLaunchKernelGGL(logits_drop_kernel, dim3(ew_blocks((size_t)B * V)), dim3(256), 0, st, logits, B, V,
@@ -929,7 +936,7 @@ int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, c
 double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which) {
   if (!h) return 0;
   const double wb = h->prec == RN_PREC_BF16 ? 2.0 : 4.0;
-  if (which == 0) return (double)4 * h->H * (h->D + h->H) * wb + (double)h->B * (h->D + h->H) * 4 + (double)h->B * 4 * h->H * 4;
+  if (which == 0) return (double)(4 * h->H + h->A) * h->H * wb + (double)h->B * h->H * 4 + (double)h->B * (4 * h->H + h->A) * 4;
   if (h->kind == RECNET_REC_GLOBAL) return (double)4 * h->R * h->R * 4.0 + (double)h->B * h->R * 4 + (double)h->B * 4 * h->R * 4;
   if (h->kind == RECNET_REC_LOCAL) return (double)4 * h->R * (h->H + h->R) * wb + (double)h->B * (h->H + h->R) * 4 + (double)h->B * 4 * h->R * 4;
   return 0;

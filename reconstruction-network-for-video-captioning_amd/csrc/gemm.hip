@@ -39,9 +39,11 @@ int rn_pick_splitk(int prec, int M, int N, int K, int max_split) {
 
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
-                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag) {
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag, int c_bf16) {
   if (M <= 0 || N <= 0) return;
   GemmArgs a;
+  a.c_bf16 = c_bf16;
+  if (c_bf16) splitk = 1;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.accumulate = accumulate;

@@ -22,6 +22,7 @@ struct GemmArgs {
   int splitk; int kchunk;     // kchunk: multiple of BK; K range of slice z = [z*kchunk, min(K,(z+1)*kchunk))
   float* ws;                  // fp32 slabs [splitk][M][N] when splitk > 1
   int a_vec, b_vec;           // 16-byte vector loads are legal for this operand (alignment checked on host)
+  int c_bf16;                 // direct epilogue stores bf16 into C (reinterpreted); requires splitk == 1
 };
 
 template <typename CT> struct GemmCfg;
@@ -239,9 +240,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const int row = m0 + wm + i * 16 + cr + r;
             if (row < p.M) {
               float v = p.alpha * acc[i][j][r] + bv;
-              float* dst = p.C + (size_t)row * p.ldc + col;
-              if (p.accumulate) v += *dst;
-              *dst = v;
+              if (p.c_bf16) {
+                reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + col] = (bf16_t)v;
+              } else {
+                float* dst = p.C + (size_t)row * p.ldc + col;
+                if (p.accumulate) v += *dst;
+                *dst = v;
+              }
             }
           }
         }

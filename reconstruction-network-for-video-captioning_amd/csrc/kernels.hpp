@@ -135,191 +135,193 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb
 }
 
 // =============================================================================================
-// decoder recurrent step, forward: one workgroup per caption
-//   phase 1 (do_lstm): gates of step t-1 = Xe[t-1] + sum_z slab_z  -> h_{t-1}, c_{t-1}
-//   phase 2 (do_attn): Wh = W h ; a[f] = w . tanh(Wh + Uv[b,f] + b) ; ctx = (1/F) sum_f a[f] enc[b,f]
-//                      (decoder.py:50-61: un-normalised scores, MEAN over frames)
+// decoder recurrent step (decoder.py:50-66), forward.
+// Exact-math restructuring: ctx_t . W_c^T = (1/F) sum_f a_t[f] (enc[b,f] . W_c^T) = (1/F) sum_f a_t[f] P[b,f,:]
+// with P = enc . W_ih[:, E:]^T hoisted out of the time loop, so the only GEMM left in the chain is
+// h_{t-1} . [W_hh ; attn_W]^T (K = H).  One workgroup per (caption, 64-hidden-unit chunk):
+//   Wh  = slab columns [4H, 4H+A)                           (attn_W h_{t-1})
+//   a[f] = w . tanh(Wh + Uv[b,f] + b)                        one wave per frame, wavefront reduction
+//   gates[col] = Xe[t,b,col] + h.W_hh^T (slabs) + (1/F) sum_f a[f] P[b,f,col]   for the chunk's 4 x 64 columns
+//   LSTM pointwise -> h_t, c_t, saved activations
 // =============================================================================================
-struct DecStepArgs {
-  int t, B, F, D, H, A, S;
-  int do_lstm, do_attn;
-  const float* slab;      // [S][B][4H] split-K partials of [ctx, h] . [W_c | W_hh]^T for step t-1
-  const float* Xe;        // [B][4H]  emb . W_e^T + b_ih + b_hh for step t-1
-  const float* c_prev;    // [B][H] or nullptr (zeros)
-  float* h_out;           // [B][H] (step t-1)
-  float* c_out;           // [B][H]
-  float* acts;            // [B][4H] post-activation gates (saved for backward) or nullptr
-  const float* h_in;      // !do_lstm: hidden state to attend with, [B][h_in_ld] or nullptr (zeros)
-  int h_in_ld;
-  float* xcat;            // [B][xcat_ld]: ctx -> [0,D), h -> [D,D+H) of step t's GEMM input (nullptr: skip)
-  int xcat_ld;
-  const float* W;         // [A][H]
+#define RN_UC 64
+struct DecCellArgs {
+  int t, B, F, H, A, S;
+  const float* slab;      // [S][B][4H+A] split-K partials of h_{t-1} . [W_hh ; W]^T, nullptr when h_{t-1} = 0
+  const float* Xe;        // [B][4H] of step t (emb . W_e^T + b_ih + b_hh)
+  const void* P;          // [B][F][4H] (bf16 in the bf16 path, fp32 in the exact path)
   const float* Uv;        // [B][F][A]
-  const float* ab;        // [A]
-  const float* w;         // [A]
-  const float* enc;       // [B][F][D]
+  const float* ab; const float* w;
+  const float* c_prev;    // [B][H] or nullptr (zeros)
+  float* h_out; float* c_out;   // [B][H] of step t
+  float* acts;            // [B][4H] post-activation gates or nullptr
   float* Wh_out;          // [B][A] or nullptr
   float* att_out;         // [B][F] or nullptr
 };
 
-__global__ __launch_bounds__(256) void dec_step_kernel(const DecStepArgs p) {
+template <typename PT>
+__global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sh = smem;              // [H]
-  float* swh = sh + p.H;         // [A]
-  float* sa = swh + p.A;         // [F]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = p.H;
-
-  if (p.do_lstm) {
-    const size_t zs = (size_t)p.B * 4 * H;
-    for (int u = tid; u < H; u += 256) {
-      float g[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const size_t o = (size_t)b * 4 * H + q * H + u;
-        float v = p.Xe[o];
-        for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + o];
-        g[q] = v;
-      }
-      const float cp = p.c_prev ? p.c_prev[(size_t)b * H + u] : 0.f;
-      const LstmOut r = lstm_point(g[0], g[1], g[2], g[3], cp);
-      p.h_out[(size_t)b * H + u] = r.h;
-      p.c_out[(size_t)b * H + u] = r.c;
-      if (p.acts) {
-        float* a = p.acts + (size_t)b * 4 * H + u;
-        a[0] = r.i; a[H] = r.f; a[2 * H] = r.g; a[3 * H] = r.o;
-      }
-      sh[u] = r.h;
+  float* swh = smem;            // [A]
+  float* sa = swh + p.A;        // [F]
+  float* spre = sa + p.F;       // [4 * RN_UC]
+  const int b = blockIdx.x, u0 = blockIdx.y * RN_UC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
+  const size_t zs = (size_t)p.B * WS;
+  for (int k = tid; k < A; k += 256) {
+    float v = 0.f;
+    if (p.slab) for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * WS + W4 + k];
+    swh[k] = v;
+    if (p.Wh_out && blockIdx.y == 0) p.Wh_out[(size_t)b * A + k] = v;
+  }
+  __syncthreads();
+  for (int f = wave; f < F; f += 4) {
+    const float* uv = p.Uv + ((size_t)b * F + f) * A;
+    float s = 0.f;
+    for (int k = lane; k < A; k += 64) s += p.w[k] * tanhf(swh[k] + uv[k] + p.ab[k]);
+    s = wave_sum(s);
+    if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+  }
+  __syncthreads();
+  const int g = wave, u = u0 + lane;          // one wave per gate, one lane per hidden unit of the chunk
+  float pre = 0.f;
+  if (u < H) {
+    const int col = g * H + u;
+    pre = p.Xe[(size_t)b * W4 + col];
+    if (p.slab) for (int z = 0; z < p.S; ++z) pre += p.slab[z * zs + (size_t)b * WS + col];
+    const PT* pp = reinterpret_cast<const PT*>(p.P) + (size_t)b * F * W4 + col;
+    float c = 0.f;
+    for (int f = 0; f < F; ++f) c += sa[f] * (float)pp[(size_t)f * W4];
+    pre += c * (1.0f / (float)F);
+  }
+  spre[g * RN_UC + lane] = pre;
+  __syncthreads();
+  if (tid < RN_UC && u0 + tid < H) {
+    const int uu = u0 + tid;
+    const size_t o = (size_t)b * H + uu;
+    const LstmOut r = lstm_point(spre[tid], spre[RN_UC + tid], spre[2 * RN_UC + tid], spre[3 * RN_UC + tid],
+                                 p.c_prev ? p.c_prev[o] : 0.f);
+    p.h_out[o] = r.h;
+    p.c_out[o] = r.c;
+    if (p.acts) {
+      float* a = p.acts + (size_t)b * W4 + uu;
+      a[0] = r.i; a[H] = r.f; a[2 * H] = r.g; a[3 * H] = r.o;
     }
-  } else {
-    for (int u = tid; u < H; u += 256) sh[u] = p.h_in ? p.h_in[(size_t)b * p.h_in_ld + u] : 0.f;
-  }
-  if (!p.do_attn) return;
-  if (p.xcat)
-    for (int u = tid; u < H; u += 256) p.xcat[(size_t)b * p.xcat_ld + p.D + u] = sh[u];
-  __syncthreads();
-
-  // Wh[k] = sum_u W[k,u] h[u]: one wave per k, lanes stride over u (coalesced rows of W)
-  for (int k = wave; k < p.A; k += 4) {
-    const float* wr = p.W + (size_t)k * H;
-    float s = 0.f;
-    for (int u = lane; u < H; u += 64) s += wr[u] * sh[u];
-    s = wave_sum(s);
-    if (lane == 0) { swh[k] = s; if (p.Wh_out) p.Wh_out[(size_t)b * p.A + k] = s; }
-  }
-  __syncthreads();
-  // a[f] = sum_k w[k] tanh(Wh[k] + Uv[b,f,k] + ab[k]): one wave per frame, wavefront reduction
-  for (int f = wave; f < p.F; f += 4) {
-    const float* uv = p.Uv + ((size_t)b * p.F + f) * p.A;
-    float s = 0.f;
-    for (int k = lane; k < p.A; k += 64) s += p.w[k] * tanhf(swh[k] + uv[k] + p.ab[k]);
-    s = wave_sum(s);
-    if (lane == 0) { sa[f] = s; if (p.att_out) p.att_out[(size_t)b * p.F + f] = s; }
-  }
-  __syncthreads();
-  // ctx[d] = (1/F) sum_f a[f] enc[b,f,d]
-  const float* e = p.enc + (size_t)b * p.F * p.D;
-  const float invF = 1.0f / (float)p.F;
-  for (int d = tid; d < p.D; d += 256) {
-    float s = 0.f;
-    for (int f = 0; f < p.F; ++f) s += sa[f] * e[(size_t)f * p.D + d];
-    p.xcat[(size_t)b * p.xcat_ld + d] = s * invF;
   }
 }
 
 // =============================================================================================
-// decoder recurrent step, backward: one workgroup per caption
-//   phase A (do_attn): attention backward of step t from dXcat_t = dG_t . [W_c | W_hh] (split-K slabs)
-//   phase B (do_lstm): LSTM pointwise backward of step t-1
+// decoder recurrent step, backward: one workgroup per caption.
+//   dh_t = dHs[t] + (dgates_{t+1} | dWh_{t+1}) . [W_hh ; W] (split-K slabs)  -> LSTM pointwise backward -> dgates_t
+//   da[f] = (1/F) dgates_t . P[b,f,:]   ;   dz = da[f] w (1 - tanh^2)   ;  dWh, dUv, dw accumulate
+// dgates_t and dWh_t are written side by side into one [B][4H+A] row: the A operand of the next
+// step's GEMM and of every deferred weight-gradient GEMM.
 // =============================================================================================
-struct DecBwdArgs {
-  int t, B, F, D, H, A, S;
-  int do_attn, do_lstm;
-  const float* slab;     // [S][B][D+H]
-  const float* enc; const float* Uv; const float* ab; const float* w; const float* W;
+struct DecCellBwdArgs {
+  int t, B, F, H, A, S;
+  const float* slab;     // [S][B][H] or nullptr (t == T-1)
+  const float* dHs;      // [B][H] direct gradient of h_t (vocabulary projection + reconstructor)
+  const float* acts; const float* c; const float* c_prev;
+  float* dc_carry; int first;
+  float* dGx;            // [B][4H+A]
+  const void* P; const float* Uv; const float* ab; const float* w;
   const float* Wh;       // [B][A] of step t
   float* dUv;            // [B][F][A] accumulated over t
-  float* dWh;            // [B][A] of step t (saved for the deferred dW = dWh^T h_prev GEMM)
-  float* dwacc;          // [B][A] accumulated over t: sum_f da[f] tanh(z[f,k])
-  int first_attn;        // initialise dUv / dwacc instead of accumulating
-  const float* dHs;      // [B][H] direct gradient of h_{t-1} (vocabulary projection + reconstructor)
-  const float* acts;     // [B][4H] of step t-1
-  const float* c;        // [B][H] c_{t-1}
-  const float* c_prev;   // [B][H] c_{t-2} or nullptr
-  float* dc_carry;       // [B][H]
-  int first_lstm;        // dc_carry starts at zero
-  float* dG;             // [B][4H] of step t-1
+  float* dwacc;          // [B][A] accumulated over t
 };
 
-__global__ __launch_bounds__(256) void dec_bwd_step_kernel(const DecBwdArgs p) {
+template <typename PT>
+__global__ __launch_bounds__(512) void dec_cell_bwd_kernel(const DecCellBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sdctx = smem;            // [D]
-  float* sdh = sdctx + p.D;       // [H]
-  float* sda = sdh + p.H;         // [F]
-  float* sdWh = sda + p.F;        // [A]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int H = p.H, D = p.D, A = p.A, F = p.F;
-
-  if (p.do_attn) {
-    const int W2 = D + H;
-    const size_t zs = (size_t)p.B * W2;
-    for (int j = tid; j < W2; j += 256) {
-      float v = 0.f;
-      for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * W2 + j];
-      if (j < D) sdctx[j] = v; else sdh[j - D] = v;
-    }
-    __syncthreads();
-    // da[f] = (1/F) dctx . enc[b,f,:]
-    const float* e = p.enc + (size_t)b * F * D;
-    const float invF = 1.0f / (float)F;
-    for (int f = wave; f < F; f += 4) {
-      float s = 0.f;
-      for (int d = lane; d < D; d += 64) s += sdctx[d] * e[(size_t)f * D + d];
-      s = wave_sum(s);
-      if (lane == 0) sda[f] = s * invF;
-    }
-    __syncthreads();
-    for (int k = tid; k < A; k += 256) {
-      const float whk = p.Wh[(size_t)b * A + k] + p.ab[k];
-      const float wk = p.w[k];
-      float dwh = 0.f, dw = 0.f;
-      for (int f = 0; f < F; ++f) {
-        const size_t o = ((size_t)b * F + f) * A + k;
-        const float tz = tanhf(whk + p.Uv[o]);
-        const float ds = sda[f] * wk * (1.f - tz * tz);
-        dw += sda[f] * tz;
-        dwh += ds;
-        p.dUv[o] = p.first_attn ? ds : p.dUv[o] + ds;
-      }
-      sdWh[k] = dwh;
-      p.dWh[(size_t)b * A + k] = dwh;
-      const size_t o2 = (size_t)b * A + k;
-      p.dwacc[o2] = p.first_attn ? dw : p.dwacc[o2] + dw;
-    }
-    __syncthreads();
-    // dh_{t-1} += dWh . W   (threads over u: coalesced rows of W)
-    for (int u = tid; u < H; u += 256) {
-      float s = 0.f;
-      for (int k = 0; k < A; ++k) s += sdWh[k] * p.W[(size_t)k * H + u];
-      sdh[u] += s;
-    }
-    __syncthreads();
-  } else {
-    for (int u = tid; u < H; u += 256) sdh[u] = 0.f;
-    __syncthreads();
-  }
-  if (!p.do_lstm) return;
-  for (int u = tid; u < H; u += 256) {
+  float* sdg = smem;            // [4H]
+  float* sda = sdg + 4 * p.H;   // [F]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x, NW = NT >> 6;
+  const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
+  const size_t zs = (size_t)p.B * H;
+  float* dgx = p.dGx + (size_t)b * WS;
+  for (int u = tid; u < H; u += NT) {
     const size_t o = (size_t)b * H + u;
-    const float dh = p.dHs[o] + sdh[u];
-    const float* a = p.acts + (size_t)b * 4 * H + u;
-    const float dc_in = p.first_lstm ? 0.f : p.dc_carry[o];
-    const LstmGrad g = lstm_point_bwd(dh, dc_in, a[0], a[H], a[2 * H], a[3 * H], p.c[o],
+    float dh = p.dHs[o];
+    if (p.slab) for (int z = 0; z < p.S; ++z) dh += p.slab[z * zs + o];
+    const float* a = p.acts + (size_t)b * W4 + u;
+    const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_carry[o], a[0], a[H], a[2 * H], a[3 * H], p.c[o],
                                       p.c_prev ? p.c_prev[o] : 0.f);
-    float* dg = p.dG + (size_t)b * 4 * H + u;
-    dg[0] = g.di; dg[H] = g.df; dg[2 * H] = g.dg; dg[3 * H] = g.d_o;
+    sdg[u] = g.di; sdg[H + u] = g.df; sdg[2 * H + u] = g.dg; sdg[3 * H + u] = g.d_o;
+    dgx[u] = g.di; dgx[H + u] = g.df; dgx[2 * H + u] = g.dg; dgx[3 * H + u] = g.d_o;
     p.dc_carry[o] = g.dc_prev;
   }
+  __syncthreads();
+  const float invF = 1.0f / (float)F;
+  const PT* Pb = reinterpret_cast<const PT*>(p.P) + (size_t)b * F * W4;
+  for (int f = wave; f < F; f += NW) {
+    const PT* pp = Pb + (size_t)f * W4;
+    float s = 0.f;
+    for (int n = lane; n < W4; n += 64) s += sdg[n] * (float)pp[n];
+    s = wave_sum(s);
+    if (lane == 0) sda[f] = s * invF;
+  }
+  __syncthreads();
+  for (int k = tid; k < A; k += NT) {
+    const float whk = p.Wh[(size_t)b * A + k] + p.ab[k];
+    const float wk = p.w[k];
+    float dwh = 0.f, dw = 0.f;
+    for (int f = 0; f < F; ++f) {
+      const size_t o = ((size_t)b * F + f) * A + k;
+      const float tz = tanhf(whk + p.Uv[o]);
+      const float ds = sda[f] * wk * (1.f - tz * tz);
+      dw += sda[f] * tz;
+      dwh += ds;
+      p.dUv[o] = p.first ? ds : p.dUv[o] + ds;
+    }
+    dgx[W4 + k] = dwh;
+    const size_t o2 = (size_t)b * A + k;
+    p.dwacc[o2] = p.first ? dw : p.dwacc[o2] + dw;
+  }
+}
+
+// ctx[t,b,d] = (1/F) sum_f att[t,b,f] enc[b,f,d] for all t at once (the attended features of every step,
+// needed only by the deferred dW_ih[:, E:] = dgates^T . ctx GEMM).  grid (B, ceil(D/256)); T <= 32.
+__global__ __launch_bounds__(256) void ctx_all_kernel(const float* __restrict__ att, const float* __restrict__ enc,
+                                                      float* __restrict__ ctx, int T, int B, int F, int D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [32][F], zero padded beyond T
+  const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < 32 * F; i += 256) {
+    const int t = i / F, f = i % F;
+    smem[i] = t < T ? att[((size_t)t * B + b) * F + f] : 0.f;
+  }
+  __syncthreads();
+  if (d >= D) return;
+  float acc[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+  for (int f = 0; f < F; ++f) {
+    const float e = enc[((size_t)b * F + f) * D + d];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc[t] += smem[t * F + f] * e;
+  }
+  const float invF = 1.0f / (float)F;
+#pragma unroll
+  for (int t = 0; t < 32; ++t)
+    if (t < T) ctx[((size_t)t * B + b) * D + d] = acc[t] * invF;
+}
+// general-T fallback (caption_max_len + 1 > 32)
+__global__ __launch_bounds__(256) void ctx_all_slow_kernel(const float* __restrict__ att, const float* __restrict__ enc,
+                                                           float* __restrict__ ctx, int T, int B, int F, int D) {
+  const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
+  if (d >= D) return;
+  for (int t = 0; t < T; ++t) {
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += att[((size_t)t * B + b) * F + f] * enc[((size_t)b * F + f) * D + d];
+    ctx[((size_t)t * B + b) * D + d] = s / (float)F;
+  }
+}
+
+// dst = [src1 (n1 elements) ; src2 (n2 elements)] converted to DT (vertical concatenation of equal-width matrices)
+template <typename DT>
+__global__ void packv_kernel(DT* __restrict__ dst, const float* __restrict__ src1, size_t n1,
+                             const float* __restrict__ src2, size_t n2) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (DT)(i < n1 ? src1[i] : src2[i - n1]);
 }
 
 // =============================================================================================
