@@ -220,6 +220,11 @@ int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms);
 int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, const float* B, int32_t b_col,
                 int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K,
                 float alpha, int32_t accumulate, int32_t splitk, float* splitk_ws, void* stream);
+/* Same with bf16 operands in memory (the production kernel of the bf16 path, csrc/gemm_lds.hpp): needs 16-byte
+ * aligned bases and leading dimensions that are multiples of 8.  tag 0 = batched form, 1..5 = chain-site forms. */
+int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, int32_t b_col, int32_t ldb, float* C,
+                     int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
+                     int32_t splitk, float* splitk_ws, int32_t tag, void* stream);
 /* Name / start / duration of the dominant kernel's launches inside the last train step are measured
  * by the caller with hipEvents; this returns the algorithmic bytes one recurrent-step launch moves. */
 double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which /*0 decoder,1 reconstructor*/);

@@ -33,23 +33,30 @@ struct OptGroup {
   bool bound = false;
 };
 
+static inline int pad8(int n) { return (n + 7) & ~7; }
+
 struct recnet_handle {
   recnet_config c;
   int B, F, D, E, H, A, V, R, RA, Tm, kind, prec, cml;
+  int lp;                // 1: operand copies / packed weights are bf16 (DMA-staged GEMM); 0: fp32 (exact path)
+  // leading dimensions (elements) of the operand buffers: multiples of 8
+  int ldD, ldE, ldH, ldV, ldA, ld4H, ldWS, ldR, ld4R, ldRA, ldHR;
   // workspace
   char* ws = nullptr; size_t ws_bytes = 0; size_t need = 0;
-  // ---- carved regions
   uint32_t* ctrl;        // [0] seed slot, [1] step slot (int32)
-  float* scal;           // internal scalars: [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
-  float *bsum_d, *Uv, *emb, *Xe, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws;
-  float *dGx, *dHs, *dc_carry, *dUv, *dwacc, *demb, *stepw, *ctxall;
-  void* P;               // [B][F][4H] = enc . W_ih[:, E:]^T (bf16 in the bf16 path, else fp32)
-  void* Wcomb;           // packed [4H + A][H] = [W_hh ; attn_W] (bf16 or f32)
-  // reconstructor
-  float *bsum_r, *mp, *mpd, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dGr, *dmpd, *dmp, *dcr_carry, *msep;
-  float *dHsrec;
-  float *Ud, *Xcat_r, *beta, *Whr, *outl, *dHr, *dUd, *dWhr, *dwacc_r;
-  void* Wihh;            // packed [4R][H+R]
+  float* scal;           // [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
+  // ---- decoder: fp32 state
+  float *bsum_d, *Uv, *Xe, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws, *dHs, *dHsrec, *dc_carry, *dUv,
+      *dwacc, *demb, *stepw, *msep;
+  // ---- decoder: operand copies (AT = bf16 | float)
+  void *enc_lp, *emb_lp, *Hs_lp, *P, *dlog_lp, *dGx, *ctx_lp, *dUv_lp, *dWhs;
+  // ---- decoder: packed weights (AT)
+  void *U_w, *Wc_w, *We_w, *Wcomb, *Wo_w;
+  // ---- reconstructor
+  float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
+  float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
+  void *mpd_lp, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr;
+  void *Wih_a, *Wih_b, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   size_t gws_floats, slab_floats;
   // bindings
   recnet_decoder_tensors dP{}, dGd{}, dM{}, dV{}, dVm{};
@@ -70,15 +77,21 @@ static size_t carve(recnet_handle* h, char* base) {
     off += ((nfloats * 4 + 255) / 256) * 256;
     return p;
   };
+  // operand buffers are sized as if fp32 (the bf16 path uses half of each)
+  auto takev = [&](size_t n) -> void* { return (void*)take(n); };
   const size_t B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, R = h->R, RA = h->RA, Tm = h->Tm;
+  h->ldD = pad8(h->D); h->ldE = pad8(h->E); h->ldH = pad8(h->H); h->ldV = pad8(h->V); h->ldA = pad8(h->A);
+  h->ld4H = pad8(4 * h->H); h->ldWS = pad8(4 * h->H + RN_FCH * h->A);
+  h->ldR = pad8(h->R); h->ld4R = pad8(4 * h->R); h->ldRA = pad8(h->RA); h->ldHR = pad8(h->H + h->R);
+  const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
+               ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
   h->scal = take(64);
   h->stepw = take(Tm);
+  h->msep = take(1024);
   h->bsum_d = take(4 * H);
   h->Uv = take(B * F * A);
-  h->emb = take(Tm * B * E);
   h->Xe = take(Tm * B * 4 * H);
-  h->P = take(B * F * 4 * H);
   h->Hs = take(Tm * B * H);
   h->Cs = take(Tm * B * H);
   h->acts = take(Tm * B * 4 * H);
@@ -86,15 +99,26 @@ static size_t carve(recnet_handle* h, char* base) {
   h->att = take(Tm * B * F);
   h->logits = take(Tm * B * V);
   h->rowloss = take(Tm * B);
-  h->dGx = take(Tm * B * (4 * H + A));
-  h->ctxall = take(Tm * B * D);
   h->dHs = take(Tm * B * H);
   h->dHsrec = take(Tm * B * H);
-  h->dc_carry = take(B * H);
+  h->dc_carry = take(2 * B * H);
   h->dUv = take(B * F * A);
-  h->dwacc = take(B * A);
+  h->dwacc = take(RN_FCH * B * A);
   h->demb = take(Tm * B * E);
-  h->Wcomb = take((4 * H + A) * H);
+  h->enc_lp = takev(B * F * ldD);
+  h->emb_lp = takev(Tm * B * ldE);
+  h->Hs_lp = takev(Tm * B * ldH);
+  h->P = takev(B * F * ld4H);
+  h->dlog_lp = takev(Tm * B * ldV);
+  h->dGx = takev(Tm * B * ldWS);
+  h->ctx_lp = takev(Tm * B * ldD);
+  h->dUv_lp = takev(B * F * ldA);
+  h->dWhs = takev(Tm * B * ldA);
+  h->U_w = takev(A * ldD);
+  h->Wc_w = takev(4 * H * ldD);
+  h->We_w = takev(4 * H * ldE);
+  h->Wcomb = takev((4 * H + RN_FCH * A) * ldH);
+  h->Wo_w = takev(V * ldH);
   size_t maxN = 4 * H + A;
   if (h->kind != RECNET_REC_NONE) {
     if (4 * R > maxN) maxN = 4 * R;
@@ -104,20 +128,27 @@ static size_t carve(recnet_handle* h, char* base) {
   h->slab = take(h->slab_floats);
   h->gws_floats = (size_t)16 << 20;   // 64 MiB of split-K slabs for the batched GEMMs
   h->gws = take(h->gws_floats);
-  h->msep = take(1024);
-  if (h->kind == RECNET_REC_GLOBAL) {
+  if (h->kind != RECNET_REC_NONE) {
     h->bsum_r = take(4 * R);
-    h->mp = take(B * H); h->mpd = take(Tm * B * H); h->Xg = take(Tm * B * 4 * R);
+    h->dcr_carry = take(B * R);
+    h->Wor_w = takev(R * ldR);
+  }
+  if (h->kind == RECNET_REC_GLOBAL) {
+    h->mp = take(B * H); h->Xg = take(Tm * B * 4 * R);
     h->Hr = take(Tm * B * R); h->Cr = take(Tm * B * R); h->acts_r = take(Tm * B * 4 * R);
     h->hrmean = take(B * R); h->outm = take(B * R); h->encmean = take(B * R); h->dhrmean = take(B * R);
-    h->dGr = take(Tm * B * 4 * R); h->dmpd = take(Tm * B * H); h->dmp = take(B * H); h->dcr_carry = take(B * R);
+    h->dmpd = take(Tm * B * H); h->dmp = take(B * H);
+    h->mpd_lp = takev(Tm * B * ldH); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
+    h->dout_lp = takev(B * ldR); h->dGr = takev(Tm * B * ld4R);
+    h->Wih_a = takev(4 * R * ldH); h->Wih_b = takev(4 * R * ldH); h->Whh_w = takev(4 * R * ldR);
   } else if (h->kind == RECNET_REC_LOCAL) {
-    h->Ud = take(Tm * B * RA); h->Xcat_r = take(F * B * (H + R));
+    h->Ud = take(Tm * B * RA);
     h->Hr = take(F * B * R); h->Cr = take(F * B * R); h->acts_r = take(F * B * 4 * R);
     h->beta = take(F * B * Tm); h->Whr = take(F * B * RA); h->outl = take(F * B * R); h->dHr = take(F * B * R);
-    h->dGr = take(F * B * 4 * R); h->dUd = take(Tm * B * RA); h->dWhr = take(F * B * RA); h->dwacc_r = take(B * RA);
-    h->dcr_carry = take(B * R);
-    h->Wihh = take(4 * R * (H + R));
+    h->dUd = take(Tm * B * RA); h->dwacc_r = take(B * RA);
+    h->Xcat_r = takev(F * B * ldHR); h->Hr_lp = takev(F * B * ldR); h->dout_lp = takev(F * B * ldR);
+    h->dGr = takev(F * B * ld4R); h->dUd_lp = takev(Tm * B * ldRA); h->dWhr = takev(F * B * ldRA);
+    h->Ur_w = takev(RA * ldH); h->Wr_w = takev(RA * ldR); h->Wihh_w = takev(4 * R * ldHR);
   }
   // optimiser tables (sizes are upper bounds; filled at bind time)
   for (int g = 0; g < 2; ++g) {
@@ -172,7 +203,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->R = c.reconstructor_type ? c.reconstructor_hidden_size : 0;
   h->RA = c.reconstructor_type == RECNET_REC_LOCAL ? c.reconstructor_attn_size : 0;
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
-  h->kind = c.reconstructor_type; h->prec = c.precision;
+  h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
   h->need = carve(h, nullptr);
   *out = h;
   return RECNET_OK;
@@ -296,19 +327,32 @@ int recnet_bind_reconstructor(recnet_handle* h, const recnet_reconstructor_tenso
 // internal helpers
 // ================================================================================================
 #define REQUIRE_WS(h) do { if (!(h) || !(h)->ws) return fail(RECNET_ESTATE, "workspace not bound"); } while (0)
+// kernels that read / write operand copies are templated on the operand type AT (bf16 | float)
+#define LAUNCH_AT(h, kern, grid, block, smem, st, ...)                                          \
+  do { if ((h)->lp) hipLaunchKernelGGL((kern<bf16_t>), grid, block, smem, st, __VA_ARGS__);     \
+       else hipLaunchKernelGGL((kern<float>), grid, block, smem, st, __VA_ARGS__); } while (0)
 
-static void gemm(recnet_handle* h, const void* A, int a_bf16, int a_col, int lda, const void* Bm, int b_bf16, int b_col,
-                 int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha, int acc,
-                 hipStream_t st) {
-  // batched GEMM with automatic split-K (slabs reduced by splitk_reduce)
-  int s = rn_pick_splitk(h->prec, M, N, K, 32);
+static inline void* at_off(const recnet_handle* h, void* p, size_t elems) {
+  return (char*)p + elems * (h->lp ? 2 : 4);
+}
+
+// batched GEMM on operand buffers (AT) with automatic split-K; fp32 output
+static void gemm(recnet_handle* h, const void* A, int a_col, int lda, const void* Bm, int b_col, int ldb, float* C, int ldc,
+                 const float* bias, int M, int N, int K, float alpha, int acc, hipStream_t st) {
+  int s = rn_pick_splitk(h->prec, M, N, K, 16);
   while (s > 1 && (size_t)s * M * N > h->gws_floats) s >>= 1;
-  rn_launch_gemm(h->prec, A, a_bf16, a_col, lda, Bm, b_bf16, b_col, ldb, C, ldc, bias, M, N, K, alpha, acc, s, h->gws, 1, st);
+  rn_launch_gemm(h->prec, A, h->lp, a_col, lda, Bm, h->lp, b_col, ldb, C, ldc, bias, M, N, K, alpha, acc, s, h->gws, 1, st);
+}
+// same, output written as an operand buffer (AT) — direct epilogue only
+static void gemm_to_at(recnet_handle* h, const void* A, int a_col, int lda, const void* Bm, int b_col, int ldb, void* C,
+                       int ldc, int M, int N, int K, hipStream_t st) {
+  rn_launch_gemm(h->prec, A, h->lp, a_col, lda, Bm, h->lp, b_col, ldb, (float*)C, ldc, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0,
+                 st, 0, h->lp);
 }
 // recurrent-step GEMM: partial slabs only; returns the slab count the consumer must sum
-static int gemm_slabs(recnet_handle* h, int tag, const void* A, int a_col, int lda, const void* Bm, int b_bf16, int b_col, int ldb,
-                      int M, int N, int K, hipStream_t st) {
-  int s = rn_pick_splitk(h->prec, M, N, K, 32);
+static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const void* Bm, int b_col, int ldb, int M, int N,
+                      int K, hipStream_t st) {
+  int s = rn_pick_splitk(h->prec, M, N, K, 16);
   while (s > 1 && (size_t)s * M * N > h->slab_floats) s >>= 1;
   if (s < 2) s = 2;  // always use the slab path so the consumer code is uniform
   s = rn_effective_splitk(h->prec, K, s);
@@ -321,23 +365,34 @@ static int gemm_slabs(recnet_handle* h, int tag, const void* A, int a_col, int l
     e0 = h->prof_ev[h->prof_used++]; e1 = h->prof_ev[h->prof_used++];
     hipEventRecord(e0, st);
   }
-  if (s < 2) {
-    // K fits one tile: write the single product into slab 0 through the direct epilogue
-    rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, h->slab, N, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0, st, tag);
+  if (s < 2) {   // K fits one tile: the single product goes to slab 0 through the direct epilogue
+    rn_launch_gemm(h->prec, A, h->lp, 0, lda, Bm, h->lp, b_col, ldb, h->slab, N, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0, st, tag);
     s = 1;
   } else {
-    rn_launch_gemm(h->prec, A, 0, a_col, lda, Bm, b_bf16, b_col, ldb, nullptr, N, nullptr, M, N, K, 1.f, 0, s, h->slab, 0, st, tag);
+    rn_launch_gemm(h->prec, A, h->lp, 0, lda, Bm, h->lp, b_col, ldb, nullptr, N, nullptr, M, N, K, 1.f, 0, s, h->slab, 0, st, tag);
   }
   if (e1) hipEventRecord(e1, st);
   return s;
 }
-static void colsum(const float* X, int rows, int cols, int ld, float* out, hipStream_t st) {
+template <typename ST>
+static void colsum_t(const ST* X, int rows, int cols, int ld, float* out, hipStream_t st) {
   int rs = rows >= 512 ? 8 : 1;
   if (rs > 1) hipMemsetAsync(out, 0, (size_t)cols * 4, st);
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), rs), dim3(256), 0, st, X, rows, cols, ld, out, rs > 1 ? 1 : 0);
+  hipLaunchKernelGGL(colsum_kernel<ST>, dim3(cdiv(cols, 64), rs), dim3(256), 0, st, X, rows, cols, ld, out, rs > 1 ? 1 : 0);
+}
+static void colsum_at(recnet_handle* h, const void* X, int rows, int cols, int ld, float* out, hipStream_t st) {
+  if (h->lp) colsum_t<bf16_t>((const bf16_t*)X, rows, cols, ld, out, st);
+  else colsum_t<float>((const float*)X, rows, cols, ld, out, st);
 }
 static void copyf(const float* x, float* y, size_t n, hipStream_t st) {
   hipMemcpyAsync(y, x, n * 4, hipMemcpyDeviceToDevice, st);
+}
+// dst (AT) [rows][ld_dst] <- scale * src fp32 [rows][.. ld_src], zero padded
+static void pack_block(recnet_handle* h, void* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, float scale,
+                       hipStream_t st) {
+  const size_t n = (size_t)rows * ld_dst;
+  if (h->lp) hipLaunchKernelGGL(pack_block_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)dst, ld_dst, src, ld_src, rows, cols, scale);
+  else hipLaunchKernelGGL(pack_block_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)dst, ld_dst, src, ld_src, rows, cols, scale);
 }
 static void param_norms(recnet_handle* h, int g, float* sum_out, hipStream_t st) {
   OptGroup& o = h->og[g];
@@ -352,25 +407,31 @@ __global__ void export_scalars_kernel(const float* scal, recnet_scalars* out) {
   out->rec_reg = scal[4]; out->rec_loss = scal[5]; out->total_loss = scal[6]; out->dec_grad_norm = scal[7];
 }
 
+// Packed operand images of the weights (AT, zero padded leading dimensions), refreshed after every optimiser step.
 static int pack_weights(recnet_handle* h, hipStream_t st) {
-  const int H = h->H, R = h->R;
+  const int H = h->H, D = h->D, E = h->E, A = h->A, V = h->V, R = h->R, RA = h->RA;
   if (h->dec_bound) {
-    const size_t n1 = (size_t)4 * H * H, n2 = (size_t)h->A * H;
-    if (h->prec == RN_PREC_BF16)
-      hipLaunchKernelGGL(packv_kernel<bf16_t>, dim3(ew_blocks(n1 + n2)), dim3(256), 0, st, (bf16_t*)h->Wcomb,
-                         h->dP.rnn_weight_hh_l0, n1, h->dP.attn_W_weight, n2);
-    else
-      hipLaunchKernelGGL(packv_kernel<float>, dim3(ew_blocks(n1 + n2)), dim3(256), 0, st, (float*)h->Wcomb,
-                         h->dP.rnn_weight_hh_l0, n1, h->dP.attn_W_weight, n2);
+    pack_block(h, h->U_w, h->ldD, h->dP.attn_U_weight, D, A, D, 1.f, st);
+    pack_block(h, h->Wc_w, h->ldD, h->dP.rnn_weight_ih_l0 + E, E + D, 4 * H, D, 1.f, st);
+    pack_block(h, h->We_w, h->ldE, h->dP.rnn_weight_ih_l0, E + D, 4 * H, E, 1.f, st);
+    pack_block(h, h->Wcomb, h->ldH, h->dP.rnn_weight_hh_l0, H, 4 * H, H, 1.f, st);      // [W_hh ; W ; W ; W ; W]
+    for (int j = 0; j < RN_FCH; ++j)
+      pack_block(h, at_off(h, h->Wcomb, (size_t)(4 * H + j * A) * h->ldH), h->ldH, h->dP.attn_W_weight, H, A, H, 1.f, st);
+    pack_block(h, h->Wo_w, h->ldH, h->dP.out_weight, H, V, H, 1.f, st);
   }
-  if (h->rec_bound && h->kind == RECNET_REC_LOCAL) {
-    const size_t n = (size_t)4 * R * (H + R);
-    if (h->prec == RN_PREC_BF16)
-      hipLaunchKernelGGL(pack2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->Wihh,
-                         h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
-    else
-      hipLaunchKernelGGL(pack2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->Wihh,
-                         h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
+  if (h->rec_bound) {
+    pack_block(h, h->Wor_w, h->ldR, h->rP.out_weight, R, R, R, 1.f, st);
+    if (h->kind == RECNET_REC_GLOBAL) {
+      pack_block(h, h->Wih_a, h->ldH, h->rP.rnn_weight_ih_l0, 2 * H, 4 * R, H, 1.f, st);
+      pack_block(h, h->Wih_b, h->ldH, h->rP.rnn_weight_ih_l0 + H, 2 * H, 4 * R, H, 1.f, st);
+      pack_block(h, h->Whh_w, h->ldR, h->rP.rnn_weight_hh_l0, R, 4 * R, R, 1.f, st);
+    } else {
+      pack_block(h, h->Ur_w, h->ldH, h->rP.attn_U_weight, H, RA, H, 1.f, st);
+      pack_block(h, h->Wr_w, h->ldR, h->rP.attn_W_weight, R, RA, R, 1.f, st);
+      const size_t n = (size_t)4 * R * h->ldHR;    // [W_ih | W_hh | 0]
+      if (h->lp) hipLaunchKernelGGL(pack2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->Wihh_w, h->ldHR, h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
+      else hipLaunchKernelGGL(pack2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->Wihh_w, h->ldHR, h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
+    }
   }
   return RECNET_OK;
 }
@@ -378,50 +439,57 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
 static size_t dec_cell_smem(const recnet_handle* h) { return (size_t)(h->A + h->F + 4 * RN_UC + 16) * 4; }
 static void launch_dec_cell(recnet_handle* h, const DecCellArgs& a, hipStream_t st) {
   dim3 grid(h->B, cdiv(h->H, RN_UC));
-  if (h->prec == RN_PREC_BF16) hipLaunchKernelGGL(dec_cell_kernel<bf16_t>, grid, dim3(256), dec_cell_smem(h), st, a);
-  else hipLaunchKernelGGL(dec_cell_kernel<float>, grid, dim3(256), dec_cell_smem(h), st, a);
+  LAUNCH_AT(h, dec_cell_kernel, grid, dim3(256), dec_cell_smem(h), st, a);
 }
 // loop-invariant products of the decoder: Uv = enc . U^T (decoder.py:54) and P = enc . W_ih[:, E:]^T
 static void dec_invariants(recnet_handle* h, const float* enc, hipStream_t st) {
-  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A;
+  const int B = h->B, F = h->F, D = h->D, H = h->H, A = h->A;
   hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, 4 * H);
-  gemm(h, enc, 0, 0, D, h->dP.attn_U_weight, 0, 0, D, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
-  rn_launch_gemm(h->prec, enc, 0, 0, D, h->dP.rnn_weight_ih_l0 + E, 0, 0, E + D, (float*)h->P, 4 * H, nullptr, B * F, 4 * H, D,
-                 1.f, 0, 1, nullptr, 0, st, 0, h->prec == RN_PREC_BF16);
+  pack_block(h, h->enc_lp, h->ldD, enc, D, B * F, D, 1.f, st);
+  gemm(h, h->enc_lp, 0, h->ldD, h->U_w, 0, h->ldD, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
+  gemm_to_at(h, h->enc_lp, 0, h->ldD, h->Wc_w, 0, h->ldD, h->P, h->ld4H, B * F, 4 * H, D, st);
+}
+static void embed_fwd(recnet_handle* h, const int64_t* targets, const int64_t* tokens, int rows, int train, int t0, hipStream_t st) {
+  const DropDesc dd = mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train);
+  if (h->lp) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(rows), dim3(128), 0, st, h->dP.embedding_weight, targets, tokens, (bf16_t*)h->emb_lp, h->ldE, h->B, h->E, h->V, h->c.embedding_scale, dd, t0);
+  else hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(rows), dim3(128), 0, st, h->dP.embedding_weight, targets, tokens, (float*)h->emb_lp, h->ldE, h->B, h->E, h->V, h->c.embedding_scale, dd, t0);
 }
 
 // ---------------------------------------------------------------------------------------------- decoder forward
 static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw,
                        int train, float* hiddens_out, hipStream_t st) {
-  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V;
-  const int pb = h->prec == RN_PREC_BF16;
+  const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A, V = h->V;
   param_norms(h, 0, h->scal + 1, st);
   dec_invariants(h, enc, st);
   // all T teacher-forced input embeddings at once    (decoder.py:46-48, train.py:25,45)
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(T * B), dim3(128), 0, st, h->dP.embedding_weight, targets, (const int64_t*)nullptr,
-                     h->emb, B, E, V, h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), 0);
+  embed_fwd(h, targets, nullptr, T * B, train, 0, st);
   // Xe = emb . W_ih[:, :E]^T + b_ih + b_hh
-  gemm(h, h->emb, 0, 0, E, h->dP.rnn_weight_ih_l0, 0, 0, E + D, h->Xe, 4 * H, h->bsum_d, T * B, 4 * H, E, 1.f, 0, st);
+  gemm(h, h->emb_lp, 0, h->ldE, h->We_w, 0, h->ldE, h->Xe, 4 * H, h->bsum_d, T * B, 4 * H, E, 1.f, 0, st);
   DecCellArgs a;
   a.B = B; a.F = F; a.H = H; a.A = A;
-  a.P = h->P; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
+  a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
+  a.ld_hlp = h->ldH;
   for (int t = 0; t < T; ++t) {
     int S = 0;
     if (t > 0)   // h_{t-1} . [W_hh ; attn_W]^T  -> recurrent gate part + Wh of the attention
-      S = gemm_slabs(h, RN_TAG_DEC_FWD, h->Hs + (size_t)(t - 1) * B * H, 0, H, h->Wcomb, pb, 0, H, B, 4 * H + A, H, st);
+      S = gemm_slabs(h, RN_TAG_DEC_FWD, at_off(h, h->Hs_lp, (size_t)(t - 1) * B * h->ldH), h->ldH, h->Wcomb, 0, h->ldH, B, 4 * H + A, H, st);
     a.t = t; a.S = S; a.slab = t > 0 ? h->slab : nullptr;
     a.Xe = h->Xe + (size_t)t * B * 4 * H;
     a.c_prev = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
     a.h_out = h->Hs + (size_t)t * B * H; a.c_out = h->Cs + (size_t)t * B * H;
+    a.h_lp = at_off(h, h->Hs_lp, (size_t)t * B * h->ldH);
     a.acts = h->acts + (size_t)t * B * 4 * H;
     a.Wh_out = h->Wh + (size_t)t * B * A; a.att_out = h->att + (size_t)t * B * F;
     launch_dec_cell(h, a, st);
   }
   // logits for all steps, then masked CE with logits dropout (decoder.py:68-69, train.py:54-68)
-  gemm(h, h->Hs, 0, 0, H, h->dP.out_weight, 0, 0, H, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
+  gemm(h, h->Hs_lp, 0, h->ldH, h->Wo_w, 0, h->ldH, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
   copyf(stepw, h->stepw, T, st);
-  hipLaunchKernelGGL(ce_kernel, dim3(T * B), dim3(256), 0, st, h->logits, targets, h->stepw, h->rowloss, B, V,
-                     mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train), 1.0f, 1);
+  {
+    const DropDesc dd = mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train);
+    if (h->lp) hipLaunchKernelGGL(ce_kernel<bf16_t>, dim3(T * B), dim3(256), 0, st, h->logits, targets, h->stepw, h->rowloss, (bf16_t*)h->dlog_lp, h->ldV, B, V, dd);
+    else hipLaunchKernelGGL(ce_kernel<float>, dim3(T * B), dim3(256), 0, st, h->logits, targets, h->stepw, h->rowloss, (float*)h->dlog_lp, h->ldV, B, V, dd);
+  }
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, h->rowloss, T * B, h->scal + 0, 1.0f);
   hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 0, h->scal + 1, h->c.decoder_lambda_reg, h->scal + 2);
   hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 2, 0.f, h->scal + 6);
@@ -434,97 +502,122 @@ static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
 static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhid, float gscale,
                        hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, T = h->T_last;
-  const int pb = h->prec == RN_PREC_BF16, train = h->train_last;
-  const int TB = T * B, WS = 4 * H + A;
-  if (gscale != 1.0f) hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks((size_t)TB * V)), dim3(256), 0, st, h->logits, (size_t)TB * V, gscale);
+  const int train = h->train_last;
+  const int TB = T * B, ldWS = h->ldWS, KW = 4 * H + RN_FCH * A;
+  if (gscale != 1.0f) {
+    const size_t n = (size_t)TB * h->ldV;
+    if (h->lp) hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->dlog_lp, n, gscale);
+    else hipLaunchKernelGGL(scale_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->dlog_lp, n, gscale);
+  }
   // dHs = dhiddens (from the reconstructor) + dlogits . W_o
   if (dhid) copyf(dhid, h->dHs, (size_t)TB * H, st); else hipMemsetAsync(h->dHs, 0, (size_t)TB * H * 4, st);
-  gemm(h, h->logits, 0, 0, V, h->dP.out_weight, 0, 1, H, h->dHs, H, nullptr, TB, H, V, 1.f, 1, st);
+  gemm(h, h->dlog_lp, 0, h->ldV, h->Wo_w, 1, h->ldH, h->dHs, H, nullptr, TB, H, V, 1.f, 1, st);
   // dW_o = dlogits^T . Hs ; db_o = colsum(dlogits)
-  gemm(h, h->logits, 0, 1, V, h->Hs, 0, 1, H, h->dGd.out_weight, H, nullptr, V, H, TB, 1.f, 0, st);
-  colsum(h->logits, TB, V, V, h->dGd.out_bias, st);
-  // BPTT: per step one fused per-caption kernel + one split-K GEMM (dgates_t | dWh_t) . [W_hh ; W]
+  gemm(h, h->dlog_lp, 1, h->ldV, h->Hs_lp, 1, h->ldH, h->dGd.out_weight, H, nullptr, V, H, TB, 1.f, 0, st);
+  colsum_at(h, h->dlog_lp, TB, V, h->ldV, h->dGd.out_bias, st);
+  // BPTT: per step one fused kernel over (caption, frame chunk) + one split-K GEMM (dgates_t | dWh_t chunks) . [W_hh ; W x4]
   DecCellBwdArgs a;
   a.B = B; a.F = F; a.H = H; a.A = A;
-  a.P = h->P; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
-  a.dUv = h->dUv; a.dwacc = h->dwacc; a.dc_carry = h->dc_carry;
-  const size_t sm = (size_t)(4 * H + F + 16) * 4;
+  a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
+  a.dUv = h->dUv; a.dwacc = h->dwacc; a.ld_dgx = ldWS; a.dUv_lp = h->dUv_lp; a.ld_dUv = h->ldA;
+  const int Asz = A <= 256 ? 256 : A;
+  const size_t sm = (size_t)(4 * H + F + 2 * Asz + 16) * 4;
   int S = 0;
   for (int t = T - 1; t >= 0; --t) {
-    a.t = t; a.S = S; a.slab = (t < T - 1) ? h->slab : nullptr; a.first = (t == T - 1);
+    a.t = t; a.S = S; a.slab = (t < T - 1) ? h->slab : nullptr; a.first = (t == T - 1); a.last = (t == 0);
     a.dHs = h->dHs + (size_t)t * B * H;
     a.acts = h->acts + (size_t)t * B * 4 * H;
     a.c = h->Cs + (size_t)t * B * H;
     a.c_prev = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
-    a.dGx = h->dGx + (size_t)t * B * WS;
+    a.dc_in = h->dc_carry + (size_t)((t + 1) & 1) * B * H; a.dc_out = h->dc_carry + (size_t)(t & 1) * B * H;
+    a.dGx = at_off(h, h->dGx, (size_t)t * B * ldWS);
     a.Wh = h->Wh + (size_t)t * B * A;
-    if (pb) hipLaunchKernelGGL(dec_cell_bwd_kernel<bf16_t>, dim3(B), dim3(512), sm, st, a);
-    else hipLaunchKernelGGL(dec_cell_bwd_kernel<float>, dim3(B), dim3(512), sm, st, a);
+    LAUNCH_AT(h, dec_cell_bwd_kernel, dim3(B, RN_FCH), dim3(256), sm, st, a);
     if (t > 0)
-      S = gemm_slabs(h, RN_TAG_DEC_BWD, h->dGx + (size_t)t * B * WS, 0, WS, h->Wcomb, pb, 1, H, B, H, WS, st);
+      S = gemm_slabs(h, RN_TAG_DEC_BWD, at_off(h, h->dGx, (size_t)t * B * ldWS), ldWS, h->Wcomb, 1, h->ldH, B, H, KW, st);
   }
-  // deferred weight gradients (batched over all T steps); dgates live in columns [0,4H) of dGx, dWh in [4H,4H+A)
-  gemm(h, h->dGx, 0, 0, WS, h->dP.rnn_weight_ih_l0, 0, 1, E + D, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
+  // deferred weight gradients (batched over all T steps); dgates live in columns [0,4H) of dGx, dWh chunks behind them
+  gemm(h, h->dGx, 0, ldWS, h->We_w, 1, h->ldE, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
   hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(TB), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
                      h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train));
-  gemm(h, h->dGx, 0, 1, WS, h->emb, 0, 1, E, h->dGd.rnn_weight_ih_l0, E + D, nullptr, 4 * H, E, TB, 1.f, 0, st);
+  gemm(h, h->dGx, 1, ldWS, h->emb_lp, 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, 4 * H, E, TB, 1.f, 0, st);
   // ctx_t = (1/F) sum_f a_t[f] enc[b,f] for every step (only needed here), then dW_ih[:, E:] = dgates^T . ctx
-  if (h->Tm <= 32)
-    hipLaunchKernelGGL(ctx_all_kernel, dim3(B, cdiv(D, 256)), dim3(256), (size_t)32 * F * 4, st, h->att, enc, h->ctxall, T, B, F, D);
-  else
-    hipLaunchKernelGGL(ctx_all_slow_kernel, dim3(B, cdiv(D, 256)), dim3(256), 0, st, h->att, enc, h->ctxall, T, B, F, D);
-  gemm(h, h->dGx, 0, 1, WS, h->ctxall, 0, 1, D, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, 4 * H, D, TB, 1.f, 0, st);
+  {
+    dim3 grid(B, cdiv(h->ldD, 256));
+    if (h->Tm <= 32) {
+      if (h->lp) hipLaunchKernelGGL(ctx_all_kernel<bf16_t>, grid, dim3(256), (size_t)32 * F * 4, st, h->att, enc, (bf16_t*)h->ctx_lp, h->ldD, T, B, F, D);
+      else hipLaunchKernelGGL(ctx_all_kernel<float>, grid, dim3(256), (size_t)32 * F * 4, st, h->att, enc, (float*)h->ctx_lp, h->ldD, T, B, F, D);
+    } else {
+      if (h->lp) hipLaunchKernelGGL(ctx_all_slow_kernel<bf16_t>, grid, dim3(256), 0, st, h->att, enc, (bf16_t*)h->ctx_lp, h->ldD, T, B, F, D);
+      else hipLaunchKernelGGL(ctx_all_slow_kernel<float>, grid, dim3(256), 0, st, h->att, enc, (float*)h->ctx_lp, h->ldD, T, B, F, D);
+    }
+  }
+  gemm(h, h->dGx, 1, ldWS, h->ctx_lp, 1, h->ldD, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, 4 * H, D, TB, 1.f, 0, st);
+  // dWh_t = sum of its RN_FCH frame-chunk partials (operand of dW_attn and source of d attn_b)
+  {
+    const size_t n = (size_t)TB * h->ldA;
+    if (h->lp) hipLaunchKernelGGL(sum_chunks_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->dWhs, h->ldA, (const bf16_t*)h->dGx + 4 * H, ldWS, TB, A, RN_FCH);
+    else hipLaunchKernelGGL(sum_chunks_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->dWhs, h->ldA, (const float*)h->dGx + 4 * H, ldWS, TB, A, RN_FCH);
+  }
   // dW_hh = sum_{t>=1} dgates_t^T h_{t-1} ; dW_attn = sum_{t>=1} dWh_t^T h_{t-1}   (h_{-1} = 0)
   if (T > 1) {
-    gemm(h, h->dGx + (size_t)B * WS, 0, 1, WS, h->Hs, 0, 1, H, h->dGd.rnn_weight_hh_l0, H, nullptr, 4 * H, H, (T - 1) * B, 1.f, 0, st);
-    gemm(h, h->dGx + (size_t)B * WS + 4 * H, 0, 1, WS, h->Hs, 0, 1, H, h->dGd.attn_W_weight, H, nullptr, A, H, (T - 1) * B, 1.f, 0, st);
+    gemm(h, at_off(h, h->dGx, (size_t)B * ldWS), 1, ldWS, h->Hs_lp, 1, h->ldH, h->dGd.rnn_weight_hh_l0, H, nullptr, 4 * H, H, (T - 1) * B, 1.f, 0, st);
+    gemm(h, at_off(h, h->dWhs, (size_t)B * h->ldA), 1, h->ldA, h->Hs_lp, 1, h->ldH, h->dGd.attn_W_weight, H, nullptr, A, H, (T - 1) * B, 1.f, 0, st);
   } else {
     hipMemsetAsync(h->dGd.rnn_weight_hh_l0, 0, (size_t)4 * H * H * 4, st);
     hipMemsetAsync(h->dGd.attn_W_weight, 0, (size_t)A * H * 4, st);
   }
-  colsum(h->dGx, TB, 4 * H, WS, h->dGd.rnn_bias_ih_l0, st);
+  colsum_at(h, h->dGx, TB, 4 * H, ldWS, h->dGd.rnn_bias_ih_l0, st);
   copyf(h->dGd.rnn_bias_ih_l0, h->dGd.rnn_bias_hh_l0, 4 * H, st);
-  gemm(h, h->dUv, 0, 1, A, enc, 0, 1, D, h->dGd.attn_U_weight, D, nullptr, A, D, B * F, 1.f, 0, st);
-  colsum(h->dGx + 4 * H, TB, A, WS, h->dGd.attn_b, st);
-  colsum(h->dwacc, B, A, A, h->dGd.attn_w_weight, st);
+  gemm(h, h->dUv_lp, 1, h->ldA, h->enc_lp, 1, h->ldD, h->dGd.attn_U_weight, D, nullptr, A, D, B * F, 1.f, 0, st);
+  colsum_at(h, h->dWhs, TB, A, h->ldA, h->dGd.attn_b, st);
+  colsum_t<float>(h->dwacc, RN_FCH * B, A, A, h->dGd.attn_w_weight, st);
   return RECNET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- global reconstructor
 static void lstm_pw(recnet_handle* h, int Hd, int S, int slab_ld, const float* X, int x_ld, const float* b1, const float* b2,
-                    const float* c_prev, float* h_out, int h_ld, float* h_out2, int h2_ld, float* c_out, float* acts,
-                    hipStream_t st) {
+                    const float* c_prev, float* h_out, void* h_lp, int hlp_ld, void* h_lp2, int hlp2_ld, float* c_out,
+                    float* acts, hipStream_t st) {
   LstmPwArgs p;
   p.B = h->B; p.Hd = Hd; p.S = S; p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld;
-  p.X = X; p.x_ld = x_ld; p.b1 = b1; p.b2 = b2; p.c_prev = c_prev; p.h_out = h_out; p.h_ld = h_ld;
-  p.h_out2 = h_out2; p.h2_ld = h2_ld; p.c_out = c_out; p.acts = acts;
-  hipLaunchKernelGGL(lstm_pw_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
+  p.X = X; p.x_ld = x_ld; p.b1 = b1; p.b2 = b2; p.c_prev = c_prev; p.h_out = h_out; p.h_ld = Hd;
+  p.h_lp = h_lp; p.hlp_ld = hlp_ld; p.hlp_pad_from = Hd; p.h_lp2 = h_lp2; p.hlp2_ld = hlp2_ld; p.c_out = c_out; p.acts = acts;
+  LAUNCH_AT(h, lstm_pw_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
+}
+static void mean_over_t(recnet_handle* h, const float* X, int T, int Cn, float scale, float* out, void* out_lp, int ld_lp, hipStream_t st) {
+  const size_t n = (size_t)h->B * (out_lp ? ld_lp : Cn);
+  if (h->lp) hipLaunchKernelGGL(mean_over_t_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, X, T, h->B, Cn, scale, out, (bf16_t*)out_lp, ld_lp);
+  else hipLaunchKernelGGL(mean_over_t_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, X, T, h->B, Cn, scale, out, (float*)out_lp, ld_lp);
 }
 
-static int fwd_rec_global(recnet_handle* h, const float* enc, const float* Hs, int T, int train, hipStream_t st) {
+static int fwd_rec_global(recnet_handle* h, const float* enc, int T, int train, hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R;
   param_norms(h, 1, h->scal + 4, st);
   hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * R, 256)), dim3(256), 0, st, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, 4 * R);
   // mean-pooled decoder states, rescaled by caption_max_len / T (global_reconstructor.py:33-37): (cml / T^2) sum_t h_t
-  const size_t nBH = (size_t)B * H;
-  hipLaunchKernelGGL(mean_over_t_kernel, dim3(ew_blocks(nBH)), dim3(256), 0, st, Hs, T, nBH, (float)h->cml / ((float)T * (float)T), h->mp);
-  hipLaunchKernelGGL(bcast_drop_kernel, dim3(ew_blocks((size_t)T * nBH)), dim3(256), 0, st, h->mp, h->mpd, T, B, H,
-                     mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train));
+  mean_over_t(h, h->Hs, T, H, (float)h->cml / ((float)T * (float)T), h->mp, nullptr, 0, st);
+  {
+    const size_t n = (size_t)T * B * h->ldH;
+    const DropDesc dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
+    if (h->lp) hipLaunchKernelGGL(bcast_drop_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, h->mp, (bf16_t*)h->mpd_lp, h->ldH, T, B, H, dd);
+    else hipLaunchKernelGGL(bcast_drop_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, h->mp, (float*)h->mpd_lp, h->ldH, T, B, H, dd);
+  }
   // Xg = [h_t ; drop_t(mp)] . W_ih^T + b_ih + b_hh, batched over T (only h_r . W_hh^T is recurrent)
-  gemm(h, Hs, 0, 0, H, h->rP.rnn_weight_ih_l0, 0, 0, 2 * H, h->Xg, 4 * R, h->bsum_r, T * B, 4 * R, H, 1.f, 0, st);
-  gemm(h, h->mpd, 0, 0, H, h->rP.rnn_weight_ih_l0 + H, 0, 0, 2 * H, h->Xg, 4 * R, nullptr, T * B, 4 * R, H, 1.f, 1, st);
+  gemm(h, h->Hs_lp, 0, h->ldH, h->Wih_a, 0, h->ldH, h->Xg, 4 * R, h->bsum_r, T * B, 4 * R, H, 1.f, 0, st);
+  gemm(h, h->mpd_lp, 0, h->ldH, h->Wih_b, 0, h->ldH, h->Xg, 4 * R, nullptr, T * B, 4 * R, H, 1.f, 1, st);
   for (int t = 0; t < T; ++t) {
     int S = 0;
-    if (t > 0) S = gemm_slabs(h, RN_TAG_REC_FWD, h->Hr + (size_t)(t - 1) * B * R, 0, R, h->rP.rnn_weight_hh_l0, 0, 0, R, B, 4 * R, R, st);
+    if (t > 0) S = gemm_slabs(h, RN_TAG_REC_FWD, at_off(h, h->Hr_lp, (size_t)(t - 1) * B * h->ldR), h->ldR, h->Whh_w, 0, h->ldR, B, 4 * R, R, st);
     lstm_pw(h, R, S, 4 * R, h->Xg + (size_t)t * B * 4 * R, 4 * R, nullptr, nullptr,
-            t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->Hr + (size_t)t * B * R, R, nullptr, 0,
-            h->Cr + (size_t)t * B * R, h->acts_r + (size_t)t * B * 4 * R, st);
+            t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->Hr + (size_t)t * B * R,
+            at_off(h, h->Hr_lp, (size_t)t * B * h->ldR), h->ldR, nullptr, 0, h->Cr + (size_t)t * B * R,
+            h->acts_r + (size_t)t * B * 4 * R, st);
   }
   // mean_t out_t = (mean_t hr_t) . W_o^T + b_o  (train.py:96-98; `out` is linear so the mean commutes)
-  const size_t nBR = (size_t)B * R;
-  hipLaunchKernelGGL(mean_over_t_kernel, dim3(ew_blocks(nBR)), dim3(256), 0, st, h->Hr, T, nBR, 1.0f / (float)T, h->hrmean);
-  gemm(h, h->hrmean, 0, 0, R, h->rP.out_weight, 0, 0, R, h->outm, R, h->rP.out_bias, B, R, R, 1.f, 0, st);
+  mean_over_t(h, h->Hr, T, R, 1.0f / (float)T, h->hrmean, h->hrmean_lp, h->ldR, st);
+  gemm(h, h->hrmean_lp, 0, h->ldR, h->Wor_w, 0, h->ldR, h->outm, R, h->rP.out_bias, B, R, R, 1.f, 0, st);
   hipLaunchKernelGGL(mean_over_f_kernel, dim3(ew_blocks((size_t)B * D)), dim3(256), 0, st, enc, B, F, D, h->encmean);
   const double cnt = (double)h->c.global_batch_size * R;
   const int nb = 256;
@@ -536,73 +629,74 @@ static int fwd_rec_global(recnet_handle* h, const float* enc, const float* Hs, i
 
 static void lstm_bwd(recnet_handle* h, int Hd, int S, int slab_ld, int slab_col0, const float* dh_direct, int dhd_ld,
                      float dh_scale, const float* acts, const float* c, const float* c_prev, float* dc_carry, int first,
-                     float* dG, hipStream_t st) {
+                     void* dG, int ld_dg, hipStream_t st) {
   LstmBwdArgs p;
   p.B = h->B; p.Hd = Hd; p.S = S; p.dh_direct = dh_direct; p.dhd_ld = dhd_ld; p.dh_scale = dh_scale;
   p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld; p.slab_col0 = slab_col0;
-  p.extra = nullptr; p.acts = acts; p.c = c; p.c_prev = c_prev; p.dc_carry = dc_carry; p.first = first; p.dG = dG;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
+  p.acts = acts; p.c = c; p.c_prev = c_prev; p.dc_carry = dc_carry; p.first = first; p.dG = dG; p.ld_dg = ld_dg;
+  LAUNCH_AT(h, lstm_bwd_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
 }
 
-static int bwd_rec_global(recnet_handle* h, const float* Hs, float gscale, float* dhid_out, hipStream_t st) {
-  const int B = h->B, H = h->H, R = h->R, T = h->T_last, TB = T * B;
+static int bwd_rec_global(recnet_handle* h, float gscale, float* dhid_out, hipStream_t st) {
+  const int B = h->B, H = h->H, R = h->R, T = h->T_last, TB = T * B, ld4R = h->ld4R;
   const int train = h->train_last;
-  if (gscale != 1.0f) hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks((size_t)B * R)), dim3(256), 0, st, h->outm, (size_t)B * R, gscale);
-  // out layer: dW_o = dout^T . hrmean ; db_o ; dhrmean = dout . W_o
-  gemm(h, h->outm, 0, 1, R, h->hrmean, 0, 1, R, h->rG.out_weight, R, nullptr, R, R, B, 1.f, 0, st);
-  colsum(h->outm, B, R, R, h->rG.out_bias, st);
-  gemm(h, h->outm, 0, 0, R, h->rP.out_weight, 0, 1, R, h->dhrmean, R, nullptr, B, R, R, 1.f, 0, st);
+  // dout (operand copy) = gscale * d loss / d out_mean
+  pack_block(h, h->dout_lp, h->ldR, h->outm, R, B, R, gscale, st);
+  gemm(h, h->dout_lp, 1, h->ldR, h->hrmean_lp, 1, h->ldR, h->rG.out_weight, R, nullptr, R, R, B, 1.f, 0, st);
+  colsum_at(h, h->dout_lp, B, R, h->ldR, h->rG.out_bias, st);
+  gemm(h, h->dout_lp, 0, h->ldR, h->Wor_w, 1, h->ldR, h->dhrmean, R, nullptr, B, R, R, 1.f, 0, st);
   int S = 0;
   for (int t = T - 1; t >= 0; --t) {
     lstm_bwd(h, R, S, R, 0, h->dhrmean, R, 1.0f / (float)T, h->acts_r + (size_t)t * B * 4 * R, h->Cr + (size_t)t * B * R,
-             t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->dcr_carry, t == T - 1, h->dGr + (size_t)t * B * 4 * R, st);
-    if (t > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, h->dGr + (size_t)t * B * 4 * R, 0, 4 * R, h->rP.rnn_weight_hh_l0, 0, 1, R, B, R, 4 * R, st);
+             t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->dcr_carry, t == T - 1, at_off(h, h->dGr, (size_t)t * B * ld4R), ld4R, st);
+    if (t > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)t * B * ld4R), ld4R, h->Whh_w, 1, h->ldR, B, R, 4 * R, st);
   }
   // input-side gradients, batched
-  gemm(h, h->dGr, 0, 0, 4 * R, h->rP.rnn_weight_ih_l0, 0, 1, 2 * H, dhid_out, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
-  gemm(h, h->dGr, 0, 0, 4 * R, h->rP.rnn_weight_ih_l0 + H, 0, 1, 2 * H, h->dmpd, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
+  gemm(h, h->dGr, 0, ld4R, h->Wih_a, 1, h->ldH, dhid_out, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
+  gemm(h, h->dGr, 0, ld4R, h->Wih_b, 1, h->ldH, h->dmpd, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
   const size_t nBH = (size_t)B * H;
   hipLaunchKernelGGL(bcast_drop_bwd_kernel, dim3(ew_blocks(nBH)), dim3(256), 0, st, h->dmpd, h->dmp, T, B, H,
                      mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train));
   hipLaunchKernelGGL(add_bcast_kernel, dim3(ew_blocks((size_t)T * nBH)), dim3(256), 0, st, dhid_out, h->dmp, T, nBH,
                      (float)h->cml / ((float)T * (float)T), 1);
-  gemm(h, h->dGr, 0, 1, 4 * R, Hs, 0, 1, H, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
-  gemm(h, h->dGr, 0, 1, 4 * R, h->mpd, 0, 1, H, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
+  gemm(h, h->dGr, 1, ld4R, h->Hs_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
+  gemm(h, h->dGr, 1, ld4R, h->mpd_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
   if (T > 1)
-    gemm(h, h->dGr + (size_t)B * 4 * R, 0, 1, 4 * R, h->Hr, 0, 1, R, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (T - 1) * B, 1.f, 0, st);
+    gemm(h, at_off(h, h->dGr, (size_t)B * ld4R), 1, ld4R, h->Hr_lp, 1, h->ldR, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (T - 1) * B, 1.f, 0, st);
   else
     hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)4 * R * R * 4, st);
-  colsum(h->dGr, TB, 4 * R, 4 * R, h->rG.rnn_bias_ih_l0, st);
+  colsum_at(h, h->dGr, TB, 4 * R, ld4R, h->rG.rnn_bias_ih_l0, st);
   copyf(h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, 4 * R, st);
   return RECNET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- local reconstructor
-static int fwd_rec_local(recnet_handle* h, const float* enc, const float* Hs, int T, int train, hipStream_t st) {
-  const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R, RA = h->RA;
-  const int pb = h->prec == RN_PREC_BF16;
+static int fwd_rec_local(recnet_handle* h, const float* enc, int T, int train, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R, RA = h->RA, ldHR = h->ldHR;
+  const size_t esz = h->lp ? 2 : 4;
   param_norms(h, 1, h->scal + 4, st);
   // Ud = hiddens . U_r^T   (local_reconstructor.py:42, hoisted)
-  gemm(h, Hs, 0, 0, H, h->rP.attn_U_weight, 0, 0, H, h->Ud, RA, nullptr, T * B, RA, H, 1.f, 0, st);
-  hipMemsetAsync(h->Xcat_r, 0, (size_t)B * (H + R) * 4, st);   // hr_{-1} = 0
+  gemm(h, h->Hs_lp, 0, h->ldH, h->Ur_w, 0, h->ldH, h->Ud, RA, nullptr, T * B, RA, H, 1.f, 0, st);
+  hipMemsetAsync(h->Xcat_r, 0, (size_t)F * B * ldHR * esz, st);   // hr_{-1} = 0 and the zero padding of every row
   LocAttnArgs a;
-  a.B = B; a.T = T; a.H = H; a.A = RA; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight; a.Hs = Hs;
-  a.xcat_ld = H + R; a.dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
+  a.B = B; a.T = T; a.H = H; a.A = RA; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight; a.Hs = h->Hs;
+  a.xcat_ld = ldHR; a.dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
   const size_t sm = (size_t)(RA + T + 16) * 4;
   for (int s = 0; s < F; ++s) {
     int Sa = 0;
-    if (s > 0) Sa = gemm_slabs(h, RN_TAG_REC_ATT, h->Hr + (size_t)(s - 1) * B * R, 0, R, h->rP.attn_W_weight, 0, 0, R, B, RA, R, st);
+    if (s > 0) Sa = gemm_slabs(h, RN_TAG_REC_ATT, at_off(h, h->Hr_lp, (size_t)(s - 1) * B * h->ldR), h->ldR, h->Wr_w, 0, h->ldR, B, RA, R, st);
     a.s = s; a.S = Sa; a.slab = s > 0 ? h->slab : nullptr;
     a.Whr_out = h->Whr + (size_t)s * B * RA; a.beta_out = h->beta + (size_t)s * B * T;
-    a.xcat = h->Xcat_r + (size_t)s * B * (H + R);
-    hipLaunchKernelGGL(loc_attn_fwd_kernel, dim3(B), dim3(256), sm, st, a);
-    const int Sb = gemm_slabs(h, RN_TAG_REC_FWD, h->Xcat_r + (size_t)s * B * (H + R), 0, H + R, h->Wihh, pb, 0, H + R, B, 4 * R, H + R, st);
+    a.xcat = at_off(h, h->Xcat_r, (size_t)s * B * ldHR);
+    LAUNCH_AT(h, loc_attn_fwd_kernel, dim3(B), dim3(256), sm, st, a);
+    const int Sb = gemm_slabs(h, RN_TAG_REC_FWD, at_off(h, h->Xcat_r, (size_t)s * B * ldHR), ldHR, h->Wihh_w, 0, ldHR, B, 4 * R, H + R, st);
     lstm_pw(h, R, Sb, 4 * R, nullptr, 0, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0,
-            s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->Hr + (size_t)s * B * R, R,
-            s + 1 < F ? h->Xcat_r + (size_t)(s + 1) * B * (H + R) + H : nullptr, H + R, h->Cr + (size_t)s * B * R,
+            s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->Hr + (size_t)s * B * R,
+            at_off(h, h->Hr_lp, (size_t)s * B * h->ldR), h->ldR,
+            s + 1 < F ? at_off(h, h->Xcat_r, (size_t)(s + 1) * B * ldHR + H) : nullptr, ldHR, h->Cr + (size_t)s * B * R,
             h->acts_r + (size_t)s * B * 4 * R, st);
   }
-  gemm(h, h->Hr, 0, 0, R, h->rP.out_weight, 0, 0, R, h->outl, R, h->rP.out_bias, F * B, R, R, 1.f, 0, st);
+  gemm(h, h->Hr_lp, 0, h->ldR, h->Wor_w, 0, h->ldR, h->outl, R, h->rP.out_bias, F * B, R, R, 1.f, 0, st);
   const double cnt = (double)h->c.global_batch_size * F * D;
   const int nb = 512;
   hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, h->outl, enc, F, B, R, (size_t)F * D, (size_t)D,
@@ -611,61 +705,66 @@ static int fwd_rec_local(recnet_handle* h, const float* enc, const float* Hs, in
   return RECNET_OK;
 }
 
-static int bwd_rec_local(recnet_handle* h, const float* Hs, float gscale, float* dhid_out, hipStream_t st) {
+static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStream_t st) {
   const int B = h->B, F = h->F, H = h->H, R = h->R, RA = h->RA, T = h->T_last, TB = T * B, FB = F * B;
-  const int pb = h->prec == RN_PREC_BF16, train = h->train_last;
-  if (gscale != 1.0f) hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks((size_t)FB * R)), dim3(256), 0, st, h->outl, (size_t)FB * R, gscale);
-  gemm(h, h->outl, 0, 1, R, h->Hr, 0, 1, R, h->rG.out_weight, R, nullptr, R, R, FB, 1.f, 0, st);
-  colsum(h->outl, FB, R, R, h->rG.out_bias, st);
-  gemm(h, h->outl, 0, 0, R, h->rP.out_weight, 0, 1, R, h->dHr, R, nullptr, FB, R, R, 1.f, 0, st);
+  const int train = h->train_last, ld4R = h->ld4R, ldHR = h->ldHR;
+  pack_block(h, h->dout_lp, h->ldR, h->outl, R, FB, R, gscale, st);
+  gemm(h, h->dout_lp, 1, h->ldR, h->Hr_lp, 1, h->ldR, h->rG.out_weight, R, nullptr, R, R, FB, 1.f, 0, st);
+  colsum_at(h, h->dout_lp, FB, R, h->ldR, h->rG.out_bias, st);
+  gemm(h, h->dout_lp, 0, h->ldR, h->Wor_w, 1, h->ldR, h->dHr, R, nullptr, FB, R, R, 1.f, 0, st);
   LocBwdArgs a;
   a.B = B; a.T = T; a.H = H; a.R = R; a.A = RA;
-  a.Hs = Hs; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight; a.Wr = h->rP.attn_W_weight;
+  a.Hs = h->Hs; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight; a.Wr = h->rP.attn_W_weight;
   a.dHs = dhid_out; a.dUd = h->dUd; a.dwacc = h->dwacc_r; a.dc_carry = h->dcr_carry; a.slab = h->slab;
+  a.ld_dwhr = h->ldRA; a.dUd_lp = h->dUd_lp; a.ld_dUd = h->ldRA; a.ld_dg = ld4R;
   a.dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
   const size_t sm = (size_t)(H + R + T + RA + 16) * 4;
   int S = 0;
   for (int s = F; s >= 0; --s) {
     a.s = s; a.S = S; a.do_attn = s < F; a.do_lstm = s > 0;
-    a.first_attn = (s == F - 1); a.first_lstm = (s == F); a.prop_hr = s > 0;
+    a.first_attn = (s == F - 1); a.first_lstm = (s == F); a.prop_hr = s > 0; a.last = (s == 0);
     a.Whr = s < F ? h->Whr + (size_t)s * B * RA : nullptr;
     a.beta = s < F ? h->beta + (size_t)s * B * T : nullptr;
-    a.dWhr = s < F ? h->dWhr + (size_t)s * B * RA : nullptr;
+    a.dWhr = s < F ? at_off(h, h->dWhr, (size_t)s * B * h->ldRA) : nullptr;
     if (s > 0) {
       a.dHr = h->dHr + (size_t)(s - 1) * B * R;
       a.acts = h->acts_r + (size_t)(s - 1) * B * 4 * R;
       a.c = h->Cr + (size_t)(s - 1) * B * R;
       a.c_prev = s > 1 ? h->Cr + (size_t)(s - 2) * B * R : nullptr;
-      a.dG = h->dGr + (size_t)(s - 1) * B * 4 * R;
+      a.dG = at_off(h, h->dGr, (size_t)(s - 1) * B * ld4R);
     }
-    hipLaunchKernelGGL(loc_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
-    if (s > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, h->dGr + (size_t)(s - 1) * B * 4 * R, 0, 4 * R, h->Wihh, pb, 1, H + R, B, H + R, 4 * R, st);
+    LAUNCH_AT(h, loc_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
+    if (s > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)(s - 1) * B * ld4R), ld4R, h->Wihh_w, 1, ldHR, B, H + R, 4 * R, st);
   }
   // deferred, batched
-  gemm(h, h->dUd, 0, 1, RA, Hs, 0, 1, H, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
-  gemm(h, h->dUd, 0, 0, RA, h->rP.attn_U_weight, 0, 1, H, dhid_out, H, nullptr, TB, H, RA, 1.f, 1, st);
-  if (F > 1)
-    gemm(h, h->dWhr + (size_t)B * RA, 0, 1, RA, h->Hr, 0, 1, R, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
-  else
+  gemm(h, h->dUd_lp, 1, h->ldRA, h->Hs_lp, 1, h->ldH, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
+  gemm(h, h->dUd_lp, 0, h->ldRA, h->Ur_w, 1, h->ldH, dhid_out, H, nullptr, TB, H, RA, 1.f, 1, st);
+  if (F > 1) {
+    gemm(h, at_off(h, h->dWhr, (size_t)B * h->ldRA), 1, h->ldRA, h->Hr_lp, 1, h->ldR, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
+    gemm(h, at_off(h, h->dGr, (size_t)B * ld4R), 1, ld4R, h->Hr_lp, 1, h->ldR, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (F - 1) * B, 1.f, 0, st);
+  } else {
     hipMemsetAsync(h->rG.attn_W_weight, 0, (size_t)RA * R * 4, st);
-  colsum(h->dWhr, FB, RA, RA, h->rG.attn_b, st);
-  colsum(h->dwacc_r, B, RA, RA, h->rG.attn_w_weight, st);
-  gemm(h, h->dGr, 0, 1, 4 * R, h->Xcat_r, 0, 1, H + R, h->rG.rnn_weight_ih_l0, H, nullptr, 4 * R, H, FB, 1.f, 0, st);
-  gemm(h, h->dGr, 0, 1, 4 * R, h->Xcat_r + H, 0, 1, H + R, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, FB, 1.f, 0, st);
-  colsum(h->dGr, FB, 4 * R, 4 * R, h->rG.rnn_bias_ih_l0, st);
+    hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)4 * R * R * 4, st);
+  }
+  colsum_at(h, h->dWhr, FB, RA, h->ldRA, h->rG.attn_b, st);
+  colsum_t<float>(h->dwacc_r, B, RA, RA, h->rG.attn_w_weight, st);
+  gemm(h, h->dGr, 1, ld4R, h->Xcat_r, 1, ldHR, h->rG.rnn_weight_ih_l0, H, nullptr, 4 * R, H, FB, 1.f, 0, st);
+  colsum_at(h, h->dGr, FB, 4 * R, ld4R, h->rG.rnn_bias_ih_l0, st);
   copyf(h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, 4 * R, st);
   return RECNET_OK;
 }
 
-static int fwd_rec(recnet_handle* h, const float* enc, const float* hid, int T, int train, hipStream_t st) {
-  const float* Hs = hid ? hid : h->Hs;
-  int r = h->kind == RECNET_REC_GLOBAL ? fwd_rec_global(h, enc, Hs, T, train, st) : fwd_rec_local(h, enc, Hs, T, train, st);
+static int fwd_rec(recnet_handle* h, const float* enc, int T, int train, hipStream_t st) {
+  int r = h->kind == RECNET_REC_GLOBAL ? fwd_rec_global(h, enc, T, train, st) : fwd_rec_local(h, enc, T, train, st);
   if (r) return r;
   // rec_loss = mse + lambda_reg * reg ; total = dec_loss + lambda_recon * rec_loss
   hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 3, h->scal + 4, h->c.reconstructor_lambda_reg, h->scal + 5);
   hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 5, h->c.lambda_recon, h->scal + 6);
   h->T_last = T; h->train_last = train; h->fwd_rec_done = 1;
   return RECNET_OK;
+}
+static int bwd_rec(recnet_handle* h, float gscale, float* dhid_out, hipStream_t st) {
+  return h->kind == RECNET_REC_GLOBAL ? bwd_rec_global(h, gscale, dhid_out, st) : bwd_rec_local(h, gscale, dhid_out, st);
 }
 
 static int optimizer_step(recnet_handle* h, int flags, hipStream_t st) {
@@ -716,21 +815,23 @@ int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_
   if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
   if (!tokens || !enc || !logits || !h_out || !c_out) return fail(RECNET_EINVAL, "null argument");
   hipStream_t st = (hipStream_t)stream;
-  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V;
-  const int pb = h->prec == RN_PREC_BF16;
+  const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A, V = h->V;
   hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
   dec_invariants(h, enc, st);   // the reference recomputes attn_U(encoder_outputs) on every call too (decoder.py:54)
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(B), dim3(128), 0, st, h->dP.embedding_weight, (const int64_t*)nullptr, tokens,
-                     h->emb, B, E, V, h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), t);
-  gemm(h, h->emb, 0, 0, E, h->dP.rnn_weight_ih_l0, 0, 0, E + D, h->Xe, 4 * H, h->bsum_d, B, 4 * H, E, 1.f, 0, st);
+  embed_fwd(h, nullptr, tokens, B, train, t, st);
+  gemm(h, h->emb_lp, 0, h->ldE, h->We_w, 0, h->ldE, h->Xe, 4 * H, h->bsum_d, B, 4 * H, E, 1.f, 0, st);
   int S = 0;
-  if (h_in) S = gemm_slabs(h, RN_TAG_DEC_FWD, h_in, 0, H, h->Wcomb, pb, 0, H, B, 4 * H + A, H, st);
+  if (h_in) {   // operand copy of the incoming hidden state, then h . [W_hh ; attn_W]^T
+    pack_block(h, h->Hs_lp, h->ldH, h_in, H, B, H, 1.f, st);
+    S = gemm_slabs(h, RN_TAG_DEC_FWD, h->Hs_lp, h->ldH, h->Wcomb, 0, h->ldH, B, 4 * H + A, H, st);
+  }
   DecCellArgs a;
   a.t = t; a.B = B; a.F = F; a.H = H; a.A = A; a.S = S; a.slab = h_in ? h->slab : nullptr;
-  a.Xe = h->Xe; a.P = h->P; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
+  a.Xe = h->Xe; a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
   a.c_prev = c_in; a.h_out = h_out; a.c_out = c_out; a.acts = nullptr; a.Wh_out = nullptr; a.att_out = nullptr;
+  a.h_lp = at_off(h, h->Hs_lp, (size_t)B * h->ldH); a.ld_hlp = h->ldH;
   launch_dec_cell(h, a, st);
-  gemm(h, h_out, 0, 0, H, h->dP.out_weight, 0, 0, H, logits, V, h->dP.out_bias, B, V, H, 1.f, 0, st);
+  gemm(h, at_off(h, h->Hs_lp, (size_t)B * h->ldH), 0, h->ldH, h->Wo_w, 0, h->ldH, logits, V, h->dP.out_bias, B, V, H, 1.f, 0, st);
   if (train && h->c.decoder_out_dropout > 0.f)
     hipLaunchKernelGGL(logits_drop_kernel, dim3(ew_blocks((size_t)B * V)), dim3(256), 0, st, logits, B, V,
                        mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train), t);
@@ -765,8 +866,11 @@ int recnet_forward_reconstructor(recnet_handle* h, const float* enc, const float
   if (!hiddens && (!h->fwd_dec_done || h->T_last != T)) return fail(RECNET_ESTATE, "no decoder hidden states for this T");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
-  if (hiddens) copyf(hiddens, h->Hs, (size_t)T * h->B * h->H, st);
-  int r = fwd_rec(h, enc, nullptr, T, train, st); if (r) return r;
+  if (hiddens) {   // hidden states handed in by the caller: refresh the fp32 image and its operand copy
+    copyf(hiddens, h->Hs, (size_t)T * h->B * h->H, st);
+    pack_block(h, h->Hs_lp, h->ldH, hiddens, h->H, T * h->B, h->H, 1.f, st);
+  }
+  int r = fwd_rec(h, enc, T, train, st); if (r) return r;
   if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
   LAUNCH_OK();
   return RECNET_OK;
@@ -778,7 +882,7 @@ int recnet_backward_reconstructor(recnet_handle* h, const float* enc, float grad
   if (!h->rG.out_weight) return fail(RECNET_ESTATE, "reconstructor gradients not bound");
   hipStream_t st = (hipStream_t)stream;
   float* dh = dhiddens_out ? dhiddens_out : h->dHsrec;
-  int r = h->kind == RECNET_REC_GLOBAL ? bwd_rec_global(h, h->Hs, grad_scale, dh, st) : bwd_rec_local(h, h->Hs, grad_scale, dh, st);
+  int r = bwd_rec(h, grad_scale, dh, st);
   if (r) return r;
   if (dhiddens_out) copyf(dhiddens_out, h->dHsrec, (size_t)h->T_last * h->B * h->H, st);
   h->rec_bwd_done = 1;
@@ -838,10 +942,8 @@ static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, i
   int r = fwd_decoder(h, enc, targets, T, stepw, 1, nullptr, st); if (r) return r;
   const float* dh = nullptr;
   if (h->kind != RECNET_REC_NONE) {
-    r = fwd_rec(h, enc, nullptr, T, 1, st); if (r) return r;
-    r = h->kind == RECNET_REC_GLOBAL ? bwd_rec_global(h, h->Hs, h->c.lambda_recon, h->dHsrec, st)
-                                     : bwd_rec_local(h, h->Hs, h->c.lambda_recon, h->dHsrec, st);
-    if (r) return r;
+    r = fwd_rec(h, enc, T, 1, st); if (r) return r;
+    r = bwd_rec(h, h->c.lambda_recon, h->dHsrec, st); if (r) return r;
     dh = h->dHsrec;
   }
   return bwd_decoder(h, enc, targets, dh, 1.0f, st);
@@ -933,12 +1035,25 @@ int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, c
   return RECNET_OK;
 }
 
+int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, int32_t b_col, int32_t ldb, float* C,
+                     int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
+                     int32_t splitk, float* splitk_ws, int32_t tag, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return fail(RECNET_EINVAL, "bad gemm argument");
+  if (splitk > 1 && !splitk_ws) return fail(RECNET_EINVAL, "split-K needs a workspace");
+  if (tag < 0 || tag > 5) return fail(RECNET_EINVAL, "bad tag");
+  rn_launch_gemm(RN_PREC_BF16, A, 1, a_col, lda, B, 1, b_col, ldb, C, ldc, bias, M, N, K, alpha, accumulate, splitk, splitk_ws, 1,
+                 (hipStream_t)stream, tag);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
 double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which) {
   if (!h) return 0;
   const double wb = h->prec == RN_PREC_BF16 ? 2.0 : 4.0;
-  if (which == 0) return (double)(4 * h->H + h->A) * h->H * wb + (double)h->B * h->H * 4 + (double)h->B * (4 * h->H + h->A) * 4;
-  if (h->kind == RECNET_REC_GLOBAL) return (double)4 * h->R * h->R * 4.0 + (double)h->B * h->R * 4 + (double)h->B * 4 * h->R * 4;
-  if (h->kind == RECNET_REC_LOCAL) return (double)4 * h->R * (h->H + h->R) * wb + (double)h->B * (h->H + h->R) * 4 + (double)h->B * 4 * h->R * 4;
+  // weights streamed once + activation block read + fp32 partial results written
+  if (which == 0) return (double)(4 * h->H + h->A) * h->H * wb + (double)h->B * h->H * wb + (double)h->B * (4 * h->H + h->A) * 4;
+  if (h->kind == RECNET_REC_GLOBAL) return (double)4 * h->R * h->R * wb + (double)h->B * h->R * wb + (double)h->B * 4 * h->R * 4;
+  if (h->kind == RECNET_REC_LOCAL) return (double)4 * h->R * (h->H + h->R) * wb + (double)h->B * (h->H + h->R) * wb + (double)h->B * 4 * h->R * 4;
   return 0;
 }
 

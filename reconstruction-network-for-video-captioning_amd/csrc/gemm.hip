@@ -1,6 +1,7 @@
 // Host-side dispatch of the MFMA GEMM template (gemm.hpp).
-#include "gemm.hpp"
+#include "gemm_lds.hpp"
 #include "launch.hpp"
+#include <stdlib.h>
 
 namespace {
 template <typename CT, typename TA, typename TB>
@@ -19,6 +20,28 @@ void launch_layout(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream
   else if (!a_col && b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true, 0>), grid, dim3(256), 0, st, a);
   else if (a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, false, 0>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, true, true, 0>), grid, dim3(256), 0, st, a);
+}
+template <bool ACOL, bool BCOL, int NS, int TAG>
+void launch_lds_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  static bool attr_done = false;
+  auto fn = gemm_lds_kernel<ACOL, BCOL, NS, TAG>;
+  if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, NS * GL_STAGE_BYTES); attr_done = true; }
+  hipLaunchKernelGGL(fn, grid, dim3(256), NS * GL_STAGE_BYTES, st, a);
+}
+template <int NS>
+void launch_lds(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream_t st, int tag) {
+  switch (tag) {
+    case RN_TAG_DEC_FWD: launch_lds_one<false, false, NS, RN_TAG_DEC_FWD>(a, grid, st); return;
+    case RN_TAG_DEC_BWD: launch_lds_one<false, true, NS, RN_TAG_DEC_BWD>(a, grid, st); return;
+    case RN_TAG_REC_FWD: launch_lds_one<false, false, NS, RN_TAG_REC_FWD>(a, grid, st); return;
+    case RN_TAG_REC_BWD: launch_lds_one<false, true, NS, RN_TAG_REC_BWD>(a, grid, st); return;
+    case RN_TAG_REC_ATT: launch_lds_one<false, false, NS, RN_TAG_REC_ATT>(a, grid, st); return;
+    default: break;
+  }
+  if (!a_col && !b_col) launch_lds_one<false, false, NS, 0>(a, grid, st);
+  else if (!a_col && b_col) launch_lds_one<false, true, NS, 0>(a, grid, st);
+  else if (a_col && !b_col) launch_lds_one<true, false, NS, 0>(a, grid, st);
+  else launch_lds_one<true, true, NS, 0>(a, grid, st);
 }
 inline int vec_ok(const void* p, int ld, int elem) {
   return (((uintptr_t)p) % 16 == 0) && (((size_t)ld * elem) % 16 == 0);
@@ -39,11 +62,11 @@ int rn_pick_splitk(int prec, int M, int N, int K, int max_split) {
 
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
-                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag, int c_bf16) {
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag, int c_bf16, void* c2, int ldc2) {
   if (M <= 0 || N <= 0) return;
   GemmArgs a;
-  a.c_bf16 = c_bf16;
-  if (c_bf16) splitk = 1;
+  a.c_bf16 = c_bf16; a.C2 = c2; a.ldc2 = ldc2;
+  if (c_bf16 || c2) splitk = 1;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.accumulate = accumulate;
@@ -61,7 +84,16 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
   if (prec == RN_PREC_BF16) {
     if (!a_bf16 && !b_bf16) launch_layout<bf16_t, float, float>(a, a_col, b_col, grid, st, tag);
     else if (!a_bf16 && b_bf16) launch_layout<bf16_t, float, bf16_t>(a, a_col, b_col, grid, st, tag);
-    else launch_layout<bf16_t, bf16_t, bf16_t>(a, a_col, b_col, grid, st, 0);   // bf16 activations (no tagged form)
+    else if (a.a_vec && a.b_vec) {
+      // both operands bf16 in memory: the DMA-staged ring kernel.  Chain launches (tag > 0) run ~1 block
+      // per CU and want the deepest ring; batched GEMMs trade ring depth for 2 resident blocks per CU.
+      static int ns_chain = getenv("RN_GEMM_NS_CHAIN") ? atoi(getenv("RN_GEMM_NS_CHAIN")) : 4;
+      static int ns_batch = getenv("RN_GEMM_NS_BATCH") ? atoi(getenv("RN_GEMM_NS_BATCH")) : 2;
+      const int ns = tag ? ns_chain : ns_batch;
+      if (ns >= 4) launch_lds<4>(a, a_col, b_col, grid, st, tag);
+      else if (ns == 3) launch_lds<3>(a, a_col, b_col, grid, st, tag);
+      else launch_lds<2>(a, a_col, b_col, grid, st, tag);
+    } else launch_layout<bf16_t, bf16_t, bf16_t>(a, a_col, b_col, grid, st, 0);   // unaligned bf16 operands
   } else {
     launch_layout<float, float, float>(a, a_col, b_col, grid, st, tag);
   }

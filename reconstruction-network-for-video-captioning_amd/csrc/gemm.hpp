@@ -23,6 +23,7 @@ struct GemmArgs {
   float* ws;                  // fp32 slabs [splitk][M][N] when splitk > 1
   int a_vec, b_vec;           // 16-byte vector loads are legal for this operand (alignment checked on host)
   int c_bf16;                 // direct epilogue stores bf16 into C (reinterpreted); requires splitk == 1
+  void* C2; int ldc2;         // optional second, bf16 copy of the fp32 result (direct epilogue of gemm_lds only)
 };
 
 template <typename CT> struct GemmCfg;

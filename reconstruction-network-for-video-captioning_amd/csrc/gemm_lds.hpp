@@ -1,0 +1,195 @@
+// bf16 MFMA GEMM with direct global->LDS staging (global_load_lds_dwordx4) and an NS-deep LDS ring.
+//
+//   C[M,N] (+)= alpha * sum_k A(m,k) B(n,k) (+ bias[n]),  A and B stored as bf16.
+//
+// Same contract as gemm.hpp (row / col operand layouts, split-K slabs, fp32 or bf16 output); this is
+// the production kernel of the bf16 path, gemm.hpp stays as the exact-fp32 path.  What differs:
+//   * operands are already bf16 in HBM (producers write bf16 operand copies; weights are packed once per
+//     optimiser step), so a tile is staged by 8 global_load_lds_dwordx4 per wave with no VGPR round trip;
+//   * NS-stage ring, prefetch distance NS-1, ONE raw s_barrier per 64-deep k-tile and a counted
+//     s_waitcnt vmcnt((NS-2)*8): loads of later tiles stay in flight across the barrier;
+//   * LDS images are lane-linear (the DMA writes base + lane*16), bank conflicts are removed by
+//     XOR-swizzling the per-lane SOURCE chunk and applying the same XOR on the fragment read:
+//       row operand  [128 m][64 k]  (128-byte rows):  chunk' = chunk ^ (m & 7)            -> ds_read_b128
+//       col operand  [64 k][128 m]  (256-byte rows):  chunk' = chunk ^ (((k&3)<<1)|(k&8)) -> ds_read_b64_tr_b16
+// Requirements (guaranteed by construction for every bf16 buffer of the library): 16-byte aligned bases,
+// leading dimensions that are multiples of 8 elements and >= the extent rounded up to 8, zero padding
+// between the logical extent and its multiple of 8.
+#pragma once
+#include "gemm.hpp"
+
+#define GL_STAGE_BYTES 32768   // A image 16 KiB + B image 16 KiB
+
+__device__ __forceinline__ int gl_col_swz(int k) { return ((k & 3) << 1) | (k & 8); }
+
+template <int N> __device__ __forceinline__ void gl_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One operand tile: 4 DMA instructions per wave, each 64 lanes x 16 B = 1 KiB of the image.
+template <bool COL>
+__device__ __forceinline__ void gl_stage(char* img, const bf16_t* base, int ld, int row0, int rext, int k0, int K,
+                                         int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const bf16_t* src;
+    if (!COL) {
+      const int r = piece * 8 + (lane >> 3), cp = lane & 7;
+      int gr = row0 + r; gr = gr < rext ? gr : rext - 1;
+      int gk = k0 + ((cp ^ (r & 7)) << 3); gk = gk < K ? gk : 0;         // beyond K: any valid address, zero-fixed later
+      src = base + (size_t)gr * ld + gk;
+    } else {
+      const int kk = piece * 4 + (lane >> 4), cp = lane & 15;
+      int gk = k0 + kk; gk = gk < K ? gk : K - 1;
+      const int r8 = (rext + 7) & ~7;
+      int gm = row0 + ((cp ^ gl_col_swz(kk)) << 3); gm = gm + 8 <= r8 ? gm : r8 - 8;
+      src = base + (size_t)gk * ld + gm;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(img + piece * 1024), 16, 0, 0);
+  }
+}
+// zero the chunks of the (last, partial) k-tile that lie beyond K
+template <bool COL>
+__device__ __forceinline__ void gl_zero_tail(char* img, int k0, int K, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    bool bad;
+    if (!COL) {
+      const int r = piece * 8 + (lane >> 3), cp = lane & 7;
+      bad = k0 + ((cp ^ (r & 7)) << 3) >= K;
+    } else {
+      bad = k0 + piece * 4 + (lane >> 4) >= K;
+    }
+    if (bad) *reinterpret_cast<f32x4*>(img + piece * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <bool COL>
+__device__ __forceinline__ bf16x8 gl_frag(const char* img, int row /*first of the 16 m-rows*/, int ks /*0 or 32*/, int lane) {
+  if (!COL) {
+    const int r = row + (lane & 15), c = (ks >> 3) + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(img + r * 128 + ((c ^ (r & 7)) << 4));
+  } else {
+    const int li = lane & 15, q = li >> 2, pp = li & 3, g = lane >> 4;
+    const int kk = ks + 8 * g + q;                      // kk + 4 has the same swizzle (bits 0,1,3 unchanged)
+    const int c = (row >> 3) + (pp >> 1);
+    const char* a = img + kk * 256 + ((c ^ gl_col_swz(kk)) << 4) + ((pp & 1) << 3);
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(a + 4 * 256));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <bool ACOL, bool BCOL, int NS, int TAG>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int m0 = blockIdx.y * GEMM_TILE, n0 = blockIdx.x * GEMM_TILE;
+  const int z = blockIdx.z;
+  const int kbeg = z * p.kchunk;
+  int kend = kbeg + p.kchunk;
+  if (kend > p.K) kend = p.K;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  constexpr int D = NS - 1;     // prefetch distance in k-tiles
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = (kend > kbeg) ? (kend - kbeg + 63) / 64 : 0;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < nkt) {
+      char* st = gl_smem + d * GL_STAGE_BYTES;
+      gl_stage<ACOL>(st, A, p.lda, m0, p.M, kbeg + d * 64, kend, wave, lane);
+      gl_stage<BCOL>(st + 16384, B, p.ldb, n0, p.N, kbeg + d * 64, kend, wave, lane);
+    }
+  for (int kt = 0; kt < nkt; ++kt) {
+    // this wave's DMA of tile kt has landed once at most `ahead` later tiles (8 DMAs each) are outstanding
+    const int issued = (kt + D < nkt) ? kt + D : nkt;
+    const int ahead = issued - (kt + 1);
+    if (NS >= 4 && ahead >= 2) gl_wait_vmcnt<16>();
+    else if (NS >= 3 && ahead >= 1) gl_wait_vmcnt<8>();
+    else gl_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();           // every wave's part of tile kt landed; everyone is done with tile kt-1
+    asm volatile("" ::: "memory");
+    if (kt + D < nkt) {
+      char* st = gl_smem + ((kt + D) % NS) * GL_STAGE_BYTES;
+      gl_stage<ACOL>(st, A, p.lda, m0, p.M, kbeg + (kt + D) * 64, kend, wave, lane);
+      gl_stage<BCOL>(st + 16384, B, p.ldb, n0, p.N, kbeg + (kt + D) * 64, kend, wave, lane);
+    }
+    char* cur = gl_smem + (kt % NS) * GL_STAGE_BYTES;
+    const int k0 = kbeg + kt * 64;
+    if (k0 + 64 > kend) {                    // partial last tile: zero what lies beyond K (block-uniform branch)
+      gl_zero_tail<ACOL>(cur, k0, kend, wave, lane);
+      gl_zero_tail<BCOL>(cur + 16384, k0, kend, wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int ks = 0; ks < 64; ks += 32) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = gl_frag<ACOL>(cur, wm + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = gl_frag<BCOL>(cur + 16384, wn + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = gemm_mma(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  const int cr = (lane >> 4) * 4, cc = lane & 15;
+  if (p.splitk > 1) {
+    float* W = p.ws + (size_t)z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn + j * 16 + cc;
+        if (col < p.N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm + i * 16 + cr + r;
+            if (row < p.M) W[(size_t)row * p.N + col] = acc[i][j][r];
+          }
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn + j * 16 + cc;
+        if (col < p.N) {
+          const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm + i * 16 + cr + r;
+            if (row < p.M) {
+              float v = p.alpha * acc[i][j][r] + bv;
+              if (p.c_bf16) {
+                reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + col] = (bf16_t)v;
+              } else {
+                float* dst = p.C + (size_t)row * p.ldc + col;
+                if (p.accumulate) v += *dst;
+                *dst = v;
+                if (p.C2) reinterpret_cast<bf16_t*>(p.C2)[(size_t)row * p.ldc2 + col] = (bf16_t)v;
+              }
+            }
+          }
+        }
+      }
+  }
+}

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
 }
 
 // out[c] (+)= sum_r X[r*ld + c].  grid (ceil(cols/64), RS); with RS > 1 `out` must be pre-zeroed (atomics).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int rows, int cols, int ld,
+template <typename ST>
+__global__ __launch_bounds__(256) void colsum_kernel(const ST* __restrict__ X, int rows, int cols, int ld,
                                                      float* __restrict__ out, int use_atomic) {
   __shared__ float sm[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   float s = 0.f;
   if (c < cols)
-    for (int r = r0 + rg; r < r1; r += 4) s += X[(size_t)r * ld + c];
+    for (int r = r0 + rg; r < r1; r += 4) s += (float)X[(size_t)r * ld + c];
   sm[rg][threadIdx.x & 63] = s;
   __syncthreads();
   if (rg == 0 && c < cols) {
@@ -55,24 +56,49 @@ __global__ void add2_kernel(const float* a, const float* b, float* out, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] + b[i];
 }
-__global__ void scale_kernel(float* x, size_t n, float s) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
+template <typename T>
+__global__ void scale_kernel(T* x, size_t n, float s) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] = (T)((float)x[i] * s);
+}
+// operand copy: dst[r][c] = (AT)(scale * src[r*ld_src + c]) for c < cols, 0 for cols <= c < ld_dst (the zero
+// padding the DMA-staged GEMM relies on).  Used for enc, the packed weight images and dout.
+template <typename AT>
+__global__ void pack_block_kernel(AT* __restrict__ dst, int ld_dst, const float* __restrict__ src, int ld_src, int rows,
+                                  int cols, float scale) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    dst[i] = (AT)(c < cols ? scale * src[(size_t)r * ld_src + c] : 0.f);
+  }
+}
+// dst[r] = [src1[r, 0:c1) | src2[r, 0:c2) | 0 ...] with leading dimension ld_dst  (concatenated weight image)
+template <typename DT>
+__global__ void pack2_kernel(DT* __restrict__ dst, int ld_dst, const float* __restrict__ src1, int ld1, int c1,
+                             const float* __restrict__ src2, int ld2, int c2, int rows) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    float v = 0.f;
+    if (c < c1) v = src1[(size_t)r * ld1 + c];
+    else if (c < c1 + c2) v = src2[(size_t)r * ld2 + (c - c1)];
+    dst[i] = (DT)v;
+  }
+}
+// dst[r][c] = sum_j src[r*ld_src + j*cols + c]  (sum of NCH side-by-side partial blocks), zero padded to ld_dst
+template <typename AT>
+__global__ void sum_chunks_kernel(AT* __restrict__ dst, int ld_dst, const AT* __restrict__ src, int ld_src, int rows,
+                                  int cols, int nch) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    float v = 0.f;
+    if (c < cols) for (int j = 0; j < nch; ++j) v += (float)src[(size_t)r * ld_src + j * cols + c];
+    dst[i] = (AT)v;
+  }
 }
 __global__ void copy_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i];
-}
-
-// dst[r][0:c1) = src1[r*ld1 + 0:c1), dst[r][c1:c1+c2) = src2[r*ld2 + 0:c2)   (packed weight images)
-template <typename DT>
-__global__ void pack2_kernel(DT* __restrict__ dst, const float* __restrict__ src1, int ld1, int c1,
-                             const float* __restrict__ src2, int ld2, int c2, int rows) {
-  const int W = c1 + c2;
-  const size_t total = (size_t)rows * W;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / W), c = (int)(i % W);
-    const float v = c < c1 ? src1[(size_t)r * ld1 + c] : src2[(size_t)r * ld2 + (c - c1)];
-    dst[i] = (DT)v;
-  }
 }
 
 // =============================================================================================
@@ -107,16 +133,17 @@ __device__ __forceinline__ LstmGrad lstm_point_bwd(float dh, float dc_in, float 
 // embedding  (decoder.py:46-48)
 // =============================================================================================
 // emb[row, :] = scale * Emb[token(row), :] * dropmask ; row = (t - t0) * B + b
+template <typename AT>
 __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict__ Emb, const int64_t* __restrict__ targets,
-                                                        const int64_t* __restrict__ tokens, float* __restrict__ emb,
+                                                        const int64_t* __restrict__ tokens, AT* __restrict__ emb, int ld,
                                                         int B, int E, int V, float scale, DropDesc dd, int t0) {
   const int row = blockIdx.x, t = t0 + row / B, b = row % B;
   long tok = tokens ? tokens[b] : (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
   tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
   const uint32_t key = drop_key(dd);
   const float* src = Emb + (size_t)tok * E;
-  float* dst = emb + (size_t)row * E;
-  for (int j = threadIdx.x; j < E; j += 128) dst[j] = src[j] * scale * drop_at(dd, key, t, b, E, j);
+  AT* dst = emb + (size_t)row * ld;
+  for (int j = threadIdx.x; j < ld; j += 128) dst[j] = (AT)(j < E ? src[j] * scale * drop_at(dd, key, t, b, E, j) : 0.f);
 }
 // dEmb[token(row), :] += scale * dropmask * demb[row, :]   (dEmb pre-zeroed)
 __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
@@ -142,24 +169,27 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb
 //   Wh  = slab columns [4H, 4H+A)                           (attn_W h_{t-1})
 //   a[f] = w . tanh(Wh + Uv[b,f] + b)                        one wave per frame, wavefront reduction
 //   gates[col] = Xe[t,b,col] + h.W_hh^T (slabs) + (1/F) sum_f a[f] P[b,f,col]   for the chunk's 4 x 64 columns
-//   LSTM pointwise -> h_t, c_t, saved activations
+//   LSTM pointwise -> h_t (fp32 + operand copy), c_t, saved activations
+// AT = operand type of the GEMM inputs this kernel reads / writes (bf16 in the bf16 path, float in the exact path).
 // =============================================================================================
 #define RN_UC 64
 struct DecCellArgs {
   int t, B, F, H, A, S;
   const float* slab;      // [S][B][4H+A] split-K partials of h_{t-1} . [W_hh ; W]^T, nullptr when h_{t-1} = 0
   const float* Xe;        // [B][4H] of step t (emb . W_e^T + b_ih + b_hh)
-  const void* P;          // [B][F][4H] (bf16 in the bf16 path, fp32 in the exact path)
+  const void* P;          // [B*F][ldp] AT
+  int ldp;
   const float* Uv;        // [B][F][A]
   const float* ab; const float* w;
   const float* c_prev;    // [B][H] or nullptr (zeros)
   float* h_out; float* c_out;   // [B][H] of step t
+  void* h_lp; int ld_hlp;       // [B][ld_hlp] AT copy of h_t (next step's GEMM operand; zero padded) or nullptr
   float* acts;            // [B][4H] post-activation gates or nullptr
   float* Wh_out;          // [B][A] or nullptr
   float* att_out;         // [B][F] or nullptr
 };
 
-template <typename PT>
+template <typename AT>
 __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* swh = smem;            // [A]
@@ -168,6 +198,16 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
   const int b = blockIdx.x, u0 = blockIdx.y * RN_UC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
   const size_t zs = (size_t)p.B * WS;
+  // issue the loads that do not depend on the attention scores first (gate pre-activations, P column)
+  const int g = wave, u = u0 + lane;          // one wave per gate, one lane per hidden unit of the chunk
+  float pre = 0.f;
+  const AT* pp = nullptr;
+  if (u < H) {
+    const int col = g * H + u;
+    pre = p.Xe[(size_t)b * W4 + col];
+    if (p.slab) for (int z = 0; z < p.S; ++z) pre += p.slab[z * zs + (size_t)b * WS + col];
+    pp = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp + col;
+  }
   for (int k = tid; k < A; k += 256) {
     float v = 0.f;
     if (p.slab) for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * WS + W4 + k];
@@ -183,15 +223,9 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
     if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
   }
   __syncthreads();
-  const int g = wave, u = u0 + lane;          // one wave per gate, one lane per hidden unit of the chunk
-  float pre = 0.f;
   if (u < H) {
-    const int col = g * H + u;
-    pre = p.Xe[(size_t)b * W4 + col];
-    if (p.slab) for (int z = 0; z < p.S; ++z) pre += p.slab[z * zs + (size_t)b * WS + col];
-    const PT* pp = reinterpret_cast<const PT*>(p.P) + (size_t)b * F * W4 + col;
     float c = 0.f;
-    for (int f = 0; f < F; ++f) c += sa[f] * (float)pp[(size_t)f * W4];
+    for (int f = 0; f < F; ++f) c += sa[f] * (float)pp[(size_t)f * p.ldp];
     pre += c * (1.0f / (float)F);
   }
   spre[g * RN_UC + lane] = pre;
@@ -203,86 +237,125 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
                                  p.c_prev ? p.c_prev[o] : 0.f);
     p.h_out[o] = r.h;
     p.c_out[o] = r.c;
+    if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)r.h;
     if (p.acts) {
       float* a = p.acts + (size_t)b * W4 + uu;
       a[0] = r.i; a[H] = r.f; a[2 * H] = r.g; a[3 * H] = r.o;
     }
   }
+  // zero padding of the operand copy (columns [H, ld_hlp)), once per row
+  if (p.h_lp && blockIdx.y == 0)
+    for (int j = H + tid; j < p.ld_hlp; j += 256) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + j] = (AT)0.f;
 }
 
 // =============================================================================================
-// decoder recurrent step, backward: one workgroup per caption.
-//   dh_t = dHs[t] + (dgates_{t+1} | dWh_{t+1}) . [W_hh ; W] (split-K slabs)  -> LSTM pointwise backward -> dgates_t
-//   da[f] = (1/F) dgates_t . P[b,f,:]   ;   dz = da[f] w (1 - tanh^2)   ;  dWh, dUv, dw accumulate
-// dgates_t and dWh_t are written side by side into one [B][4H+A] row: the A operand of the next
-// step's GEMM and of every deferred weight-gradient GEMM.
+// decoder recurrent step, backward: one workgroup per (caption, frame chunk), RN_FCH chunks.
+//   dh_t = dHs[t] + (dgates_{t+1} | dWh_{t+1}) . [W_hh ; W ; .. ; W] (split-K slabs) -> LSTM pointwise backward
+//   da[f] = (1/F) dgates_t . P[b,f,:]   ;   dz = da[f] w (1 - tanh^2)   ;  dWh (per chunk), dUv, dw accumulate
+// Every chunk recomputes the (cheap) pointwise backward of the whole row, chunk 0 stores it.  The row
+// written is [dgates (4H) | dWh chunk 0 (A) | .. | dWh chunk RN_FCH-1 (A)]: the A operand of the next step's
+// GEMM (against the packed [W_hh ; W x RN_FCH]) and of the deferred weight-gradient GEMMs — the partial dWh
+// are summed by the GEMM's K loop, deterministically, instead of by atomics.
+// dc_carry is double-buffered by step parity because the chunks of one caption run concurrently.
 // =============================================================================================
+#define RN_FCH 4
 struct DecCellBwdArgs {
   int t, B, F, H, A, S;
   const float* slab;     // [S][B][H] or nullptr (t == T-1)
   const float* dHs;      // [B][H] direct gradient of h_t (vocabulary projection + reconstructor)
   const float* acts; const float* c; const float* c_prev;
-  float* dc_carry; int first;
-  float* dGx;            // [B][4H+A]
-  const void* P; const float* Uv; const float* ab; const float* w;
+  const float* dc_in; float* dc_out; int first;
+  void* dGx; int ld_dgx;   // [B][ld_dgx] AT
+  const void* P; int ldp; const float* Uv; const float* ab; const float* w;
   const float* Wh;       // [B][A] of step t
   float* dUv;            // [B][F][A] accumulated over t
-  float* dwacc;          // [B][A] accumulated over t
+  float* dwacc;          // [RN_FCH][B][A] accumulated over t
+  void* dUv_lp; int ld_dUv; int last;   // at the last executed step (t == 0) also emit the AT copy of dUv
 };
 
-template <typename PT>
-__global__ __launch_bounds__(512) void dec_cell_bwd_kernel(const DecCellBwdArgs p) {
+template <typename AT>
+__global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sdg = smem;            // [4H]
   float* sda = sdg + 4 * p.H;   // [F]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x, NW = NT >> 6;
-  const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
+  float* spart = sda + p.F;     // [2][G][A] partial sums
+  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = p.H, A = p.A, F = p.F, W4 = 4 * H;
   const size_t zs = (size_t)p.B * H;
-  float* dgx = p.dGx + (size_t)b * WS;
-  for (int u = tid; u < H; u += NT) {
+  AT* dgx = reinterpret_cast<AT*>(p.dGx) + (size_t)b * p.ld_dgx;
+  for (int u = tid; u < H; u += 256) {
     const size_t o = (size_t)b * H + u;
     float dh = p.dHs[o];
     if (p.slab) for (int z = 0; z < p.S; ++z) dh += p.slab[z * zs + o];
     const float* a = p.acts + (size_t)b * W4 + u;
-    const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_carry[o], a[0], a[H], a[2 * H], a[3 * H], p.c[o],
+    const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_in[o], a[0], a[H], a[2 * H], a[3 * H], p.c[o],
                                       p.c_prev ? p.c_prev[o] : 0.f);
     sdg[u] = g.di; sdg[H + u] = g.df; sdg[2 * H + u] = g.dg; sdg[3 * H + u] = g.d_o;
-    dgx[u] = g.di; dgx[H + u] = g.df; dgx[2 * H + u] = g.dg; dgx[3 * H + u] = g.d_o;
-    p.dc_carry[o] = g.dc_prev;
+    if (ch == 0) {
+      dgx[u] = (AT)g.di; dgx[H + u] = (AT)g.df; dgx[2 * H + u] = (AT)g.dg; dgx[3 * H + u] = (AT)g.d_o;
+      p.dc_out[o] = g.dc_prev;
+    }
   }
+  if (ch == 0) for (int j = W4 + RN_FCH * A + tid; j < p.ld_dgx; j += 256) dgx[j] = (AT)0.f;   // pad
   __syncthreads();
+  // frames of this chunk: f = ch, ch + RN_FCH, ...
   const float invF = 1.0f / (float)F;
-  const PT* Pb = reinterpret_cast<const PT*>(p.P) + (size_t)b * F * W4;
-  for (int f = wave; f < F; f += NW) {
-    const PT* pp = Pb + (size_t)f * W4;
+  const AT* Pb = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp;
+  const int nf = (F - ch + RN_FCH - 1) / RN_FCH;          // frames in this chunk
+  for (int i = wave; i < nf; i += 4) {
+    const int f = ch + i * RN_FCH;
+    const AT* pp = Pb + (size_t)f * p.ldp;
     float s = 0.f;
     for (int n = lane; n < W4; n += 64) s += sdg[n] * (float)pp[n];
     s = wave_sum(s);
     if (lane == 0) sda[f] = s * invF;
   }
   __syncthreads();
-  for (int k = tid; k < A; k += NT) {
-    const float whk = p.Wh[(size_t)b * A + k] + p.ab[k];
-    const float wk = p.w[k];
+  // (f, k) plane: thread -> k = tid % A, frame group gi = tid / A (A <= 256), else one thread per k
+  const int G = (A <= 256) ? 256 / A : 1;
+  auto fk = [&](int kk, int gi) {
+    const float whk = p.Wh[(size_t)b * A + kk] + p.ab[kk];
+    const float wk = p.w[kk];
     float dwh = 0.f, dw = 0.f;
-    for (int f = 0; f < F; ++f) {
-      const size_t o = ((size_t)b * F + f) * A + k;
+    for (int i = gi; i < nf; i += G) {
+      const int f = ch + i * RN_FCH;
+      const size_t o = ((size_t)b * F + f) * A + kk;
       const float tz = tanhf(whk + p.Uv[o]);
       const float ds = sda[f] * wk * (1.f - tz * tz);
       dw += sda[f] * tz;
       dwh += ds;
-      p.dUv[o] = p.first ? ds : p.dUv[o] + ds;
+      const float nv = p.first ? ds : p.dUv[o] + ds;
+      p.dUv[o] = nv;
+      if (p.last) reinterpret_cast<AT*>(p.dUv_lp)[((size_t)b * F + f) * p.ld_dUv + kk] = (AT)nv;
     }
-    dgx[W4 + k] = dwh;
-    const size_t o2 = (size_t)b * A + k;
-    p.dwacc[o2] = p.first ? dw : p.dwacc[o2] + dw;
+    spart[gi * A + kk] = dwh;
+    spart[(G + gi) * A + kk] = dw;
+  };
+  if (A <= 256) {
+    if (tid < G * A) fk(tid % A, tid / A);
+  } else {
+    for (int kk = tid; kk < A; kk += 256) fk(kk, 0);
   }
+  __syncthreads();
+  for (int kk = tid; kk < A; kk += 256) {
+    float a = 0.f, c = 0.f;
+    for (int j = 0; j < G; ++j) { a += spart[j * A + kk]; c += spart[(G + j) * A + kk]; }
+    dgx[W4 + ch * A + kk] = (AT)a;
+    const size_t o2 = ((size_t)ch * p.B + b) * A + kk;
+    p.dwacc[o2] = p.first ? c : p.dwacc[o2] + c;
+  }
+  if (p.last)   // zero padding of the dUv operand copy
+    for (int i = wave; i < nf; i += 4) {
+      const int f = ch + i * RN_FCH;
+      for (int j = A + lane; j < p.ld_dUv; j += 64) reinterpret_cast<AT*>(p.dUv_lp)[((size_t)b * F + f) * p.ld_dUv + j] = (AT)0.f;
+    }
 }
 
 // ctx[t,b,d] = (1/F) sum_f att[t,b,f] enc[b,f,d] for all t at once (the attended features of every step,
-// needed only by the deferred dW_ih[:, E:] = dgates^T . ctx GEMM).  grid (B, ceil(D/256)); T <= 32.
+// needed only by the deferred dW_ih[:, E:] = dgates^T . ctx GEMM).  grid (B, ceil(ld/256)); T <= 32.
+template <typename AT>
 __global__ __launch_bounds__(256) void ctx_all_kernel(const float* __restrict__ att, const float* __restrict__ enc,
-                                                      float* __restrict__ ctx, int T, int B, int F, int D) {
+                                                      AT* __restrict__ ctx, int ld, int T, int B, int F, int D) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [32][F], zero padded beyond T
   const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
   for (int i = threadIdx.x; i < 32 * F; i += 256) {
@@ -290,38 +363,32 @@ __global__ __launch_bounds__(256) void ctx_all_kernel(const float* __restrict__ 
     smem[i] = t < T ? att[((size_t)t * B + b) * F + f] : 0.f;
   }
   __syncthreads();
-  if (d >= D) return;
+  if (d >= ld) return;
   float acc[32];
 #pragma unroll
   for (int t = 0; t < 32; ++t) acc[t] = 0.f;
-  for (int f = 0; f < F; ++f) {
-    const float e = enc[((size_t)b * F + f) * D + d];
+  if (d < D)
+    for (int f = 0; f < F; ++f) {
+      const float e = enc[((size_t)b * F + f) * D + d];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) acc[t] += smem[t * F + f] * e;
-  }
+      for (int t = 0; t < 32; ++t) acc[t] += smem[t * F + f] * e;
+    }
   const float invF = 1.0f / (float)F;
 #pragma unroll
   for (int t = 0; t < 32; ++t)
-    if (t < T) ctx[((size_t)t * B + b) * D + d] = acc[t] * invF;
+    if (t < T) ctx[((size_t)t * B + b) * ld + d] = (AT)(acc[t] * invF);
 }
 // general-T fallback (caption_max_len + 1 > 32)
+template <typename AT>
 __global__ __launch_bounds__(256) void ctx_all_slow_kernel(const float* __restrict__ att, const float* __restrict__ enc,
-                                                           float* __restrict__ ctx, int T, int B, int F, int D) {
+                                                           AT* __restrict__ ctx, int ld, int T, int B, int F, int D) {
   const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
-  if (d >= D) return;
+  if (d >= ld) return;
   for (int t = 0; t < T; ++t) {
     float s = 0.f;
-    for (int f = 0; f < F; ++f) s += att[((size_t)t * B + b) * F + f] * enc[((size_t)b * F + f) * D + d];
-    ctx[((size_t)t * B + b) * D + d] = s / (float)F;
+    if (d < D) for (int f = 0; f < F; ++f) s += att[((size_t)t * B + b) * F + f] * enc[((size_t)b * F + f) * D + d];
+    ctx[((size_t)t * B + b) * ld + d] = (AT)(s / (float)F);
   }
-}
-
-// dst = [src1 (n1 elements) ; src2 (n2 elements)] converted to DT (vertical concatenation of equal-width matrices)
-template <typename DT>
-__global__ void packv_kernel(DT* __restrict__ dst, const float* __restrict__ src1, size_t n1,
-                             const float* __restrict__ src2, size_t n2) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = (DT)(i < n1 ? src1[i] : src2[i - n1]);
 }
 
 // =============================================================================================
@@ -333,10 +400,12 @@ struct LstmPwArgs {
   const float* X; int x_ld;                              // optional pre-computed input part [B][x_ld]
   const float* b1; const float* b2;                      // optional bias vectors [4Hd]
   const float* c_prev;                                   // [B][Hd] or nullptr
-  float* h_out; int h_ld;                                // [B][h_ld]
-  float* h_out2; int h2_ld;                              // optional second destination (next step's GEMM input)
+  float* h_out; int h_ld;                                // [B][h_ld] fp32
+  void* h_lp; int hlp_ld; int hlp_pad_from;              // AT copy [B][hlp_ld]; pad columns [hlp_pad_from, hlp_ld) zeroed
+  void* h_lp2; int hlp2_ld;                              // optional second AT destination (next step's GEMM input row)
   float* c_out; float* acts;
 };
+template <typename AT>
 __global__ __launch_bounds__(256) void lstm_pw_kernel(const LstmPwArgs p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.B * p.Hd) return;
@@ -354,7 +423,12 @@ __global__ __launch_bounds__(256) void lstm_pw_kernel(const LstmPwArgs p) {
   const float cp = p.c_prev ? p.c_prev[(size_t)b * Hd + u] : 0.f;
   const LstmOut r = lstm_point(g[0], g[1], g[2], g[3], cp);
   p.h_out[(size_t)b * p.h_ld + u] = r.h;
-  if (p.h_out2) p.h_out2[(size_t)b * p.h2_ld + u] = r.h;
+  if (p.h_lp) {
+    AT* d = reinterpret_cast<AT*>(p.h_lp) + (size_t)b * p.hlp_ld;
+    d[u] = (AT)r.h;
+    if (u < p.hlp_ld - p.hlp_pad_from) d[p.hlp_pad_from + u] = (AT)0.f;
+  }
+  if (p.h_lp2) reinterpret_cast<AT*>(p.h_lp2)[(size_t)b * p.hlp2_ld + u] = (AT)r.h;
   p.c_out[(size_t)b * Hd + u] = r.c;
   float* a = p.acts + (size_t)b * 4 * Hd + u;
   a[0] = r.i; a[Hd] = r.f; a[2 * Hd] = r.g; a[3 * Hd] = r.o;
@@ -364,42 +438,44 @@ struct LstmBwdArgs {
   int B, Hd, S;
   const float* dh_direct; int dhd_ld; float dh_scale;    // optional [B][dhd_ld]
   const float* slab; size_t slab_stride; int slab_ld; int slab_col0;   // recurrent part: sum_z slab[z][b][col0+u]
-  const float* extra;                                     // optional [B][Hd]
   const float* acts; const float* c; const float* c_prev;
   float* dc_carry; int first;
-  float* dG;                                              // [B][4Hd]
+  void* dG; int ld_dg;                                    // [B][ld_dg] AT, gate columns [0,4Hd), zero padded
 };
+template <typename AT>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.B * p.Hd) return;
   const int b = i / p.Hd, u = i % p.Hd, Hd = p.Hd;
   float dh = p.dh_direct ? p.dh_scale * p.dh_direct[(size_t)b * p.dhd_ld + u] : 0.f;
   for (int z = 0; z < p.S; ++z) dh += p.slab[z * p.slab_stride + (size_t)b * p.slab_ld + p.slab_col0 + u];
-  if (p.extra) dh += p.extra[(size_t)b * Hd + u];
   const size_t o = (size_t)b * Hd + u;
   const float* a = p.acts + (size_t)b * 4 * Hd + u;
   const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_carry[o], a[0], a[Hd], a[2 * Hd], a[3 * Hd], p.c[o],
                                     p.c_prev ? p.c_prev[o] : 0.f);
-  float* dg = p.dG + (size_t)b * 4 * Hd + u;
-  dg[0] = g.di; dg[Hd] = g.df; dg[2 * Hd] = g.dg; dg[3 * Hd] = g.d_o;
+  AT* dg = reinterpret_cast<AT*>(p.dG) + (size_t)b * p.ld_dg;
+  dg[u] = (AT)g.di; dg[Hd + u] = (AT)g.df; dg[2 * Hd + u] = (AT)g.dg; dg[3 * Hd + u] = (AT)g.d_o;
+  if (u < p.ld_dg - 4 * Hd) dg[4 * Hd + u] = (AT)0.f;
   p.dc_carry[o] = g.dc_prev;
 }
 
 // =============================================================================================
 // masked cross-entropy with logits dropout (decoder.py:69, train.py:54-56,68) — forward + dlogits
-//   rowloss[t,b] = [tgt>0] * cw[t] * CE(drop(logits[t,b,:]), tgt) ; logits overwritten by
-//   d loss / d logits = [tgt>0] * cw[t] * gscale * (softmax - onehot) * dropmask
+//   rowloss[t,b] = [tgt>0] * cw[t] * CE(drop(logits[t,b,:]), tgt) ;
+//   dlog[t,b,:]  = [tgt>0] * cw[t] * (softmax - onehot) * dropmask     (AT operand copy, zero padded to ld)
 // =============================================================================================
-__global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ logits, const int64_t* __restrict__ targets,
-                                                 const float* __restrict__ cw, float* __restrict__ rowloss, int B,
-                                                 int V, DropDesc dd, float gscale, int write_grad) {
+template <typename AT>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                 const float* __restrict__ cw, float* __restrict__ rowloss,
+                                                 AT* __restrict__ dlog, int ld, int B, int V, DropDesc dd) {
   __shared__ float sm[4];
   const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
-  float* x = logits + (size_t)row * V;
+  const float* x = logits + (size_t)row * V;
+  AT* dx = dlog + (size_t)row * ld;
   const long tgt = targets[(size_t)t * B + b];
   if (tgt <= 0 || tgt >= V) {
     if (tid == 0) rowloss[row] = 0.f;
-    if (write_grad) for (int v = tid; v < V; v += 256) x[v] = 0.f;
+    for (int v = tid; v < ld; v += 256) dx[v] = (AT)0.f;
     return;
   }
   const uint32_t key = drop_key(dd);
@@ -412,14 +488,13 @@ __global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ logits, con
   const float lse = mx + logf(s);
   const float wgt = cw[t];
   if (tid == 0) rowloss[row] = wgt * (lse - x[tgt] * drop_at(dd, key, t, b, V, (int)tgt));
-  if (write_grad) {
-    __syncthreads();
-    const float k = wgt * gscale;
-    for (int v = tid; v < V; v += 256) {
+  for (int v = tid; v < ld; v += 256) {
+    float gv = 0.f;
+    if (v < V) {
       const float m = drop_at(dd, key, t, b, V, v);
-      const float pr = expf(x[v] * m - lse);
-      x[v] = k * (pr - (v == tgt ? 1.f : 0.f)) * m;
+      gv = wgt * (expf(x[v] * m - lse) - (v == tgt ? 1.f : 0.f)) * m;
     }
+    dx[v] = (AT)gv;
   }
 }
 // logits *= dropmask (step API, train mode)
@@ -435,21 +510,31 @@ __global__ void logits_drop_kernel(float* __restrict__ logits, int B, int V, Dro
 // =============================================================================================
 // global reconstructor helpers (global_reconstructor.py:33-41, train.py:96-102)
 // =============================================================================================
-// out[i] = scale * sum_t X[t*n + i]
-__global__ void mean_over_t_kernel(const float* __restrict__ X, int T, size_t n, float scale, float* __restrict__ out) {
+// out[b,c] = scale * sum_t X[t,b,c]  (+ AT operand copy with zero padding)
+template <typename AT>
+__global__ void mean_over_t_kernel(const float* __restrict__ X, int T, int Bn, int Cn, float scale, float* __restrict__ out,
+                                   AT* __restrict__ out_lp, int ld_lp) {
+  const int ldx = out_lp ? ld_lp : Cn;
+  const size_t n = (size_t)Bn * ldx;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ldx), c = (int)(i % ldx);
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += X[(size_t)t * n + i];
-    out[i] = s * scale;
+    if (c < Cn) {
+      for (int t = 0; t < T; ++t) s += X[((size_t)t * Bn + b) * Cn + c];
+      s *= scale;
+      out[(size_t)b * Cn + c] = s;
+    }
+    if (out_lp) out_lp[i] = (AT)s;
   }
 }
-// mpd[t,b,h] = mp[b,h] * dropmask(t,b,h)
-__global__ void bcast_drop_kernel(const float* __restrict__ mp, float* __restrict__ mpd, int T, int B, int H, DropDesc dd) {
+// mpd[t,b,h] = mp[b,h] * dropmask(t,b,h)   (AT operand, zero padded)
+template <typename AT>
+__global__ void bcast_drop_kernel(const float* __restrict__ mp, AT* __restrict__ mpd, int ld, int T, int B, int H, DropDesc dd) {
   const uint32_t key = drop_key(dd);
-  const size_t total = (size_t)T * B * H;
+  const size_t total = (size_t)T * B * ld;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int h = (int)(i % H), b = (int)((i / H) % B), t = (int)(i / ((size_t)H * B));
-    mpd[i] = mp[(size_t)b * H + h] * drop_at(dd, key, t, b, H, h);
+    const int h = (int)(i % ld), b = (int)((i / ld) % B), t = (int)(i / ((size_t)ld * B));
+    mpd[i] = (AT)(h < H ? mp[(size_t)b * H + h] * drop_at(dd, key, t, b, H, h) : 0.f);
   }
 }
 // dmp[b,h] = sum_t dmpd[t,b,h] * dropmask(t,b,h)
@@ -481,7 +566,7 @@ __global__ void mean_over_f_kernel(const float* __restrict__ enc, int B, int F, 
     out[i] = s / (float)F;
   }
 }
-// diff = out - ref(b, s, :);  partial[block] = sum diff^2 ; out <- gcoef * diff   (d loss / d out)
+// diff = out - ref(b, s, :);  partial[block] = sum diff^2 ; out <- gcoef * diff   (d loss / d out, fp32)
 //   ref indexing: ref[b*ref_bstride + s*ref_sstride + r], out rows ordered (s, b)
 __global__ __launch_bounds__(256) void mse_kernel(float* __restrict__ out, const float* __restrict__ ref, int Sn, int B,
                                                   int R, size_t ref_bstride, size_t ref_sstride,
@@ -511,9 +596,10 @@ struct LocAttnArgs {
   const float* Hs;        // [T][B][H] decoder hidden states
   float* Whr_out;         // [B][A]
   float* beta_out;        // [B][T]
-  float* xcat; int xcat_ld;   // x -> [0,H) of the step's GEMM input row
+  void* xcat; int xcat_ld;   // AT row [x (H) | hr (R) | pad]: x -> [0,H)
   DropDesc dd;
 };
+template <typename AT>
 __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* swh = smem;            // [A]
@@ -537,10 +623,11 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   __syncthreads();
   const uint32_t key = drop_key(p.dd);
   const float invT = 1.0f / (float)p.T;
+  AT* xr = reinterpret_cast<AT*>(p.xcat) + (size_t)b * p.xcat_ld;
   for (int h = tid; h < p.H; h += 256) {
     float s = 0.f;
     for (int t = 0; t < p.T; ++t) s += sbeta[t] * p.Hs[((size_t)t * p.B + b) * p.H + h];
-    p.xcat[(size_t)b * p.xcat_ld + h] = s * invT * drop_at(p.dd, key, p.s, b, p.H, h);
+    xr[h] = (AT)(s * invT * drop_at(p.dd, key, p.s, b, p.H, h));
   }
 }
 
@@ -548,22 +635,24 @@ struct LocBwdArgs {
   int s, B, T, H, R, A, S;
   int do_attn, do_lstm;
   const float* slab;      // [S][B][H+R] = dGr_s . [W_ih | W_hh]
-  const float* Hs; const float* Ud; const float* ab; const float* w; const float* Wr;  // Wr [A][R]
+  const float* Hs; const float* Ud; const float* ab; const float* w; const float* Wr;  // Wr [A][R] fp32
   const float* Whr;       // [B][A] of step s
   const float* beta;      // [B][T] of step s
   float* dHs;             // [T][B][H] accumulated over s
   float* dUd;             // [T][B][A] accumulated over s
-  float* dWhr;            // [B][A] of step s
+  void* dWhr; int ld_dwhr;   // AT [B][ld] of step s (operand of the deferred dW_r GEMM)
   float* dwacc;           // [B][A]
   int first_attn;
   int prop_hr;            // s > 0: propagate dWhr . W_r into hr_{s-1}
+  void* dUd_lp; int ld_dUd; int last;   // at s == 0 also emit the AT copy of dUd
   DropDesc dd;
   // LSTM backward of step s-1
   const float* dHr;       // [B][R] direct gradient of hr_{s-1}
   const float* acts; const float* c; const float* c_prev;
   float* dc_carry; int first_lstm;
-  float* dG;              // [B][4R]
+  void* dG; int ld_dg;    // AT [B][ld_dg]
 };
+template <typename AT>
 __global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sdx = smem;            // [H]
@@ -597,7 +686,9 @@ __global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
       for (int h = tid; h < H; h += 256) dst[h] = p.first_attn ? bt * sdx[h] : dst[h] + bt * sdx[h];
     }
     __syncthreads();
-    for (int k = tid; k < A; k += 256) {
+    AT* dwr = reinterpret_cast<AT*>(p.dWhr) + (size_t)b * p.ld_dwhr;
+    for (int k = tid; k < p.ld_dwhr; k += 256) {
+      if (k >= A) { dwr[k] = (AT)0.f; continue; }
       const float whk = p.Whr[(size_t)b * A + k] + p.ab[k];
       const float wk = p.w[k];
       float dwh = 0.f, dw = 0.f;
@@ -607,13 +698,18 @@ __global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
         const float dz = sdb[t] * wk * (1.f - tz * tz);
         dw += sdb[t] * tz;
         dwh += dz;
-        p.dUd[o] = p.first_attn ? dz : p.dUd[o] + dz;
+        const float nv = p.first_attn ? dz : p.dUd[o] + dz;
+        p.dUd[o] = nv;
+        if (p.last) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + k] = (AT)nv;
       }
       sdWh[k] = dwh;
-      p.dWhr[(size_t)b * A + k] = dwh;
+      dwr[k] = (AT)dwh;
       const size_t o2 = (size_t)b * A + k;
       p.dwacc[o2] = p.first_attn ? dw : p.dwacc[o2] + dw;
     }
+    if (p.last)
+      for (int t = 0; t < T; ++t)
+        for (int j = A + tid; j < p.ld_dUd; j += 256) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + j] = (AT)0.f;
     __syncthreads();
     if (p.prop_hr) {
       for (int r = tid; r < R; r += 256) {
@@ -628,16 +724,17 @@ __global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
     __syncthreads();
   }
   if (!p.do_lstm) return;
+  AT* dg = reinterpret_cast<AT*>(p.dG) + (size_t)b * p.ld_dg;
   for (int u = tid; u < R; u += 256) {
     const size_t o = (size_t)b * R + u;
     const float dh = p.dHr[o] + sdh[u];
     const float* a = p.acts + (size_t)b * 4 * R + u;
     const LstmGrad g = lstm_point_bwd(dh, p.first_lstm ? 0.f : p.dc_carry[o], a[0], a[R], a[2 * R], a[3 * R],
                                       p.c[o], p.c_prev ? p.c_prev[o] : 0.f);
-    float* dg = p.dG + (size_t)b * 4 * R + u;
-    dg[0] = g.di; dg[R] = g.df; dg[2 * R] = g.dg; dg[3 * R] = g.d_o;
+    dg[u] = (AT)g.di; dg[R + u] = (AT)g.df; dg[2 * R + u] = (AT)g.dg; dg[3 * R + u] = (AT)g.d_o;
     p.dc_carry[o] = g.dc_prev;
   }
+  for (int j = 4 * R + tid; j < p.ld_dg; j += 256) dg[j] = (AT)0.f;
 }
 
 // =============================================================================================

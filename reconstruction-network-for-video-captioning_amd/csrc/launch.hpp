@@ -21,7 +21,8 @@ int rn_effective_splitk(int prec, int K, int splitk);
 // run the slab reduction (otherwise the caller's fused consumer sums ws[z][M][N] itself).
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
-                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag = 0, int c_bf16 = 0);
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag = 0, int c_bf16 = 0,
+                    void* c2 = nullptr, int ldc2 = 0);
 
 // ---- dropout descriptor handed to kernels: seed lives in device memory so a captured graph can be
 // replayed with a new seed.

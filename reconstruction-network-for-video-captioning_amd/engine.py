@@ -296,6 +296,22 @@ class Engine:
         v = self.scalars.tolist()
         return dict(zip(_lib.SCALAR_NAMES, v))
 
+    def gemm_bf16(self, A, B, a_col=False, b_col=False, bias=None, alpha=1.0, C_out=None, accumulate=False, splitk=1,
+                  M=None, N=None, K=None, tag=0):
+        """Test hook for the DMA-staged bf16 kernel: A, B are torch.bfloat16."""
+        if M is None:
+            M = A.shape[1] if a_col else A.shape[0]
+            K = A.shape[0] if a_col else A.shape[1]
+            N = B.shape[1] if b_col else B.shape[0]
+        if C_out is None:
+            C_out = torch.zeros(M, N, dtype=torch.float32, device=A.device)
+        ws = torch.empty(max(1, splitk) * M * N, dtype=torch.float32, device=A.device) if splitk > 1 else None
+        _lib.check(self.lib.recnet_gemm_bf16(_ptr(A), int(a_col), A.stride(0), _ptr(B), int(b_col), B.stride(0),
+                                             _ptr(C_out), C_out.stride(0), _ptr(bias), M, N, K, float(alpha),
+                                             int(accumulate), int(splitk), _ptr(ws), int(tag), _stream()),
+                   "recnet_gemm_bf16")
+        return C_out
+
     def gemm(self, A, B, a_col=False, b_col=False, bias=None, alpha=1.0, C_out=None, accumulate=False, splitk=1,
              M=None, N=None, K=None):
         """Test hook: C[M,N] (+)= alpha * op(A) op(B)^T + bias through the MFMA GEMM."""
