@@ -17,6 +17,29 @@ __global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t
   int s = *step + 1; *step = s; *seed_slot = seed_base + (uint32_t)s;
 }
 
+// sum_{z<n} p[z*stride] with four independent accumulators: the loads are issued back to back instead of
+// one per add (these kernels run at low occupancy, so instruction-level parallelism hides the L2 latency)
+__device__ __forceinline__ float sum_strided(const float* __restrict__ p, size_t stride, int n) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int z = 0;
+  for (; z + 4 <= n; z += 4) {
+    const float a = p[(size_t)z * stride], b = p[(size_t)(z + 1) * stride], c = p[(size_t)(z + 2) * stride], d = p[(size_t)(z + 3) * stride];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; z < n; ++z) s0 += p[(size_t)z * stride];
+  return (s0 + s1) + (s2 + s3);
+}
+// 8 consecutive operand elements as floats (16-byte aligned for bf16, 32-byte for float)
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
 __device__ __forceinline__ uint32_t drop_key(const DropDesc& dd) { return rn_site_key(*dd.seed, dd.site); }
 __device__ __forceinline__ float drop_at(const DropDesc& dd, uint32_t key, int t, int b, int N, int j) {
   const uint32_t idx = ((uint32_t)t * (uint32_t)dd.Bg + (uint32_t)(dd.boff + b)) * (uint32_t)N + (uint32_t)j;
@@ -205,12 +228,11 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
   if (u < H) {
     const int col = g * H + u;
     pre = p.Xe[(size_t)b * W4 + col];
-    if (p.slab) for (int z = 0; z < p.S; ++z) pre += p.slab[z * zs + (size_t)b * WS + col];
+    if (p.slab) pre += sum_strided(p.slab + (size_t)b * WS + col, zs, p.S);
     pp = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp + col;
   }
   for (int k = tid; k < A; k += 256) {
-    float v = 0.f;
-    if (p.slab) for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * WS + W4 + k];
+    const float v = p.slab ? sum_strided(p.slab + (size_t)b * WS + W4 + k, zs, p.S) : 0.f;
     swh[k] = v;
     if (p.Wh_out && blockIdx.y == 0) p.Wh_out[(size_t)b * A + k] = v;
   }
@@ -224,9 +246,15 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
   }
   __syncthreads();
   if (u < H) {
-    float c = 0.f;
-    for (int f = 0; f < F; ++f) c += sa[f] * (float)pp[(size_t)f * p.ldp];
-    pre += c * (1.0f / (float)F);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    int f = 0;
+    for (; f + 4 <= F; f += 4) {
+      const float v0 = (float)pp[(size_t)f * p.ldp], v1 = (float)pp[(size_t)(f + 1) * p.ldp],
+                  v2 = (float)pp[(size_t)(f + 2) * p.ldp], v3 = (float)pp[(size_t)(f + 3) * p.ldp];
+      c0 += sa[f] * v0; c1 += sa[f + 1] * v1; c2 += sa[f + 2] * v2; c3 += sa[f + 3] * v3;
+    }
+    for (; f < F; ++f) c0 += sa[f] * (float)pp[(size_t)f * p.ldp];
+    pre += ((c0 + c1) + (c2 + c3)) * (1.0f / (float)F);
   }
   spre[g * RN_UC + lane] = pre;
   __syncthreads();
@@ -286,7 +314,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   for (int u = tid; u < H; u += 256) {
     const size_t o = (size_t)b * H + u;
     float dh = p.dHs[o];
-    if (p.slab) for (int z = 0; z < p.S; ++z) dh += p.slab[z * zs + o];
+    if (p.slab) dh += sum_strided(p.slab + o, zs, p.S);
     const float* a = p.acts + (size_t)b * W4 + u;
     const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_in[o], a[0], a[H], a[2 * H], a[3 * H], p.c[o],
                                       p.c_prev ? p.c_prev[o] : 0.f);
@@ -306,7 +334,19 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
     const int f = ch + i * RN_FCH;
     const AT* pp = Pb + (size_t)f * p.ldp;
     float s = 0.f;
-    for (int n = lane; n < W4; n += 64) s += sdg[n] * (float)pp[n];
+    if ((W4 & 7) == 0) {
+      float s1 = 0.f;
+      for (int n = lane * 8; n < W4; n += 512) {
+        float v[8];
+        load8(pp + n, v);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sdg + n), g1 = *reinterpret_cast<const f32x4*>(sdg + n + 4);
+        s += g0[0] * v[0] + g0[1] * v[1] + g0[2] * v[2] + g0[3] * v[3];
+        s1 += g1[0] * v[4] + g1[1] * v[5] + g1[2] * v[6] + g1[3] * v[7];
+      }
+      s += s1;
+    } else {
+      for (int n = lane; n < W4; n += 64) s += sdg[n] * (float)pp[n];
+    }
     s = wave_sum(s);
     if (lane == 0) sda[f] = s * invF;
   }
@@ -417,7 +457,7 @@ __global__ __launch_bounds__(256) void lstm_pw_kernel(const LstmPwArgs p) {
     float v = p.X ? p.X[(size_t)b * p.x_ld + col] : 0.f;
     if (p.b1) v += p.b1[col];
     if (p.b2) v += p.b2[col];
-    for (int z = 0; z < p.S; ++z) v += p.slab[z * p.slab_stride + (size_t)b * p.slab_ld + col];
+    if (p.S) v += sum_strided(p.slab + (size_t)b * p.slab_ld + col, p.slab_stride, p.S);
     g[q] = v;
   }
   const float cp = p.c_prev ? p.c_prev[(size_t)b * Hd + u] : 0.f;
@@ -448,7 +488,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs p) {
   if (i >= p.B * p.Hd) return;
   const int b = i / p.Hd, u = i % p.Hd, Hd = p.Hd;
   float dh = p.dh_direct ? p.dh_scale * p.dh_direct[(size_t)b * p.dhd_ld + u] : 0.f;
-  for (int z = 0; z < p.S; ++z) dh += p.slab[z * p.slab_stride + (size_t)b * p.slab_ld + p.slab_col0 + u];
+  if (p.S) dh += sum_strided(p.slab + (size_t)b * p.slab_ld + p.slab_col0 + u, p.slab_stride, p.S);
   const size_t o = (size_t)b * Hd + u;
   const float* a = p.acts + (size_t)b * 4 * Hd + u;
   const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_carry[o], a[0], a[Hd], a[2 * Hd], a[3 * Hd], p.c[o],
@@ -607,8 +647,7 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t zs = (size_t)p.B * p.A;
   for (int k = tid; k < p.A; k += 256) {
-    float v = 0.f;
-    if (p.slab) for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * p.A + k];
+    const float v = p.slab ? sum_strided(p.slab + (size_t)b * p.A + k, zs, p.S) : 0.f;
     swh[k] = v;
     p.Whr_out[(size_t)b * p.A + k] = v;
   }
@@ -666,8 +705,7 @@ __global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
     const size_t zs = (size_t)p.B * W2;
     const uint32_t key = drop_key(p.dd);
     for (int j = tid; j < W2; j += 256) {
-      float v = 0.f;
-      for (int z = 0; z < p.S; ++z) v += p.slab[z * zs + (size_t)b * W2 + j];
+      const float v = sum_strided(p.slab + (size_t)b * W2 + j, zs, p.S);
       if (j < H) sdx[j] = v * drop_at(p.dd, key, p.s, b, H, j); else sdh[j - H] = v;
     }
     __syncthreads();
