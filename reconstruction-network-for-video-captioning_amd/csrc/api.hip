@@ -58,6 +58,8 @@ struct recnet_handle {
   void *mpd_lp, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr;
   void *Wih_a, *Wih_b, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   size_t gws_floats, slab_floats;
+  float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
+  hipStream_t s2 = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int overlap = 1;
   // bindings
   recnet_decoder_tensors dP{}, dGd{}, dM{}, dV{}, dVm{};
   recnet_reconstructor_tensors rP{}, rG{}, rM{}, rV{}, rVm{};
@@ -128,6 +130,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->slab = take(h->slab_floats);
   h->gws_floats = (size_t)16 << 20;   // 64 MiB of split-K slabs for the batched GEMMs
   h->gws = take(h->gws_floats);
+  h->gws2 = take(h->gws_floats);
   if (h->kind != RECNET_REC_NONE) {
     h->bsum_r = take(4 * R);
     h->dcr_carry = take(B * R);
@@ -212,6 +215,8 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
 void recnet_destroy(recnet_handle* h) {
   if (!h) return;
   for (auto e : h->prof_ev) hipEventDestroy(e);
+  for (int i = 0; i < 6; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  if (h->s2) hipStreamDestroy(h->s2);
   delete h;
 }
 
@@ -237,6 +242,13 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   if (((uintptr_t)workspace) % 256) return fail(RECNET_EINVAL, "workspace must be 256-byte aligned");
   h->ws = (char*)workspace; h->ws_bytes = bytes;
   carve(h, h->ws);
+  h->gws_cur = h->gws;
+  if (!h->s2) {
+    const char* ov = getenv("RN_OVERLAP");
+    h->overlap = ov ? atoi(ov) : 1;
+    HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
+    for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
+  }
   h->fwd_dec_done = h->fwd_rec_done = h->rec_bwd_done = 0;
   int r = upload_tables(h, 0); if (r) return r;
   return upload_tables(h, 1);
@@ -341,7 +353,7 @@ static void gemm(recnet_handle* h, const void* A, int a_col, int lda, const void
                  const float* bias, int M, int N, int K, float alpha, int acc, hipStream_t st) {
   int s = rn_pick_splitk(h->prec, M, N, K, 16);
   while (s > 1 && (size_t)s * M * N > h->gws_floats) s >>= 1;
-  rn_launch_gemm(h->prec, A, h->lp, a_col, lda, Bm, h->lp, b_col, ldb, C, ldc, bias, M, N, K, alpha, acc, s, h->gws, 1, st);
+  rn_launch_gemm(h->prec, A, h->lp, a_col, lda, Bm, h->lp, b_col, ldb, C, ldc, bias, M, N, K, alpha, acc, s, h->gws_cur, 1, st);
 }
 // same, output written as an operand buffer (AT) — direct epilogue only
 static void gemm_to_at(recnet_handle* h, const void* A, int a_col, int lda, const void* Bm, int b_col, int ldb, void* C,
@@ -383,6 +395,14 @@ static void colsum_t(const ST* X, int rows, int cols, int ld, float* out, hipStr
 static void colsum_at(recnet_handle* h, const void* X, int rows, int cols, int ld, float* out, hipStream_t st) {
   if (h->lp) colsum_t<bf16_t>((const bf16_t*)X, rows, cols, ld, out, st);
   else colsum_t<float>((const float*)X, rows, cols, ld, out, st);
+}
+// fork: `side` continues after everything enqueued on `main` so far; join: `main` waits for `side`.  Under
+// stream capture these become graph edges, so independent work runs in parallel branches of the hipGraph.
+static void fork_to(recnet_handle* h, int e, hipStream_t main, hipStream_t side) {
+  hipEventRecord(h->ev[e], main); hipStreamWaitEvent(side, h->ev[e], 0);
+}
+static void join_from(recnet_handle* h, int e, hipStream_t main, hipStream_t side) {
+  hipEventRecord(h->ev[e], side); hipStreamWaitEvent(main, h->ev[e], 0);
 }
 static void copyf(const float* x, float* y, size_t n, hipStream_t st) {
   hipMemcpyAsync(y, x, n * 4, hipMemcpyDeviceToDevice, st);
@@ -456,9 +476,9 @@ static void embed_fwd(recnet_handle* h, const int64_t* targets, const int64_t* t
 }
 
 // ---------------------------------------------------------------------------------------------- decoder forward
-static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw,
-                       int train, float* hiddens_out, hipStream_t st) {
-  const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A, V = h->V;
+// the dependent chain: invariants, embeddings, T x (GEMM + cell kernel)
+static int dec_fwd_chain(recnet_handle* h, const float* enc, const int64_t* targets, int T, int train, hipStream_t st) {
+  const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A;
   param_norms(h, 0, h->scal + 1, st);
   dec_invariants(h, enc, st);
   // all T teacher-forced input embeddings at once    (decoder.py:46-48, train.py:25,45)
@@ -482,7 +502,12 @@ static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
     a.Wh_out = h->Wh + (size_t)t * B * A; a.att_out = h->att + (size_t)t * B * F;
     launch_dec_cell(h, a, st);
   }
-  // logits for all steps, then masked CE with logits dropout (decoder.py:68-69, train.py:54-68)
+  h->T_last = T; h->train_last = train;
+  return RECNET_OK;
+}
+// vocabulary projection + loss for all steps (decoder.py:68-69, train.py:54-68); independent of the reconstructor
+static int dec_fwd_loss(recnet_handle* h, const int64_t* targets, int T, const float* stepw, int train, hipStream_t st) {
+  const int B = h->B, H = h->H, V = h->V;
   gemm(h, h->Hs_lp, 0, h->ldH, h->Wo_w, 0, h->ldH, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
   copyf(stepw, h->stepw, T, st);
   {
@@ -493,29 +518,37 @@ static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, h->rowloss, T * B, h->scal + 0, 1.0f);
   hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 0, h->scal + 1, h->c.decoder_lambda_reg, h->scal + 2);
   hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 2, 0.f, h->scal + 6);
-  if (hiddens_out) copyf(h->Hs, hiddens_out, (size_t)T * B * H, st);
-  h->T_last = T; h->train_last = train; h->fwd_dec_done = 1; h->fwd_rec_done = 0; h->rec_bwd_done = 0;
+  return RECNET_OK;
+}
+static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw,
+                       int train, float* hiddens_out, hipStream_t st) {
+  int r = dec_fwd_chain(h, enc, targets, T, train, st); if (r) return r;
+  r = dec_fwd_loss(h, targets, T, stepw, train, st); if (r) return r;
+  if (hiddens_out) copyf(h->Hs, hiddens_out, (size_t)T * h->B * h->H, st);
+  h->fwd_dec_done = 1; h->fwd_rec_done = 0; h->rec_bwd_done = 0;
   return RECNET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- decoder backward
-static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhid, float gscale,
-                       hipStream_t st) {
-  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, T = h->T_last;
-  const int train = h->train_last;
-  const int TB = T * B, ldWS = h->ldWS, KW = 4 * H + RN_FCH * A;
+// output layer: dHs_out = dlogits . W_o, dW_o, db_o — needs only the decoder forward
+static int dec_bwd_out(recnet_handle* h, float gscale, hipStream_t st) {
+  const int B = h->B, H = h->H, V = h->V, T = h->T_last, TB = T * B;
   if (gscale != 1.0f) {
     const size_t n = (size_t)TB * h->ldV;
     if (h->lp) hipLaunchKernelGGL(scale_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->dlog_lp, n, gscale);
     else hipLaunchKernelGGL(scale_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->dlog_lp, n, gscale);
   }
-  // dHs = dhiddens (from the reconstructor) + dlogits . W_o
-  if (dhid) copyf(dhid, h->dHs, (size_t)TB * H, st); else hipMemsetAsync(h->dHs, 0, (size_t)TB * H * 4, st);
-  gemm(h, h->dlog_lp, 0, h->ldV, h->Wo_w, 1, h->ldH, h->dHs, H, nullptr, TB, H, V, 1.f, 1, st);
+  gemm(h, h->dlog_lp, 0, h->ldV, h->Wo_w, 1, h->ldH, h->dHs, H, nullptr, TB, H, V, 1.f, 0, st);
   // dW_o = dlogits^T . Hs ; db_o = colsum(dlogits)
   gemm(h, h->dlog_lp, 1, h->ldV, h->Hs_lp, 1, h->ldH, h->dGd.out_weight, H, nullptr, V, H, TB, 1.f, 0, st);
   colsum_at(h, h->dlog_lp, TB, V, h->ldV, h->dGd.out_bias, st);
-  // BPTT: per step one fused kernel over (caption, frame chunk) + one split-K GEMM (dgates_t | dWh_t chunks) . [W_hh ; W x4]
+  return RECNET_OK;
+}
+// BPTT chain; dh_t (direct) = dHs_out[t] + dhid[t] (the reconstructor's gradient w.r.t. the hidden states)
+static int dec_bwd_chain(recnet_handle* h, const float* dhid, hipStream_t st) {
+  const int B = h->B, F = h->F, H = h->H, A = h->A, T = h->T_last;
+  const int ldWS = h->ldWS, KW = 4 * H + RN_FCH * A;
+  // per step one fused kernel over (caption, frame chunk) + one split-K GEMM (dgates_t | dWh_t chunks) . [W_hh ; W x4]
   DecCellBwdArgs a;
   a.B = B; a.F = F; a.H = H; a.A = A;
   a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
@@ -525,7 +558,7 @@ static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
   int S = 0;
   for (int t = T - 1; t >= 0; --t) {
     a.t = t; a.S = S; a.slab = (t < T - 1) ? h->slab : nullptr; a.first = (t == T - 1); a.last = (t == 0);
-    a.dHs = h->dHs + (size_t)t * B * H;
+    a.dHs = h->dHs + (size_t)t * B * H; a.dHs2 = dhid ? dhid + (size_t)t * B * H : nullptr;
     a.acts = h->acts + (size_t)t * B * 4 * H;
     a.c = h->Cs + (size_t)t * B * H;
     a.c_prev = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
@@ -536,6 +569,11 @@ static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
     if (t > 0)
       S = gemm_slabs(h, RN_TAG_DEC_BWD, at_off(h, h->dGx, (size_t)t * B * ldWS), ldWS, h->Wcomb, 1, h->ldH, B, H, KW, st);
   }
+  return RECNET_OK;
+}
+static int dec_bwd_deferred(recnet_handle* h, const float* enc, const int64_t* targets, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, T = h->T_last;
+  const int train = h->train_last, TB = T * B, ldWS = h->ldWS;
   // deferred weight gradients (batched over all T steps); dgates live in columns [0,4H) of dGx, dWh chunks behind them
   gemm(h, h->dGx, 0, ldWS, h->We_w, 1, h->ldE, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
   hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
@@ -574,6 +612,12 @@ static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
   colsum_at(h, h->dWhs, TB, A, h->ldA, h->dGd.attn_b, st);
   colsum_t<float>(h->dwacc, RN_FCH * B, A, A, h->dGd.attn_w_weight, st);
   return RECNET_OK;
+}
+static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhid, float gscale,
+                       hipStream_t st) {
+  int r = dec_bwd_out(h, gscale, st); if (r) return r;
+  r = dec_bwd_chain(h, dhid, st); if (r) return r;
+  return dec_bwd_deferred(h, enc, targets, st);
 }
 
 // ---------------------------------------------------------------------------------------------- global reconstructor
@@ -659,6 +703,10 @@ static int bwd_rec_global(recnet_handle* h, float gscale, float* dhid_out, hipSt
                      mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train));
   hipLaunchKernelGGL(add_bcast_kernel, dim3(ew_blocks((size_t)T * nBH)), dim3(256), 0, st, dhid_out, h->dmp, T, nBH,
                      (float)h->cml / ((float)T * (float)T), 1);
+  return RECNET_OK;
+}
+static int bwd_rec_global_deferred(recnet_handle* h, hipStream_t st) {
+  const int B = h->B, H = h->H, R = h->R, T = h->T_last, TB = T * B, ld4R = h->ld4R;
   gemm(h, h->dGr, 1, ld4R, h->Hs_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
   gemm(h, h->dGr, 1, ld4R, h->mpd_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
   if (T > 1)
@@ -736,9 +784,13 @@ static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStr
     LAUNCH_AT(h, loc_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
     if (s > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)(s - 1) * B * ld4R), ld4R, h->Wihh_w, 1, ldHR, B, H + R, 4 * R, st);
   }
-  // deferred, batched
-  gemm(h, h->dUd_lp, 1, h->ldRA, h->Hs_lp, 1, h->ldH, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
   gemm(h, h->dUd_lp, 0, h->ldRA, h->Ur_w, 1, h->ldH, dhid_out, H, nullptr, TB, H, RA, 1.f, 1, st);
+  return RECNET_OK;
+}
+static int bwd_rec_local_deferred(recnet_handle* h, hipStream_t st) {
+  const int B = h->B, F = h->F, H = h->H, R = h->R, RA = h->RA, T = h->T_last, TB = T * B, FB = F * B;
+  const int ld4R = h->ld4R, ldHR = h->ldHR;
+  gemm(h, h->dUd_lp, 1, h->ldRA, h->Hs_lp, 1, h->ldH, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
   if (F > 1) {
     gemm(h, at_off(h, h->dWhr, (size_t)B * h->ldRA), 1, h->ldRA, h->Hr_lp, 1, h->ldR, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
     gemm(h, at_off(h, h->dGr, (size_t)B * ld4R), 1, ld4R, h->Hr_lp, 1, h->ldR, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (F - 1) * B, 1.f, 0, st);
@@ -763,8 +815,16 @@ static int fwd_rec(recnet_handle* h, const float* enc, int T, int train, hipStre
   h->T_last = T; h->train_last = train; h->fwd_rec_done = 1;
   return RECNET_OK;
 }
-static int bwd_rec(recnet_handle* h, float gscale, float* dhid_out, hipStream_t st) {
+// chain part (ends with d loss / d hiddens, which the decoder backward needs) and the deferred weight gradients
+static int bwd_rec_chain(recnet_handle* h, float gscale, float* dhid_out, hipStream_t st) {
   return h->kind == RECNET_REC_GLOBAL ? bwd_rec_global(h, gscale, dhid_out, st) : bwd_rec_local(h, gscale, dhid_out, st);
+}
+static int bwd_rec_deferred(recnet_handle* h, hipStream_t st) {
+  return h->kind == RECNET_REC_GLOBAL ? bwd_rec_global_deferred(h, st) : bwd_rec_local_deferred(h, st);
+}
+static int bwd_rec(recnet_handle* h, float gscale, float* dhid_out, hipStream_t st) {
+  int r = bwd_rec_chain(h, gscale, dhid_out, st); if (r) return r;
+  return bwd_rec_deferred(h, st);
 }
 
 static int optimizer_step(recnet_handle* h, int flags, hipStream_t st) {
@@ -938,15 +998,39 @@ int recnet_optimizer_step(recnet_handle* h, int32_t step, int32_t flags, recnet_
   return RECNET_OK;
 }
 
+// The whole forward + backward.  The four dependent chains (decoder fwd, reconstructor fwd, reconstructor bwd,
+// decoder bwd) stay on `st`; work that no chain waits for runs on the side stream beside them: the vocabulary
+// projection + CE + output-layer gradients while the reconstructor runs, the reconstructor's deferred weight
+// gradients while the decoder BPTT runs.  The chains are latency-bound (~1 workgroup per CU), so the batched
+// GEMMs fill CUs that would otherwise idle.
 static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st) {
-  int r = fwd_decoder(h, enc, targets, T, stepw, 1, nullptr, st); if (r) return r;
+  const bool rec = h->kind != RECNET_REC_NONE;
+  hipStream_t sd = (h->overlap && rec) ? h->s2 : st;
+  const bool par = sd != st;
+  int r = dec_fwd_chain(h, enc, targets, T, 1, st); if (r) return r;
+  if (par) { fork_to(h, 0, st, sd); h->gws_cur = h->gws2; }
+  r = dec_fwd_loss(h, targets, T, stepw, 1, sd); if (r) return r;
+  r = dec_bwd_out(h, 1.0f, sd); if (r) return r;
+  h->gws_cur = h->gws;
   const float* dh = nullptr;
-  if (h->kind != RECNET_REC_NONE) {
+  if (rec) {
     r = fwd_rec(h, enc, T, 1, st); if (r) return r;
-    r = bwd_rec(h, h->c.lambda_recon, h->dHsrec, st); if (r) return r;
+    r = bwd_rec_chain(h, h->c.lambda_recon, h->dHsrec, st); if (r) return r;
     dh = h->dHsrec;
+    if (par) {
+      join_from(h, 1, st, sd);              // the decoder BPTT needs dHs_out
+      fork_to(h, 2, st, sd); h->gws_cur = h->gws2;
+    }
+    r = bwd_rec_deferred(h, sd); if (r) return r;
+    h->gws_cur = h->gws;
+    // total = dec_loss + lambda_recon * rec_loss (both parts are final here)
+    hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 5, h->c.lambda_recon, h->scal + 6);
   }
-  return bwd_decoder(h, enc, targets, dh, 1.0f, st);
+  r = dec_bwd_chain(h, dh, st); if (r) return r;
+  r = dec_bwd_deferred(h, enc, targets, st); if (r) return r;
+  if (par) join_from(h, 3, st, sd);
+  h->fwd_dec_done = 0;
+  return RECNET_OK;
 }
 
 int recnet_train_step_fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,

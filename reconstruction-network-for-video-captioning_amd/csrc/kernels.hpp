@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
 struct DecCellBwdArgs {
   int t, B, F, H, A, S;
   const float* slab;     // [S][B][H] or nullptr (t == T-1)
-  const float* dHs;      // [B][H] direct gradient of h_t (vocabulary projection + reconstructor)
+  const float* dHs;      // [B][H] direct gradient of h_t from the vocabulary projection
+  const float* dHs2;     // [B][H] direct gradient of h_t from the reconstructor, or nullptr
   const float* acts; const float* c; const float* c_prev;
   const float* dc_in; float* dc_out; int first;
   void* dGx; int ld_dgx;   // [B][ld_dgx] AT
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   for (int u = tid; u < H; u += 256) {
     const size_t o = (size_t)b * H + u;
     float dh = p.dHs[o];
+    if (p.dHs2) dh += p.dHs2[o];
     if (p.slab) dh += sum_strided(p.slab + o, zs, p.S);
     const float* a = p.acts + (size_t)b * W4 + u;
     const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_in[o], a[0], a[H], a[2 * H], a[3 * H], p.c[o],
