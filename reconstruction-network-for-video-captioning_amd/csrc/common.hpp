@@ -62,6 +62,13 @@ __device__ __forceinline__ float block_max256(float v, float* sm) {
   return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
-__device__ __forceinline__ float rn_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// tanh with full fp32 accuracy (tanhf is accurate; __expf-based forms lose bits near 0)
-__device__ __forceinline__ float rn_tanh(float x) { return tanhf(x); }
+// Transcendentals.  The recurrent-step kernels are VALU-issue bound on tanh / sigmoid (libm tanhf is ~80
+// instructions); these forms are one v_exp_f32 + one v_rcp_f32 (~12 instructions) with absolute error
+// <= 3e-7, far inside the fp32-path parity bar (2e-5 on hidden states).
+__device__ __forceinline__ float rn_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float rn_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float rn_tanh(float x) {
+  const float t = __expf(-2.0f * fabsf(x));
+  const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  return copysignf(r, x);
+}

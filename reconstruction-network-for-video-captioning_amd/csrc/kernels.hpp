@@ -40,6 +40,20 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
 
+template <typename AT> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void zero() { for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f; }
+  __device__ __forceinline__ float at(int j) const { return (float)v[j]; }
+};
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+  __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+  __device__ __forceinline__ float at(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
+
 __device__ __forceinline__ uint32_t drop_key(const DropDesc& dd) { return rn_site_key(*dd.seed, dd.site); }
 __device__ __forceinline__ float drop_at(const DropDesc& dd, uint32_t key, int t, int b, int N, int j) {
   const uint32_t idx = ((uint32_t)t * (uint32_t)dd.Bg + (uint32_t)(dd.boff + b)) * (uint32_t)N + (uint32_t)j;
@@ -130,18 +144,18 @@ __global__ void copy_kernel(const float* __restrict__ x, float* __restrict__ y, 
 struct LstmOut { float i, f, g, o, c, h; };
 __device__ __forceinline__ LstmOut lstm_point(float gi, float gf, float gg, float go, float c_prev) {
   LstmOut r;
-  r.i = 1.0f / (1.0f + expf(-gi));
-  r.f = 1.0f / (1.0f + expf(-gf));
-  r.g = tanhf(gg);
-  r.o = 1.0f / (1.0f + expf(-go));
+  r.i = rn_sigmoid(gi);
+  r.f = rn_sigmoid(gf);
+  r.g = rn_tanh(gg);
+  r.o = rn_sigmoid(go);
   r.c = r.f * c_prev + r.i * r.g;
-  r.h = r.o * tanhf(r.c);
+  r.h = r.o * rn_tanh(r.c);
   return r;
 }
 struct LstmGrad { float di, df, dg, d_o, dc_prev; };
 __device__ __forceinline__ LstmGrad lstm_point_bwd(float dh, float dc_in, float i, float f, float g, float o,
                                                    float c, float c_prev) {
-  const float tc = tanhf(c);
+  const float tc = rn_tanh(c);
   const float dc = dc_in + dh * o * (1.f - tc * tc);
   LstmGrad r;
   r.d_o = dh * tc * o * (1.f - o);
@@ -221,15 +235,37 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
   const int b = blockIdx.x, u0 = blockIdx.y * RN_UC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
   const size_t zs = (size_t)p.B * WS;
-  // issue the loads that do not depend on the attention scores first (gate pre-activations, P column)
-  const int g = wave, u = u0 + lane;          // one wave per gate, one lane per hidden unit of the chunk
+  // ---- every global load of the kernel is issued up front (the kernel is one link of a dependent chain and
+  // runs at ~3 waves per SIMD, so exposed memory latency, not bandwidth, is what it costs)
+  const int g = wave, u = u0 + lane;          // gate phase: one wave per gate, one lane per hidden unit of the chunk
   float pre = 0.f;
+  float pv[32];                               // P[b, f, col] for f < min(F, 32)
+#pragma unroll
+  for (int f = 0; f < 32; ++f) pv[f] = 0.f;
   const AT* pp = nullptr;
   if (u < H) {
     const int col = g * H + u;
+    pp = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp + col;
+#pragma unroll
+    for (int f = 0; f < 32; ++f) if (f < F) pv[f] = (float)pp[(size_t)f * p.ldp];
     pre = p.Xe[(size_t)b * W4 + col];
     if (p.slab) pre += sum_strided(p.slab + (size_t)b * WS + col, zs, p.S);
-    pp = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp + col;
+  }
+  float cprev = 0.f;
+  if (tid < RN_UC && u0 + tid < H && p.c_prev) cprev = p.c_prev[(size_t)b * H + u0 + tid];
+  // score phase operands: wave w handles frames w, w+4, ...; lane handles k = lane, lane + 64, ... (A <= 128 fast path)
+  float uvr[8][2];
+  const bool fastA = (A <= 128) && (F <= 32);
+  if (fastA) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = wave + 4 * i;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = lane + 64 * j;
+        uvr[i][j] = (f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+      }
+    }
   }
   for (int k = tid; k < A; k += 256) {
     const float v = p.slab ? sum_strided(p.slab + (size_t)b * WS + W4 + k, zs, p.S) : 0.f;
@@ -237,32 +273,49 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
     if (p.Wh_out && blockIdx.y == 0) p.Wh_out[(size_t)b * A + k] = v;
   }
   __syncthreads();
-  for (int f = wave; f < F; f += 4) {
-    const float* uv = p.Uv + ((size_t)b * F + f) * A;
-    float s = 0.f;
-    for (int k = lane; k < A; k += 64) s += p.w[k] * tanhf(swh[k] + uv[k] + p.ab[k]);
-    s = wave_sum(s);
-    if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+  if (fastA) {
+    float wk[2], bk[2], hk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = lane + 64 * j;
+      wk[j] = k < A ? p.w[k] : 0.f; bk[j] = k < A ? p.ab[k] : 0.f; hk[j] = k < A ? swh[k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = wave + 4 * i;
+      if (f < F) {
+        float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
+        if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
+        s = wave_sum(s);
+        if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+      }
+    }
+  } else {
+    for (int f = wave; f < F; f += 4) {
+      const float* uv = p.Uv + ((size_t)b * F + f) * A;
+      float s = 0.f;
+      for (int k = lane; k < A; k += 64) s += p.w[k] * rn_tanh(swh[k] + uv[k] + p.ab[k]);
+      s = wave_sum(s);
+      if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+    }
   }
   __syncthreads();
   if (u < H) {
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-    int f = 0;
-    for (; f + 4 <= F; f += 4) {
-      const float v0 = (float)pp[(size_t)f * p.ldp], v1 = (float)pp[(size_t)(f + 1) * p.ldp],
-                  v2 = (float)pp[(size_t)(f + 2) * p.ldp], v3 = (float)pp[(size_t)(f + 3) * p.ldp];
-      c0 += sa[f] * v0; c1 += sa[f + 1] * v1; c2 += sa[f + 2] * v2; c3 += sa[f + 3] * v3;
+    float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+    for (int f = 0; f < 32; f += 2) {
+      if (f < F) c0 += sa[f] * pv[f];
+      if (f + 1 < F) c1 += sa[f + 1] * pv[f + 1];
     }
-    for (; f < F; ++f) c0 += sa[f] * (float)pp[(size_t)f * p.ldp];
-    pre += ((c0 + c1) + (c2 + c3)) * (1.0f / (float)F);
+    for (int f = 32; f < F; ++f) c0 += sa[f] * (float)pp[(size_t)f * p.ldp];
+    pre += (c0 + c1) * (1.0f / (float)F);
   }
   spre[g * RN_UC + lane] = pre;
   __syncthreads();
   if (tid < RN_UC && u0 + tid < H) {
     const int uu = u0 + tid;
     const size_t o = (size_t)b * H + uu;
-    const LstmOut r = lstm_point(spre[tid], spre[RN_UC + tid], spre[2 * RN_UC + tid], spre[3 * RN_UC + tid],
-                                 p.c_prev ? p.c_prev[o] : 0.f);
+    const LstmOut r = lstm_point(spre[tid], spre[RN_UC + tid], spre[2 * RN_UC + tid], spre[3 * RN_UC + tid], cprev);
     p.h_out[o] = r.h;
     p.c_out[o] = r.c;
     if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)r.h;
@@ -312,6 +365,36 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   const int H = p.H, A = p.A, F = p.F, W4 = 4 * H;
   const size_t zs = (size_t)p.B * H;
   AT* dgx = reinterpret_cast<AT*>(p.dGx) + (size_t)b * p.ld_dgx;
+  const AT* Pb = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp;
+  const int nf = (F - ch + RN_FCH - 1) / RN_FCH;          // frames of this chunk: f = ch, ch + RN_FCH, ...
+  const int G = (A <= 256) ? 256 / A : 1;
+  // ---- loads that do not depend on this kernel's own results are issued first (P rows of the wave's frames,
+  // Uv / dUv of the thread's (f, k) cells); fast path: 4H <= 2048 (multiple of 8), <= 8 frames per chunk, A <= 256
+  const bool fast = ((W4 & 7) == 0) && W4 <= 2048 && nf <= 8 && A <= 256 && nf <= 4 * G;
+  Raw8<AT> pr[2][4];
+  float uvr[4], duvr[4];
+  const int kk = (A <= 256) ? tid % A : 0, gi = (A <= 256) ? tid / A : 0;
+  if (fast) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = wave + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = (lane + 64 * j) * 8;
+        if (i < nf && n < W4) pr[q][j].load(Pb + (size_t)(ch + i * RN_FCH) * p.ldp + n); else pr[q][j].zero();
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = gi + q * G;
+      uvr[q] = 0.f; duvr[q] = 0.f;
+      if (gi < G && i < nf) {
+        const size_t o = ((size_t)b * F + ch + i * RN_FCH) * A + kk;
+        uvr[q] = p.Uv[o];
+        if (!p.first) duvr[q] = p.dUv[o];
+      }
+    }
+  }
   for (int u = tid; u < H; u += 256) {
     const size_t o = (size_t)b * H + u;
     float dh = p.dHs[o];
@@ -328,62 +411,92 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   }
   if (ch == 0) for (int j = W4 + RN_FCH * A + tid; j < p.ld_dgx; j += 256) dgx[j] = (AT)0.f;   // pad
   __syncthreads();
-  // frames of this chunk: f = ch, ch + RN_FCH, ...
   const float invF = 1.0f / (float)F;
-  const AT* Pb = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp;
-  const int nf = (F - ch + RN_FCH - 1) / RN_FCH;          // frames in this chunk
-  for (int i = wave; i < nf; i += 4) {
-    const int f = ch + i * RN_FCH;
-    const AT* pp = Pb + (size_t)f * p.ldp;
-    float s = 0.f;
-    if ((W4 & 7) == 0) {
-      float s1 = 0.f;
-      for (int n = lane * 8; n < W4; n += 512) {
-        float v[8];
-        load8(pp + n, v);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sdg + n), g1 = *reinterpret_cast<const f32x4*>(sdg + n + 4);
-        s += g0[0] * v[0] + g0[1] * v[1] + g0[2] * v[2] + g0[3] * v[3];
-        s1 += g1[0] * v[4] + g1[1] * v[5] + g1[2] * v[6] + g1[3] * v[7];
+  if (fast) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = wave + 4 * q;
+      if (i < nf) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = (lane + 64 * j) * 8;
+          if (n < W4) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(sdg + n), g1 = *reinterpret_cast<const f32x4*>(sdg + n + 4);
+            s0 += g0[0] * pr[q][j].at(0) + g0[1] * pr[q][j].at(1) + g0[2] * pr[q][j].at(2) + g0[3] * pr[q][j].at(3);
+            s1 += g1[0] * pr[q][j].at(4) + g1[1] * pr[q][j].at(5) + g1[2] * pr[q][j].at(6) + g1[3] * pr[q][j].at(7);
+          }
+        }
+        const float s = wave_sum(s0 + s1);
+        if (lane == 0) sda[ch + i * RN_FCH] = s * invF;
       }
-      s += s1;
-    } else {
-      for (int n = lane; n < W4; n += 64) s += sdg[n] * (float)pp[n];
     }
-    s = wave_sum(s);
-    if (lane == 0) sda[f] = s * invF;
+  } else {
+    for (int i = wave; i < nf; i += 4) {
+      const int f = ch + i * RN_FCH;
+      const AT* pp = Pb + (size_t)f * p.ldp;
+      float s = 0.f;
+      for (int n = lane; n < W4; n += 64) s += sdg[n] * (float)pp[n];
+      s = wave_sum(s);
+      if (lane == 0) sda[f] = s * invF;
+    }
   }
   __syncthreads();
   // (f, k) plane: thread -> k = tid % A, frame group gi = tid / A (A <= 256), else one thread per k
-  const int G = (A <= 256) ? 256 / A : 1;
-  auto fk = [&](int kk, int gi) {
-    const float whk = p.Wh[(size_t)b * A + kk] + p.ab[kk];
-    const float wk = p.w[kk];
-    float dwh = 0.f, dw = 0.f;
-    for (int i = gi; i < nf; i += G) {
-      const int f = ch + i * RN_FCH;
-      const size_t o = ((size_t)b * F + f) * A + kk;
-      const float tz = tanhf(whk + p.Uv[o]);
-      const float ds = sda[f] * wk * (1.f - tz * tz);
-      dw += sda[f] * tz;
-      dwh += ds;
-      const float nv = p.first ? ds : p.dUv[o] + ds;
-      p.dUv[o] = nv;
-      if (p.last) reinterpret_cast<AT*>(p.dUv_lp)[((size_t)b * F + f) * p.ld_dUv + kk] = (AT)nv;
+  if (fast) {
+    if (gi < G) {
+      const float whk = p.Wh[(size_t)b * A + kk] + p.ab[kk];
+      const float wk = p.w[kk];
+      float dwh = 0.f, dw = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = gi + q * G;
+        if (i < nf) {
+          const int f = ch + i * RN_FCH;
+          const size_t o = ((size_t)b * F + f) * A + kk;
+          const float tz = rn_tanh(whk + uvr[q]);
+          const float ds = sda[f] * wk * (1.f - tz * tz);
+          dw += sda[f] * tz;
+          dwh += ds;
+          const float nv = duvr[q] + ds;
+          p.dUv[o] = nv;
+          if (p.last) reinterpret_cast<AT*>(p.dUv_lp)[((size_t)b * F + f) * p.ld_dUv + kk] = (AT)nv;
+        }
+      }
+      spart[gi * A + kk] = dwh;
+      spart[(G + gi) * A + kk] = dw;
     }
-    spart[gi * A + kk] = dwh;
-    spart[(G + gi) * A + kk] = dw;
-  };
-  if (A <= 256) {
-    if (tid < G * A) fk(tid % A, tid / A);
   } else {
-    for (int kk = tid; kk < A; kk += 256) fk(kk, 0);
+    auto fk = [&](int k2, int g2) {
+      const float whk = p.Wh[(size_t)b * A + k2] + p.ab[k2];
+      const float wk = p.w[k2];
+      float dwh = 0.f, dw = 0.f;
+      for (int i = g2; i < nf; i += G) {
+        const int f = ch + i * RN_FCH;
+        const size_t o = ((size_t)b * F + f) * A + k2;
+        const float tz = rn_tanh(whk + p.Uv[o]);
+        const float ds = sda[f] * wk * (1.f - tz * tz);
+        dw += sda[f] * tz;
+        dwh += ds;
+        const float nv = p.first ? ds : p.dUv[o] + ds;
+        p.dUv[o] = nv;
+        if (p.last) reinterpret_cast<AT*>(p.dUv_lp)[((size_t)b * F + f) * p.ld_dUv + k2] = (AT)nv;
+      }
+      spart[g2 * A + k2] = dwh;
+      spart[(G + g2) * A + k2] = dw;
+    };
+    if (A <= 256) {
+      if (tid < G * A) fk(tid % A, tid / A);
+    } else {
+      for (int k2 = tid; k2 < A; k2 += 256) fk(k2, 0);
+    }
   }
   __syncthreads();
-  for (int kk = tid; kk < A; kk += 256) {
+  for (int k2 = tid; k2 < A; k2 += 256) {
     float a = 0.f, c = 0.f;
-    for (int j = 0; j < G; ++j) { a += spart[j * A + kk]; c += spart[(G + j) * A + kk]; }
-    dgx[W4 + ch * A + kk] = (AT)a;
-    const size_t o2 = ((size_t)ch * p.B + b) * A + kk;
+    for (int j = 0; j < G; ++j) { a += spart[j * A + k2]; c += spart[(G + j) * A + k2]; }
+    dgx[W4 + ch * A + k2] = (AT)a;
+    const size_t o2 = ((size_t)ch * p.B + b) * A + k2;
     p.dwacc[o2] = p.first ? c : p.dwacc[o2] + c;
   }
   if (p.last)   // zero padding of the dUv operand copy
@@ -657,7 +770,7 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   for (int t = wave; t < p.T; t += 4) {
     const float* ud = p.Ud + ((size_t)t * p.B + b) * p.A;
     float s = 0.f;
-    for (int k = lane; k < p.A; k += 64) s += p.w[k] * tanhf(swh[k] + ud[k] + p.ab[k]);
+    for (int k = lane; k < p.A; k += 64) s += p.w[k] * rn_tanh(swh[k] + ud[k] + p.ab[k]);
     s = wave_sum(s);
     if (lane == 0) { sbeta[t] = s; p.beta_out[(size_t)b * p.T + t] = s; }
   }
@@ -734,7 +847,7 @@ __global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
       float dwh = 0.f, dw = 0.f;
       for (int t = 0; t < T; ++t) {
         const size_t o = ((size_t)t * p.B + b) * A + k;
-        const float tz = tanhf(whk + p.Ud[o]);
+        const float tz = rn_tanh(whk + p.Ud[o]);
         const float dz = sdb[t] * wk * (1.f - tz * tz);
         dw += sdb[t] * tz;
         dwh += dz;
