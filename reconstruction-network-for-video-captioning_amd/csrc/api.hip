@@ -364,7 +364,12 @@ static void gemm_to_at(recnet_handle* h, const void* A, int a_col, int lda, cons
 // recurrent-step GEMM: partial slabs only; returns the slab count the consumer must sum
 static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const void* Bm, int b_col, int ldb, int M, int N,
                       int K, hipStream_t st) {
-  int s = rn_pick_splitk(h->prec, M, N, K, 16);
+  // split-K caps per site: more slices than this buy nothing for the GEMM (measured) and every slab is re-read by
+  // the consumer kernel
+  static const int cap_env = getenv("RN_SLAB_CAP") ? atoi(getenv("RN_SLAB_CAP")) : 0;
+  int cap = (tag == RN_TAG_DEC_FWD) ? 4 : (tag == RN_TAG_DEC_BWD ? 8 : 16);
+  if (cap_env) cap = cap_env;
+  int s = rn_pick_splitk(h->prec, M, N, K, cap);
   while (s > 1 && (size_t)s * M * N > h->slab_floats) s >>= 1;
   if (s < 2) s = 2;  // always use the slab path so the consumer code is uniform
   s = rn_effective_splitk(h->prec, K, s);
@@ -456,10 +461,14 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
   return RECNET_OK;
 }
 
-static size_t dec_cell_smem(const recnet_handle* h) { return (size_t)(h->A + h->F + 4 * RN_UC + 16) * 4; }
 static void launch_dec_cell(recnet_handle* h, const DecCellArgs& a, hipStream_t st) {
-  dim3 grid(h->B, cdiv(h->H, RN_UC));
-  LAUNCH_AT(h, dec_cell_kernel, grid, dim3(256), dec_cell_smem(h), st, a);
+  // units per workgroup: 256 (1024 threads) when H allows, so a caption is covered by H/256 workgroups
+  int uc = h->H >= 256 ? 256 : (h->H >= 128 ? 128 : 64);
+  static const char* e = getenv("RN_DEC_UC");
+  if (e) uc = atoi(e);
+  dim3 grid(h->B, cdiv(h->H, uc));
+  const size_t sm = (size_t)(h->A + h->F + 4 * uc + 16) * 4;
+  LAUNCH_AT(h, dec_cell_kernel, grid, dim3(4 * uc), sm, st, a);
 }
 // loop-invariant products of the decoder: Uv = enc . U^T (decoder.py:54) and P = enc . W_ih[:, E:]^T
 static void dec_invariants(recnet_handle* h, const float* enc, hipStream_t st) {

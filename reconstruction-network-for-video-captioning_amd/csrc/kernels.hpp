@@ -17,9 +17,25 @@ __global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t
   int s = *step + 1; *step = s; *seed_slot = seed_base + (uint32_t)s;
 }
 
-// sum_{z<n} p[z*stride] with four independent accumulators: the loads are issued back to back instead of
-// one per add (these kernels run at low occupancy, so instruction-level parallelism hides the L2 latency)
+// sum_{z<n} p[z*stride] over the split-K slabs.  All (<= 16) loads are issued back to back and reduced as a
+// tree: a dependent round trip to L2 / memory costs ~1-3 us in these low-occupancy chain kernels, so the
+// number of serialized load rounds, not bytes, sets their run time (PMC: SQ_WAIT_ANY ~75 % of wave cycles).
 __device__ __forceinline__ float sum_strided(const float* __restrict__ p, size_t stride, int n) {
+  if (n <= 16) {
+    float v[16];
+#pragma unroll
+    for (int z = 0; z < 16; ++z) {
+      const int zz = z < n ? z : n - 1;                 // clamped: branch-free, the duplicates hit L1
+      v[z] = p[(size_t)zz * stride];
+    }
+#pragma unroll
+    for (int z = 0; z < 16; ++z) v[z] = z < n ? v[z] : 0.f;
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int z = 0; z < w; ++z) v[z] += v[z + w];
+    return v[0];
+  }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int z = 0;
   for (; z + 4 <= n; z += 4) {
@@ -207,9 +223,11 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb
 //   a[f] = w . tanh(Wh + Uv[b,f] + b)                        one wave per frame, wavefront reduction
 //   gates[col] = Xe[t,b,col] + h.W_hh^T (slabs) + (1/F) sum_f a[f] P[b,f,col]   for the chunk's 4 x 64 columns
 //   LSTM pointwise -> h_t (fp32 + operand copy), c_t, saved activations
+// Workgroup = 4 gates x UC units (UC = blockDim.x / 4, 64..256): big workgroups keep the per-caption score work and
+// the Uv / slab re-reads (the kernel is bound by bytes pulled from the memory side) to 2 per caption.
 // AT = operand type of the GEMM inputs this kernel reads / writes (bf16 in the bf16 path, float in the exact path).
 // =============================================================================================
-#define RN_UC 64
+#define RN_UC_MAX 256       // hidden units per workgroup = blockDim.x / 4 (one thread per gate per unit)
 struct DecCellArgs {
   int t, B, F, H, A, S;
   const float* slab;      // [S][B][4H+A] split-K partials of h_{t-1} . [W_hh ; W]^T, nullptr when h_{t-1} = 0
@@ -227,17 +245,18 @@ struct DecCellArgs {
 };
 
 template <typename AT>
-__global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
+__global__ __launch_bounds__(1024) void dec_cell_kernel(const DecCellArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* swh = smem;            // [A]
   float* sa = swh + p.A;        // [F]
-  float* spre = sa + p.F;       // [4 * RN_UC]
-  const int b = blockIdx.x, u0 = blockIdx.y * RN_UC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* spre = sa + p.F;       // [4 * UC]
+  const int NT = blockDim.x, UC = NT >> 2, NW = NT >> 6;
+  const int b = blockIdx.x, u0 = blockIdx.y * UC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
   const size_t zs = (size_t)p.B * WS;
   // ---- every global load of the kernel is issued up front (the kernel is one link of a dependent chain and
   // runs at ~3 waves per SIMD, so exposed memory latency, not bandwidth, is what it costs)
-  const int g = wave, u = u0 + lane;          // gate phase: one wave per gate, one lane per hidden unit of the chunk
+  const int g = tid / UC, ul = tid % UC, u = u0 + ul;   // gate phase: thread = (gate, hidden unit of the chunk)
   float pre = 0.f;
   float pv[32];                               // P[b, f, col] for f < min(F, 32)
 #pragma unroll
@@ -252,14 +271,14 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
     if (p.slab) pre += sum_strided(p.slab + (size_t)b * WS + col, zs, p.S);
   }
   float cprev = 0.f;
-  if (tid < RN_UC && u0 + tid < H && p.c_prev) cprev = p.c_prev[(size_t)b * H + u0 + tid];
-  // score phase operands: wave w handles frames w, w+4, ...; lane handles k = lane, lane + 64, ... (A <= 128 fast path)
+  if (tid < UC && u0 + tid < H && p.c_prev) cprev = p.c_prev[(size_t)b * H + u0 + tid];
+  // score phase operands: wave w handles frames w, w+NW, ...; lane handles k = lane, lane + 64 (A <= 128 fast path)
   float uvr[8][2];
-  const bool fastA = (A <= 128) && (F <= 32);
+  const bool fastA = (A <= 128) && (F <= 8 * NW);
   if (fastA) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int f = wave + 4 * i;
+      const int f = wave + NW * i;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int k = lane + 64 * j;
@@ -267,7 +286,7 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
       }
     }
   }
-  for (int k = tid; k < A; k += 256) {
+  for (int k = tid; k < A; k += NT) {
     const float v = p.slab ? sum_strided(p.slab + (size_t)b * WS + W4 + k, zs, p.S) : 0.f;
     swh[k] = v;
     if (p.Wh_out && blockIdx.y == 0) p.Wh_out[(size_t)b * A + k] = v;
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int f = wave + 4 * i;
+      const int f = wave + NW * i;
       if (f < F) {
         float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
         if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
@@ -291,7 +310,7 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
       }
     }
   } else {
-    for (int f = wave; f < F; f += 4) {
+    for (int f = wave; f < F; f += NW) {
       const float* uv = p.Uv + ((size_t)b * F + f) * A;
       float s = 0.f;
       for (int k = lane; k < A; k += 64) s += p.w[k] * rn_tanh(swh[k] + uv[k] + p.ab[k]);
@@ -310,12 +329,12 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
     for (int f = 32; f < F; ++f) c0 += sa[f] * (float)pp[(size_t)f * p.ldp];
     pre += (c0 + c1) * (1.0f / (float)F);
   }
-  spre[g * RN_UC + lane] = pre;
+  spre[g * UC + ul] = pre;
   __syncthreads();
-  if (tid < RN_UC && u0 + tid < H) {
+  if (tid < UC && u0 + tid < H) {
     const int uu = u0 + tid;
     const size_t o = (size_t)b * H + uu;
-    const LstmOut r = lstm_point(spre[tid], spre[RN_UC + tid], spre[2 * RN_UC + tid], spre[3 * RN_UC + tid], cprev);
+    const LstmOut r = lstm_point(spre[tid], spre[UC + tid], spre[2 * UC + tid], spre[3 * UC + tid], cprev);
     p.h_out[o] = r.h;
     p.c_out[o] = r.c;
     if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)r.h;
@@ -326,7 +345,7 @@ __global__ __launch_bounds__(256) void dec_cell_kernel(const DecCellArgs p) {
   }
   // zero padding of the operand copy (columns [H, ld_hlp)), once per row
   if (p.h_lp && blockIdx.y == 0)
-    for (int j = H + tid; j < p.ld_hlp; j += 256) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + j] = (AT)0.f;
+    for (int j = H + tid; j < p.ld_hlp; j += NT) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + j] = (AT)0.f;
 }
 
 // =============================================================================================
