@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--batch", type=int, default=100, help="captions per GPU")
     ap.add_argument("--rec", default="global", choices=["global", "local", "none"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--frames", type=int, default=28, help="encoder_output_len F (C4: 40)")
+    ap.add_argument("--feat", type=int, default=1536, help="encoder_output_size D = reconstructor size (C4: 2048, C5: 3584)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
@@ -97,9 +99,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B, F, D, V = args.batch, 28, 1536, 4188
+    B, F, D, V = args.batch, args.frames, args.feat, 4188
     kind = None if args.rec == "none" else args.rec
     C, dec, rec = build_models(R, dict(batch_size=B, use_recon=kind is not None, reconstructor_type=kind or "global",
+                                       encoder_output_len=F, encoder_output_size=D, reconstructor_hidden_size=D,
                                        precision=args.precision, device=str(dev)), V)
     Bg = B * world
     targets_g = synthetic_targets(Bg, V, seed=1234)
@@ -142,8 +145,8 @@ def main():
             "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=28, "
-                                   "D=R=1536, V=4188, E=468, H=512, A=128, T=31, dropout 0.5" % (args.rec, B),
+            "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
+                                   "D=R=%d, V=4188, E=468, H=512, A=128, T=31, dropout 0.5" % (args.rec, B, F, D),
                        "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph),
                        "loss": round(sc["total_loss"], 5)},
             "roofline": prof,
