@@ -46,6 +46,7 @@ struct recnet_handle {
   uint32_t* ctrl;        // [0] seed slot, [1] step slot (int32)
   float* scal;           // [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
   // ---- decoder: fp32 state
+  float *slab2 = nullptr;   // second slab buffer (local reconstructor backward: dWhr . W_r)
   float *bsum_d, *Uv, *Xe, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws, *dHs, *dHsrec, *dc_carry, *dUv,
       *dwacc, *demb, *stepw, *msep;
   // ---- decoder: operand copies (AT = bf16 | float)
@@ -152,6 +153,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->Xcat_r = takev(F * B * ldHR); h->Hr_lp = takev(F * B * ldR); h->dout_lp = takev(F * B * ldR);
     h->dGr = takev(F * B * ld4R); h->dUd_lp = takev(Tm * B * ldRA); h->dWhr = takev(F * B * ldRA);
     h->Ur_w = takev(RA * ldH); h->Wr_w = takev(RA * ldR); h->Wihh_w = takev(4 * R * ldHR);
+    h->slab2 = take(16 * B * R);
   }
   // optimiser tables (sizes are upper bounds; filled at bind time)
   for (int g = 0; g < 2; ++g) {
@@ -363,11 +365,13 @@ static void gemm_to_at(recnet_handle* h, const void* A, int a_col, int lda, cons
 }
 // recurrent-step GEMM: partial slabs only; returns the slab count the consumer must sum
 static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const void* Bm, int b_col, int ldb, int M, int N,
-                      int K, hipStream_t st) {
+                      int K, hipStream_t st, float* dst = nullptr) {
+  float* slab = dst ? dst : h->slab;
   // split-K caps per site: more slices than this buy nothing for the GEMM (measured) and every slab is re-read by
   // the consumer kernel
   static const int cap_env = getenv("RN_SLAB_CAP") ? atoi(getenv("RN_SLAB_CAP")) : 0;
   int cap = (tag == RN_TAG_DEC_FWD) ? 4 : (tag == RN_TAG_DEC_BWD ? 8 : 16);
+  if (dst) cap = 8;
   if (cap_env) cap = cap_env;
   int s = rn_pick_splitk(h->prec, M, N, K, cap);
   while (s > 1 && (size_t)s * M * N > h->slab_floats) s >>= 1;
@@ -383,10 +387,10 @@ static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const v
     hipEventRecord(e0, st);
   }
   if (s < 2) {   // K fits one tile: the single product goes to slab 0 through the direct epilogue
-    rn_launch_gemm(h->prec, A, h->lp, 0, lda, Bm, h->lp, b_col, ldb, h->slab, N, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0, st, tag);
+    rn_launch_gemm(h->prec, A, h->lp, 0, lda, Bm, h->lp, b_col, ldb, slab, N, nullptr, M, N, K, 1.f, 0, 1, nullptr, 0, st, tag);
     s = 1;
   } else {
-    rn_launch_gemm(h->prec, A, h->lp, 0, lda, Bm, h->lp, b_col, ldb, nullptr, N, nullptr, M, N, K, 1.f, 0, s, h->slab, 0, st, tag);
+    rn_launch_gemm(h->prec, A, h->lp, 0, lda, Bm, h->lp, b_col, ldb, nullptr, N, nullptr, M, N, K, 1.f, 0, s, slab, 0, st, tag);
   }
   if (e1) hipEventRecord(e1, st);
   return s;
@@ -682,10 +686,11 @@ static int fwd_rec_global(recnet_handle* h, const float* enc, int T, int train, 
 
 static void lstm_bwd(recnet_handle* h, int Hd, int S, int slab_ld, int slab_col0, const float* dh_direct, int dhd_ld,
                      float dh_scale, const float* acts, const float* c, const float* c_prev, float* dc_carry, int first,
-                     void* dG, int ld_dg, hipStream_t st) {
+                     void* dG, int ld_dg, hipStream_t st, const float* slab2 = nullptr, int S2 = 0) {
   LstmBwdArgs p;
   p.B = h->B; p.Hd = Hd; p.S = S; p.dh_direct = dh_direct; p.dhd_ld = dhd_ld; p.dh_scale = dh_scale;
   p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld; p.slab_col0 = slab_col0;
+  p.slab2 = slab2; p.slab2_stride = (size_t)h->B * Hd; p.S2 = S2;
   p.acts = acts; p.c = c; p.c_prev = c_prev; p.dc_carry = dc_carry; p.first = first; p.dG = dG; p.ld_dg = ld_dg;
   LAUNCH_AT(h, lstm_bwd_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
 }
@@ -771,27 +776,25 @@ static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStr
   gemm(h, h->dout_lp, 0, h->ldR, h->Wor_w, 1, h->ldR, h->dHr, R, nullptr, FB, R, R, 1.f, 0, st);
   LocBwdArgs a;
   a.B = B; a.T = T; a.H = H; a.R = R; a.A = RA;
-  a.Hs = h->Hs; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight; a.Wr = h->rP.attn_W_weight;
-  a.dHs = dhid_out; a.dUd = h->dUd; a.dwacc = h->dwacc_r; a.dc_carry = h->dcr_carry; a.slab = h->slab;
-  a.ld_dwhr = h->ldRA; a.dUd_lp = h->dUd_lp; a.ld_dUd = h->ldRA; a.ld_dg = ld4R;
+  a.Hs = h->Hs; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight;
+  a.dHs = dhid_out; a.dUd = h->dUd; a.dwacc = h->dwacc_r; a.slab = h->slab;
+  a.ld_dwhr = h->ldRA; a.dUd_lp = h->dUd_lp; a.ld_dUd = h->ldRA;
   a.dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
-  const size_t sm = (size_t)(H + R + T + RA + 16) * 4;
-  int S = 0;
-  for (int s = F; s >= 0; --s) {
-    a.s = s; a.S = S; a.do_attn = s < F; a.do_lstm = s > 0;
-    a.first_attn = (s == F - 1); a.first_lstm = (s == F); a.prop_hr = s > 0; a.last = (s == 0);
-    a.Whr = s < F ? h->Whr + (size_t)s * B * RA : nullptr;
-    a.beta = s < F ? h->beta + (size_t)s * B * T : nullptr;
-    a.dWhr = s < F ? at_off(h, h->dWhr, (size_t)s * B * h->ldRA) : nullptr;
-    if (s > 0) {
-      a.dHr = h->dHr + (size_t)(s - 1) * B * R;
-      a.acts = h->acts_r + (size_t)(s - 1) * B * 4 * R;
-      a.c = h->Cr + (size_t)(s - 1) * B * R;
-      a.c_prev = s > 1 ? h->Cr + (size_t)(s - 2) * B * R : nullptr;
-      a.dG = at_off(h, h->dGr, (size_t)(s - 1) * B * ld4R);
-    }
-    LAUNCH_AT(h, loc_bwd_step_kernel, dim3(B), dim3(256), sm, st, a);
-    if (s > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)(s - 1) * B * ld4R), ld4R, h->Wihh_w, 1, ldHR, B, H + R, 4 * R, st);
+  const int Asz = RA <= 256 ? 256 : RA;
+  const size_t sm = (size_t)(H + 2 * T + 2 * Asz + 16) * 4;
+  // per step: LSTM backward -> GEMM dGr_s . [W_ih | W_hh] -> attention backward -> GEMM dWhr_s . W_r
+  int S1 = 0, S2 = 0;
+  for (int s = F - 1; s >= 0; --s) {
+    lstm_bwd(h, R, S1, H + R, H, h->dHr + (size_t)s * B * R, R, 1.0f, h->acts_r + (size_t)s * B * 4 * R, h->Cr + (size_t)s * B * R,
+             s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->dcr_carry, s == F - 1, at_off(h, h->dGr, (size_t)s * B * ld4R), ld4R, st,
+             h->slab2, S2);
+    S1 = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)s * B * ld4R), ld4R, h->Wihh_w, 1, ldHR, B, H + R, 4 * R, st);
+    a.s = s; a.S = S1; a.first = (s == F - 1); a.last = (s == 0);
+    a.Whr = h->Whr + (size_t)s * B * RA; a.beta = h->beta + (size_t)s * B * T;
+    a.dWhr = at_off(h, h->dWhr, (size_t)s * B * h->ldRA);
+    LAUNCH_AT(h, loc_attn_bwd_kernel, dim3(B), dim3(256), sm, st, a);
+    if (s > 0)   // d hr_{s-1} (attention path) = dWhr_s . W_r
+      S2 = gemm_slabs(h, RN_TAG_REC_ATT_BWD, at_off(h, h->dWhr, (size_t)s * B * h->ldRA), h->ldRA, h->Wr_w, 1, h->ldR, B, R, RA, st, h->slab2);
   }
   gemm(h, h->dUd_lp, 0, h->ldRA, h->Ur_w, 1, h->ldH, dhid_out, H, nullptr, TB, H, RA, 1.f, 1, st);
   return RECNET_OK;

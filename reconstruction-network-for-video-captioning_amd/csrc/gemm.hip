@@ -14,6 +14,7 @@ void launch_layout(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream
     case RN_TAG_REC_FWD: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false, RN_TAG_REC_FWD>), grid, dim3(256), 0, st, a); return;
     case RN_TAG_REC_BWD: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true, RN_TAG_REC_BWD>), grid, dim3(256), 0, st, a); return;
     case RN_TAG_REC_ATT: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false, RN_TAG_REC_ATT>), grid, dim3(256), 0, st, a); return;
+    case RN_TAG_REC_ATT_BWD: hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, true, RN_TAG_REC_ATT_BWD>), grid, dim3(256), 0, st, a); return;
     default: break;
   }
   if (!a_col && !b_col) hipLaunchKernelGGL((gemm_kernel<CT, TA, TB, false, false, 0>), grid, dim3(256), 0, st, a);
@@ -36,6 +37,7 @@ void launch_lds(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream_t 
     case RN_TAG_REC_FWD: launch_lds_one<false, false, NS, RN_TAG_REC_FWD>(a, grid, st); return;
     case RN_TAG_REC_BWD: launch_lds_one<false, true, NS, RN_TAG_REC_BWD>(a, grid, st); return;
     case RN_TAG_REC_ATT: launch_lds_one<false, false, NS, RN_TAG_REC_ATT>(a, grid, st); return;
+    case RN_TAG_REC_ATT_BWD: launch_lds_one<false, true, NS, RN_TAG_REC_ATT_BWD>(a, grid, st); return;
     default: break;
   }
   if (!a_col && !b_col) launch_lds_one<false, false, NS, 0>(a, grid, st);

@@ -612,6 +612,7 @@ struct LstmBwdArgs {
   int B, Hd, S;
   const float* dh_direct; int dhd_ld; float dh_scale;    // optional [B][dhd_ld]
   const float* slab; size_t slab_stride; int slab_ld; int slab_col0;   // recurrent part: sum_z slab[z][b][col0+u]
+  const float* slab2; size_t slab2_stride; int S2;                     // optional second product [S2][B][Hd]
   const float* acts; const float* c; const float* c_prev;
   float* dc_carry; int first;
   void* dG; int ld_dg;                                    // [B][ld_dg] AT, gate columns [0,4Hd), zero padded
@@ -623,6 +624,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs p) {
   const int b = i / p.Hd, u = i % p.Hd, Hd = p.Hd;
   float dh = p.dh_direct ? p.dh_scale * p.dh_direct[(size_t)b * p.dhd_ld + u] : 0.f;
   if (p.S) dh += sum_strided(p.slab + (size_t)b * p.slab_ld + p.slab_col0 + u, p.slab_stride, p.S);
+  if (p.S2) dh += sum_strided(p.slab2 + (size_t)b * Hd + u, p.slab2_stride, p.S2);
   const size_t o = (size_t)b * Hd + u;
   const float* a = p.acts + (size_t)b * 4 * Hd + u;
   const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_carry[o], a[0], a[Hd], a[2 * Hd], a[3 * Hd], p.c[o],
@@ -804,109 +806,99 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   }
 }
 
+// Attention backward of reconstructor step s, one workgroup per caption.  dx_s comes from the x columns of
+// dGr_s . [W_ih | W_hh] (split-K slabs); outputs: dHs += (1/T) beta dx, dUd += dz, dWhr_s (operand of the next small
+// GEMM dWhr_s . W_r and of the deferred dW_r), dw accumulator.
 struct LocBwdArgs {
   int s, B, T, H, R, A, S;
-  int do_attn, do_lstm;
-  const float* slab;      // [S][B][H+R] = dGr_s . [W_ih | W_hh]
-  const float* Hs; const float* Ud; const float* ab; const float* w; const float* Wr;  // Wr [A][R] fp32
+  const float* slab;      // [S][B][H+R]
+  const float* Hs; const float* Ud; const float* ab; const float* w;
   const float* Whr;       // [B][A] of step s
   const float* beta;      // [B][T] of step s
   float* dHs;             // [T][B][H] accumulated over s
   float* dUd;             // [T][B][A] accumulated over s
-  void* dWhr; int ld_dwhr;   // AT [B][ld] of step s (operand of the deferred dW_r GEMM)
+  void* dWhr; int ld_dwhr;   // AT [B][ld] of step s
   float* dwacc;           // [B][A]
-  int first_attn;
-  int prop_hr;            // s > 0: propagate dWhr . W_r into hr_{s-1}
+  int first;
   void* dUd_lp; int ld_dUd; int last;   // at s == 0 also emit the AT copy of dUd
   DropDesc dd;
-  // LSTM backward of step s-1
-  const float* dHr;       // [B][R] direct gradient of hr_{s-1}
-  const float* acts; const float* c; const float* c_prev;
-  float* dc_carry; int first_lstm;
-  void* dG; int ld_dg;    // AT [B][ld_dg]
 };
 template <typename AT>
-__global__ __launch_bounds__(256) void loc_bwd_step_kernel(const LocBwdArgs p) {
+__global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sdx = smem;            // [H]
-  float* sdh = sdx + p.H;       // [R]
-  float* sdb = sdh + p.R;       // [T]
-  float* sdWh = sdb + p.T;      // [A]
+  float* sdb = sdx + p.H;       // [T]
+  float* sbt = sdb + p.T;       // [T] beta / T
+  float* spart = sbt + p.T;     // [2][G][A]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, R = p.R, A = p.A, T = p.T;
-  if (p.do_attn) {
-    const int W2 = H + R;
-    const size_t zs = (size_t)p.B * W2;
-    const uint32_t key = drop_key(p.dd);
-    for (int j = tid; j < W2; j += 256) {
-      const float v = sum_strided(p.slab + (size_t)b * W2 + j, zs, p.S);
-      if (j < H) sdx[j] = v * drop_at(p.dd, key, p.s, b, H, j); else sdh[j - H] = v;
-    }
-    __syncthreads();
-    const float invT = 1.0f / (float)T;
-    for (int t = wave; t < T; t += 4) {
-      const float* hs = p.Hs + ((size_t)t * p.B + b) * H;
-      float s = 0.f;
-      for (int h = lane; h < H; h += 64) s += sdx[h] * hs[h];
-      s = wave_sum(s);
-      if (lane == 0) sdb[t] = s * invT;
-    }
-    // dHs[t',b,:] += (1/T) beta[t'] dx
-    for (int t = 0; t < T; ++t) {
-      const float bt = p.beta[(size_t)b * T + t] * invT;
-      float* dst = p.dHs + ((size_t)t * p.B + b) * H;
-      for (int h = tid; h < H; h += 256) dst[h] = p.first_attn ? bt * sdx[h] : dst[h] + bt * sdx[h];
-    }
-    __syncthreads();
-    AT* dwr = reinterpret_cast<AT*>(p.dWhr) + (size_t)b * p.ld_dwhr;
-    for (int k = tid; k < p.ld_dwhr; k += 256) {
-      if (k >= A) { dwr[k] = (AT)0.f; continue; }
-      const float whk = p.Whr[(size_t)b * A + k] + p.ab[k];
-      const float wk = p.w[k];
-      float dwh = 0.f, dw = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const size_t o = ((size_t)t * p.B + b) * A + k;
-        const float tz = rn_tanh(whk + p.Ud[o]);
-        const float dz = sdb[t] * wk * (1.f - tz * tz);
-        dw += sdb[t] * tz;
-        dwh += dz;
-        const float nv = p.first_attn ? dz : p.dUd[o] + dz;
-        p.dUd[o] = nv;
-        if (p.last) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + k] = (AT)nv;
-      }
-      sdWh[k] = dwh;
-      dwr[k] = (AT)dwh;
-      const size_t o2 = (size_t)b * A + k;
-      p.dwacc[o2] = p.first_attn ? dw : p.dwacc[o2] + dw;
-    }
-    if (p.last)
-      for (int t = 0; t < T; ++t)
-        for (int j = A + tid; j < p.ld_dUd; j += 256) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + j] = (AT)0.f;
-    __syncthreads();
-    if (p.prop_hr) {
-      for (int r = tid; r < R; r += 256) {
-        float s = 0.f;
-        for (int k = 0; k < A; ++k) s += sdWh[k] * p.Wr[(size_t)k * R + r];
-        sdh[r] += s;
-      }
-      __syncthreads();
-    }
-  } else {
-    for (int r = tid; r < R; r += 256) sdh[r] = 0.f;
-    __syncthreads();
+  const int W2 = H + R;
+  const size_t zs = (size_t)p.B * W2;
+  const uint32_t key = drop_key(p.dd);
+  const float invT = 1.0f / (float)T;
+  for (int j = tid; j < H; j += 256)
+    sdx[j] = sum_strided(p.slab + (size_t)b * W2 + j, zs, p.S) * drop_at(p.dd, key, p.s, b, H, j);
+  for (int t = tid; t < T; t += 256) sbt[t] = p.beta[(size_t)b * T + t] * invT;
+  __syncthreads();
+  for (int t = wave; t < T; t += 4) {
+    const float* hs = p.Hs + ((size_t)t * p.B + b) * H;
+    float s = 0.f;
+    for (int h = lane; h < H; h += 64) s += sdx[h] * hs[h];
+    s = wave_sum(s);
+    if (lane == 0) sdb[t] = s * invT;
   }
-  if (!p.do_lstm) return;
-  AT* dg = reinterpret_cast<AT*>(p.dG) + (size_t)b * p.ld_dg;
-  for (int u = tid; u < R; u += 256) {
-    const size_t o = (size_t)b * R + u;
-    const float dh = p.dHr[o] + sdh[u];
-    const float* a = p.acts + (size_t)b * 4 * R + u;
-    const LstmGrad g = lstm_point_bwd(dh, p.first_lstm ? 0.f : p.dc_carry[o], a[0], a[R], a[2 * R], a[3 * R],
-                                      p.c[o], p.c_prev ? p.c_prev[o] : 0.f);
-    dg[u] = (AT)g.di; dg[R + u] = (AT)g.df; dg[2 * R + u] = (AT)g.dg; dg[3 * R + u] = (AT)g.d_o;
-    p.dc_carry[o] = g.dc_prev;
+  // dHs[t',b,:] += (1/T) beta[t'] dx     (independent read-modify-writes, issued in groups of 4 steps)
+  for (int h = tid; h < H; h += 256) {
+    const float dx = sdx[h];
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      float* d0 = p.dHs + ((size_t)t * p.B + b) * H + h;
+      const size_t st = (size_t)p.B * H;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      if (!p.first) { v0 = d0[0]; v1 = d0[st]; v2 = d0[2 * st]; v3 = d0[3 * st]; }
+      d0[0] = v0 + sbt[t] * dx; d0[st] = v1 + sbt[t + 1] * dx; d0[2 * st] = v2 + sbt[t + 2] * dx; d0[3 * st] = v3 + sbt[t + 3] * dx;
+    }
+    for (; t < T; ++t) {
+      float* d0 = p.dHs + ((size_t)t * p.B + b) * H + h;
+      d0[0] = (p.first ? 0.f : d0[0]) + sbt[t] * dx;
+    }
   }
-  for (int j = 4 * R + tid; j < p.ld_dg; j += 256) dg[j] = (AT)0.f;
+  __syncthreads();
+  // (t', k) plane: thread -> k = tid % A, step group gi = tid / A
+  const int G = (A <= 256) ? 256 / A : 1;
+  auto tk = [&](int k2, int g2) {
+    const float whk = p.Whr[(size_t)b * A + k2] + p.ab[k2];
+    const float wk = p.w[k2];
+    float dwh = 0.f, dw = 0.f;
+    for (int t = g2; t < T; t += G) {
+      const size_t o = ((size_t)t * p.B + b) * A + k2;
+      const float tz = rn_tanh(whk + p.Ud[o]);
+      const float dz = sdb[t] * wk * (1.f - tz * tz);
+      dw += sdb[t] * tz;
+      dwh += dz;
+      const float nv = p.first ? dz : p.dUd[o] + dz;
+      p.dUd[o] = nv;
+      if (p.last) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + k2] = (AT)nv;
+    }
+    spart[g2 * A + k2] = dwh;
+    spart[(G + g2) * A + k2] = dw;
+  };
+  if (A <= 256) { if (tid < G * A) tk(tid % A, tid / A); }
+  else for (int k2 = tid; k2 < A; k2 += 256) tk(k2, 0);
+  __syncthreads();
+  AT* dwr = reinterpret_cast<AT*>(p.dWhr) + (size_t)b * p.ld_dwhr;
+  for (int k2 = tid; k2 < p.ld_dwhr; k2 += 256) {
+    float a = 0.f, c = 0.f;
+    if (k2 < A) for (int j = 0; j < G; ++j) { a += spart[j * A + k2]; c += spart[(G + j) * A + k2]; }
+    dwr[k2] = (AT)a;
+    if (k2 < A) {
+      const size_t o2 = (size_t)b * A + k2;
+      p.dwacc[o2] = p.first ? c : p.dwacc[o2] + c;
+    }
+  }
+  if (p.last)
+    for (int t = 0; t < T; ++t)
+      for (int j = A + tid; j < p.ld_dUd; j += 256) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + j] = (AT)0.f;
 }
 
 // =============================================================================================

@@ -12,6 +12,7 @@
 #define RN_TAG_REC_FWD 3
 #define RN_TAG_REC_BWD 4
 #define RN_TAG_REC_ATT 5
+#define RN_TAG_REC_ATT_BWD 6
 
 // ---- gemm.hip
 int rn_gemm_bk(int prec);
