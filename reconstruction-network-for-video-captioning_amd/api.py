@@ -369,7 +369,9 @@ class TrainStep:
 
     def fwd_bwd(self, enc, targets, T, step_weight, seed=None):
         ms = self.decoder["_state"]
-        seed = self.seed_base + ms.step if seed is None else seed
+        # dropout seed of optimiser step n (1-based) = seed_base + n, the same rule the device-side counter of
+        # the graph-replay path applies (recnet_train_step_fwd_bwd_dev)
+        seed = self.seed_base + ms.step + 1 if seed is None else seed
         self.engine.train_step_fwd_bwd(enc, targets, T, step_weight, seed)
 
     def optimizer_step(self):
@@ -381,7 +383,7 @@ class TrainStep:
 
     def __call__(self, enc, targets, T, step_weight, seed=None):
         ms = self.decoder["_state"]
-        seed = self.seed_base + ms.step if seed is None else seed
+        seed = self.seed_base + ms.step + 1 if seed is None else seed
         ms.step += 1
         if self.reconstructor:
             self.reconstructor["_state"].step = ms.step

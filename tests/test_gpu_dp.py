@@ -1,0 +1,83 @@
+"""Data-parallel GPU path end to end on ONE GPU: two processes share cuda:0 and exchange gradients over
+gloo (RCCL refuses two ranks on one device; the collective call site is the same torch.distributed
+all_reduce).  Two ranks x B/2 captions must reproduce one rank x B captions: same losses, same parameters
+after the optimiser steps (exact-fp32 MFMA path, so only summation order differs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [8, 5, 64, 61, 16, 32, 16, 16]
+LENS = [5, 2, 7, 3, 1, 4, 9, 6]
+
+
+def _setup(kind, B, lo, hi, prec="f32"):
+    import recnet_amd as R
+    from tests import golden_util as GU
+    from tests.gpu_util import make_models
+    Bfull, F, D, V, E, H, A, RA = DIMS
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 3)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 4) if kind else None
+    enc, targets = GU.make_batch(Bfull, F, D, V, LENS, 9)
+    dims = [hi - lo] + DIMS[1:]
+    C, dec, rec = make_models(dims, kind, prec, decP, recP, device="cuda:0")
+    return R, dec, rec, enc, targets
+
+
+def _worker(rank, world, port, kind, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import recnet_amd as R
+    lo, hi = R.shard_bounds(DIMS[0], world, rank)
+    R_, dec, rec, enc, targets = _setup(kind, DIMS[0], lo, hi)
+    step = R.DataParallelTrainStep(dec, rec, DIMS[0], rank, world, n_frames=DIMS[1])
+    T, w = step.prepare(targets.numpy())
+    e, t = enc[lo:hi].cuda(), targets[:, lo:hi].contiguous().cuda()
+    run = R.GraphedStep(step, e, t, T, w, warmup=0)
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    sc = step.reduce_scalars().cpu().numpy()
+    if rank == 0:
+        q.put((sc, {k: v.detach().cpu().numpy() for k, v in dec["model"].state_dict().items()},
+               {k: v.detach().cpu().numpy() for k, v in rec["model"].state_dict().items()} if rec else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["global", "local"])
+def test_two_ranks_on_one_gpu_match_single_rank(kind):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sc2, dec2, rec2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single rank, whole batch, same two steps (eager TrainStep: also cross-checks graph replay vs eager launch)
+    R, dec, rec, enc, targets = _setup(kind, DIMS[0], 0, DIMS[0])
+    step = R.TrainStep(dec, rec)
+    T, w = step.prepare(targets.numpy())
+    for _ in range(2):
+        sc1 = step(enc.cuda(), targets.cuda(), T, w)
+    torch.cuda.synchronize()
+    sc1 = sc1.cpu().numpy()
+    for i in (0, 3, 6):      # dec_ce, rec_mse, total
+        if i == 6:
+            continue         # the per-rank total mixes local partial sums; compare the parts
+        assert abs(sc2[i] - sc1[i]) <= 2e-5 * max(abs(sc1[i]), 1e-3), (i, sc2[i], sc1[i])
+    for k, v in dec["model"].state_dict().items():
+        assert np.abs(dec2[k] - v.cpu().numpy()).max() <= 2e-6, k
+    for k, v in rec["model"].state_dict().items():
+        assert np.abs(rec2[k] - v.cpu().numpy()).max() <= 2e-6, k
