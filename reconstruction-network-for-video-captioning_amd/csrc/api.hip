@@ -353,7 +353,7 @@ static inline void* at_off(const recnet_handle* h, void* p, size_t elems) {
 // batched GEMM on operand buffers (AT) with automatic split-K; fp32 output
 static void gemm(recnet_handle* h, const void* A, int a_col, int lda, const void* Bm, int b_col, int ldb, float* C, int ldc,
                  const float* bias, int M, int N, int K, float alpha, int acc, hipStream_t st) {
-  int s = rn_pick_splitk(h->prec, M, N, K, 16);
+  int s = rn_pick_splitk(h->prec, M, N, K, 16, 0);
   while (s > 1 && (size_t)s * M * N > h->gws_floats) s >>= 1;
   rn_launch_gemm(h->prec, A, h->lp, a_col, lda, Bm, h->lp, b_col, ldb, C, ldc, bias, M, N, K, alpha, acc, s, h->gws_cur, 1, st);
 }
@@ -373,7 +373,7 @@ static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const v
   int cap = (tag == RN_TAG_DEC_FWD) ? 4 : (tag == RN_TAG_DEC_BWD ? 8 : 16);
   if (dst) cap = 8;
   if (cap_env) cap = cap_env;
-  int s = rn_pick_splitk(h->prec, M, N, K, cap);
+  int s = rn_pick_splitk(h->prec, M, N, K, cap, 1);
   while (s > 1 && (size_t)s * M * N > h->slab_floats) s >>= 1;
   if (s < 2) s = 2;  // always use the slab path so the consumer code is uniform
   s = rn_effective_splitk(h->prec, K, s);

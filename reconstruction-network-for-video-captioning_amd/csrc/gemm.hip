@@ -52,13 +52,20 @@ inline int vec_ok(const void* p, int ld, int elem) {
 
 int rn_gemm_bk(int prec) { return prec == RN_PREC_BF16 ? GemmCfg<bf16_t>::BK : GemmCfg<float>::BK; }
 
-// Picks a split-K factor so that a small-M (recurrent) GEMM still fills the chip: ~256 workgroups.
-int rn_pick_splitk(int prec, int M, int N, int K, int max_split) {
+// Split-K factor.  chain = 1 (recurrent-step GEMMs, M <= 128): latency matters, spread over ~256 workgroups
+// whatever the slice length.  chain = 0 (batched GEMMs): fill one round of 2 workgroups per CU (tiles * s <= 512)
+// while every slice keeps >= 5 k-tiles — the rule that matched the measured optimum on every shape of the step
+// (scratch/gemm_shapes.py; e.g. 100 tiles x K 6144: s = 4, 460 TF vs 190 TF unsplit).
+int rn_pick_splitk(int prec, int M, int N, int K, int max_split, int chain) {
   const int tiles = ((M + GEMM_TILE - 1) / GEMM_TILE) * ((N + GEMM_TILE - 1) / GEMM_TILE);
   const int bk = rn_gemm_bk(prec);
   int nkt = (K + bk - 1) / bk;
   int s = 1;
-  while (s * 2 <= max_split && tiles * s * 2 <= 320 && nkt / (s * 2) >= 1) s *= 2;
+  if (chain) {
+    while (s * 2 <= max_split && tiles * s * 2 <= 320 && nkt / (s * 2) >= 1) s *= 2;
+  } else {
+    while (s * 2 <= max_split && tiles * s * 2 <= 512 && nkt / (s * 2) >= 5) s *= 2;
+  }
   return s;
 }
 

@@ -16,7 +16,7 @@
 
 // ---- gemm.hip
 int rn_gemm_bk(int prec);
-int rn_pick_splitk(int prec, int M, int N, int K, int max_split);
+int rn_pick_splitk(int prec, int M, int N, int K, int max_split, int chain);
 int rn_effective_splitk(int prec, int K, int splitk);
 // a_bf16 / b_bf16: operand memory holds bf16 (pre-packed) instead of fp32.  reduce_after: when splitk > 1,
 // run the slab reduction (otherwise the caller's fused consumer sums ws[z][M][N] itself).
