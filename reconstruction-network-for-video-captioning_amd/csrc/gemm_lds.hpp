@@ -150,46 +150,63 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
     }
   }
 
+  // ---- epilogue.  The MFMA C/D fragment is 4 rows x 16 columns per register, i.e. 64-byte row segments per
+  // store instruction; going through a wave-private LDS staging block turns the wave's 64x64 tile into whole
+  // 256-byte row segments written with one 16-byte store per lane (4x fewer store instructions).
   const int cr = (lane >> 4) * 4, cc = lane & 15;
-  if (p.splitk > 1) {
-    float* W = p.ws + (size_t)z * p.M * p.N;
+  __builtin_amdgcn_s_barrier();                 // every wave has finished reading the operand ring
+  asm volatile("" ::: "memory");
+  float* stg = reinterpret_cast<float*>(gl_smem) + wave * (32 * 68);
+  const bool to_slab = p.splitk > 1;
+  float* Cb = to_slab ? p.ws + (size_t)z * p.M * p.N : p.C;
+  const int ldc = to_slab ? p.N : p.ldc;
+  const bool vec4 = ((ldc & 3) == 0) && ((((uintptr_t)Cb) & 15) == 0) && !p.c_bf16 &&
+                    (!p.C2 || (((p.ldc2 & 3) == 0) && ((((uintptr_t)p.C2) & 7) == 0)));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn + j * 16 + cc;
-        if (col < p.N) {
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm + i * 16 + cr + r;
-            if (row < p.M) W[(size_t)row * p.N + col] = acc[i][j][r];
-          }
-        }
-      }
-  } else {
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r) stg[(ii * 16 + cr + r) * 68 + j * 16 + cc] = acc[half * 2 + ii][j][r];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn + j * 16 + cc;
-        if (col < p.N) {
-          const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 68 + c4);
+      const int row = m0 + wm + half * 32 + rl, col = n0 + wn + c4;
+      if (row >= p.M || col >= p.N) continue;
+      if (to_slab) {
+        float* dst = Cb + (size_t)row * ldc + col;
+        if (vec4 && col + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
+        else for (int q = 0; q < 4 && col + q < p.N; ++q) dst[q] = v[q];
+      } else {
+        float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm + i * 16 + cr + r;
-            if (row < p.M) {
-              float v = p.alpha * acc[i][j][r] + bv;
-              if (p.c_bf16) {
-                reinterpret_cast<bf16_t*>(p.C)[(size_t)row * p.ldc + col] = (bf16_t)v;
-              } else {
-                float* dst = p.C + (size_t)row * p.ldc + col;
-                if (p.accumulate) v += *dst;
-                *dst = v;
-                if (p.C2) reinterpret_cast<bf16_t*>(p.C2)[(size_t)row * p.ldc2 + col] = (bf16_t)v;
-              }
+        for (int q = 0; q < 4; ++q) o[q] = p.alpha * v[q] + ((p.bias && col + q < p.N) ? p.bias[col + q] : 0.f);
+        if (p.c_bf16) {
+          bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col;
+          for (int q = 0; q < 4 && col + q < p.N; ++q) dst[q] = (bf16_t)o[q];
+        } else {
+          float* dst = Cb + (size_t)row * ldc + col;
+          if (vec4 && col + 3 < p.N) {
+            f32x4 w = f32x4{o[0], o[1], o[2], o[3]};
+            if (p.accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(dst); w += old; }
+            *reinterpret_cast<f32x4*>(dst) = w;
+            if (p.C2) {
+              bf16x4 hb; hb[0] = (bf16_t)w[0]; hb[1] = (bf16_t)w[1]; hb[2] = (bf16_t)w[2]; hb[3] = (bf16_t)w[3];
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C2) + (size_t)row * p.ldc2 + col) = hb;
+            }
+          } else {
+            for (int q = 0; q < 4 && col + q < p.N; ++q) {
+              float w = o[q];
+              if (p.accumulate) w += dst[q];
+              dst[q] = w;
+              if (p.C2) reinterpret_cast<bf16_t*>(p.C2)[(size_t)row * p.ldc2 + col + q] = (bf16_t)w;
             }
           }
         }
       }
+    }
   }
 }

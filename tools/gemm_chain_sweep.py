@@ -1,5 +1,5 @@
 import sys, time, torch, os
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from recnet_amd.engine import Engine
 eng = Engine(dict(B=2, F=2, D=8, E=4, H=8, A=4, V=8), None, "bf16")
 def bench(fn, n=30):
