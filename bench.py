@@ -32,6 +32,8 @@ def cpu_baseline(kind, B, F, D, V, steps, warmup):
     """The oracle (CPU port of the reference algorithm, oracle/recnet_oracle.py) timed on this host."""
     import torch
     from oracle import recnet_oracle as O
+    # small per-step ops: more than ~32 threads only adds synchronisation cost to the CPU port
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     torch.manual_seed(0)
     decP = O.init_decoder_params(V, D=D)
     recP = O.init_rec_params(kind, R=D) if kind else None
