@@ -103,10 +103,12 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ          # torch.distributed.run, any world size
+    if world > 1 or under_launcher:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(os.environ.get("RN_DIST_BACKEND", "nccl"), rank=rank, world_size=world, device_id=dev)
 
     B, F, D, V = args.batch, args.frames, args.feat, 4188
     kind = None if args.rec == "none" else args.rec
@@ -118,7 +120,7 @@ def main():
     lo, hi = R.shard_bounds(Bg, world, rank)
     enc = synthetic_features(hi - lo, F, D, seed=1234 + rank).to(dev)
     targets = targets_g[:, lo:hi].contiguous().to(dev)
-    step = R.DataParallelTrainStep(dec, rec, Bg, rank, world, n_frames=F)
+    step = R.DataParallelTrainStep(dec, rec, Bg, rank, world, n_frames=F, always_reduce=under_launcher)
     T, w = step.prepare(targets_g.numpy())
 
     def sync_all():
@@ -156,7 +158,7 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
                                    "D=R=%d, V=4188, E=468, H=512, A=128, T=31, dropout 0.5" % (args.rec, B, F, D),
-                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph),
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "grad_allreduce": bool(step.reduce),
                        "loss": round(sc["total_loss"], 5)},
             "roofline": prof,
         }
@@ -166,7 +168,7 @@ def main():
                                    "sample": "1 warm-up + %d timed train steps of the same workload (B=%d, T=31) by "
                                              "oracle/recnet_oracle.py on torch-CPU; median %.2f s/step" % (args.cpu_steps, B, med)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or under_launcher:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -416,20 +416,22 @@ class GraphedStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # thread_local: the RCCL watchdog thread of torch.distributed issues event queries of its own; in the
+        # default (global) mode those would invalidate an ongoing capture
         self.g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1):
+        with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
             eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
-            if dp_step.world == 1:
+            if not dp_step.reduce:
                 eng.optimizer_step_dev(self.flags)
         self.g2 = None
-        if dp_step.world > 1:
+        if dp_step.reduce:
             self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2):
+            with torch.cuda.graph(self.g2, capture_error_mode="thread_local"):
                 eng.optimizer_step_dev(self.flags)
 
     def _eager(self):
         self.eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
-        if self.dp.world > 1:
+        if self.dp.reduce:
             from .dp import allreduce_sum_
             allreduce_sum_(self.dp.grad_buffers(), self.dp.group)
         self.eng.optimizer_step_dev(self.flags)

@@ -29,9 +29,12 @@ def allreduce_sum_(flat_buffers, group=None):
 class DataParallelTrainStep:
     """Wraps api.TrainStep for world_size ranks.  Each rank owns captions [lo, hi) of the global batch."""
 
-    def __init__(self, decoder, reconstructor, global_batch, rank, world_size, n_frames=None, group=None):
+    def __init__(self, decoder, reconstructor, global_batch, rank, world_size, n_frames=None, group=None,
+                 always_reduce=False):
         from .api import TrainStep
         self.rank, self.world = rank, world_size
+        # reduce even with one rank (exercises the collective path under torchrun --nproc-per-node 1)
+        self.reduce = world_size > 1 or always_reduce
         self.global_batch = global_batch
         self.lo, self.hi = shard_bounds(global_batch, world_size, rank)
         self.group = group
@@ -55,7 +58,7 @@ class DataParallelTrainStep:
 
     def __call__(self, enc_local, targets_local, T, step_weight, seed=None):
         self.step_impl.fwd_bwd(enc_local, targets_local, T, step_weight, seed)
-        if self.world > 1:
+        if self.reduce:
             allreduce_sum_(self.grad_buffers(), self.group)
         self.step_impl.optimizer_step()
         return self.step_impl.scalars
