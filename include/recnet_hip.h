@@ -202,6 +202,12 @@ int recnet_train_step(recnet_handle* h, const float* enc, const int64_t* targets
 int recnet_set_step(recnet_handle* h, int32_t step, void* stream);
 int recnet_train_step_fwd_bwd_dev(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
                                   const float* step_weight, uint32_t seed_base, recnet_scalars* scalars, void* stream);
+/* The same forward + backward in two launches, so that a data-parallel caller can all-reduce the reconstructor's
+ * gradient bucket while the decoder's backward is still running: part 1 = step += 1, decoder forward, loss,
+ * reconstructor forward + complete backward (all reconstructor gradients final, d loss / d hiddens kept);
+ * part 2 = decoder BPTT + deferred decoder gradients. */
+int recnet_train_step_part_dev(recnet_handle* h, int32_t part, const float* enc, const int64_t* targets, int32_t T,
+                               const float* step_weight, uint32_t seed_base, recnet_scalars* scalars, void* stream);
 int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* scalars, void* stream);
 
 /* ---- plumbing exposed for tests and profiling */

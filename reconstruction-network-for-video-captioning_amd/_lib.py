@@ -122,3 +122,5 @@ EXPORTS["recnet_profile_begin"] = (_i, [C.c_void_p, _i])
 EXPORTS["recnet_profile_end"] = (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_d)])
 EXPORTS["recnet_gemm_bf16"] = (_i, [C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _f, _i, _i,
                                   C.c_void_p, _i, C.c_void_p])
+EXPORTS["recnet_train_step_part_dev"] = (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_uint32,
+                                              C.c_void_p, C.c_void_p])

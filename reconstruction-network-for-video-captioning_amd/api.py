@@ -392,11 +392,17 @@ class TrainStep:
 
 
 class GraphedStep:
-    """Replays the train step from captured hipGraphs (one per fixed T): the step is ~300 dependent
+    """Replays the train step from captured hipGraphs (one per fixed T): the step is ~340 dependent
     launches, so eager launching is host-bound; a graph removes the launch overhead.  The optimiser
-    step count and the dropout seed advance on the device (recnet_train_step_fwd_bwd_dev), so every
-    replay is a new training step.  With world_size > 1 the gradient all-reduce runs between two graphs
-    (fwd+bwd | RCCL all-reduce | optimiser)."""
+    step count and the dropout seed advance on the device (recnet_train_step_*_dev), so every replay is
+    a new training step.
+
+    One rank: a single graph (fwd + bwd + optimiser).  Data parallel: three graphs with the two gradient
+    all-reduces in between,
+        graph A (fwd, reconstructor bwd)  ->  all-reduce(reconstructor bucket, async, RCCL stream)
+        graph B (decoder bwd)  [runs while the reconstructor bucket is on the wire]
+        all-reduce(decoder bucket)  ->  wait both  ->  graph C (regulariser, clip, Adam, re-pack)
+    so only the decoder bucket's all-reduce is exposed."""
 
     def __init__(self, dp_step, enc, targets, T, step_weight, warmup=2):
         self.dp = dp_step
@@ -407,33 +413,51 @@ class GraphedStep:
         self.rs = st.reconstructor["_state"] if st.reconstructor else None
         self.seed_base = st.seed_base
         self.flags = _lib.OPT_REG | _lib.OPT_CLIP
+        self.split = bool(dp_step.reduce)
         eng = self.eng
         eng.set_step(self.ms.step)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up outside capture (lazy module loading)
+        with torch.cuda.stream(side):                      # warm-up outside capture (lazy module loading, RCCL init)
             for _ in range(warmup):
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # thread_local: the RCCL watchdog thread of torch.distributed issues event queries of its own; in the
         # default (global) mode those would invalidate an ongoing capture
-        self.g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
-            eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
-            if not dp_step.reduce:
+        mode = dict(capture_error_mode="thread_local")
+        self.graphs = []
+        if not self.split:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **mode):
+                eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
                 eng.optimizer_step_dev(self.flags)
-        self.g2 = None
-        if dp_step.reduce:
-            self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2, capture_error_mode="thread_local"):
+            self.graphs = [g]
+        else:
+            for part in (1, 2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **mode):
+                    eng.train_step_part_dev(part, self.enc, self.targets, self.T, self.w, self.seed_base)
+                self.graphs.append(g)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **mode):
                 eng.optimizer_step_dev(self.flags)
+            self.graphs.append(g)
+
+    def _reduce_async(self, buf):
+        import torch.distributed as dist
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.dp.group, async_op=True)
 
     def _eager(self):
-        self.eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
-        if self.dp.reduce:
-            from .dp import allreduce_sum_
-            allreduce_sum_(self.dp.grad_buffers(), self.dp.group)
+        if not self.split:
+            self.eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
+        else:
+            self.eng.train_step_part_dev(1, self.enc, self.targets, self.T, self.w, self.seed_base)
+            works = [self._reduce_async(self.rs.flat()["grad"].flat)] if self.rs else []
+            self.eng.train_step_part_dev(2, self.enc, self.targets, self.T, self.w, self.seed_base)
+            works.append(self._reduce_async(self.ms.flat()["grad"].flat))
+            for w in works:
+                w.wait()
         self.eng.optimizer_step_dev(self.flags)
         self._bump()
 
@@ -443,10 +467,16 @@ class GraphedStep:
             self.rs.step = self.ms.step
 
     def __call__(self):
-        self.g1.replay()
-        if self.g2 is not None:
-            from .dp import allreduce_sum_
-            allreduce_sum_(self.dp.grad_buffers(), self.dp.group)
-            self.g2.replay()
+        if not self.split:
+            self.graphs[0].replay()
+        else:
+            ga, gb, gc = self.graphs
+            ga.replay()
+            works = [self._reduce_async(self.rs.flat()["grad"].flat)] if self.rs else []
+            gb.replay()
+            works.append(self._reduce_async(self.ms.flat()["grad"].flat))
+            for w in works:
+                w.wait()
+            gc.replay()
         self._bump()
         return self.eng.scalars

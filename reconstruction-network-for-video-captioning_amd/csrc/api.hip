@@ -1015,32 +1015,40 @@ int recnet_optimizer_step(recnet_handle* h, int32_t step, int32_t flags, recnet_
 // projection + CE + output-layer gradients while the reconstructor runs, the reconstructor's deferred weight
 // gradients while the decoder BPTT runs.  The chains are latency-bound (~1 workgroup per CU), so the batched
 // GEMMs fill CUs that would otherwise idle.
-static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st) {
+// phase 0: everything.  phase 1: up to and including every reconstructor gradient (so a data-parallel caller can
+// start all-reducing the reconstructor bucket).  phase 2: the decoder BPTT + its deferred gradients.
+static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st,
+                   int phase = 0) {
   const bool rec = h->kind != RECNET_REC_NONE;
   hipStream_t sd = (h->overlap && rec) ? h->s2 : st;
   const bool par = sd != st;
-  int r = dec_fwd_chain(h, enc, targets, T, 1, st); if (r) return r;
-  if (par) { fork_to(h, 0, st, sd); h->gws_cur = h->gws2; }
-  r = dec_fwd_loss(h, targets, T, stepw, 1, sd); if (r) return r;
-  r = dec_bwd_out(h, 1.0f, sd); if (r) return r;
-  h->gws_cur = h->gws;
-  const float* dh = nullptr;
-  if (rec) {
-    r = fwd_rec(h, enc, T, 1, st); if (r) return r;
-    r = bwd_rec_chain(h, h->c.lambda_recon, h->dHsrec, st); if (r) return r;
-    dh = h->dHsrec;
-    if (par) {
-      join_from(h, 1, st, sd);              // the decoder BPTT needs dHs_out
-      fork_to(h, 2, st, sd); h->gws_cur = h->gws2;
+  int r;
+  const float* dh = rec ? h->dHsrec : nullptr;
+  if (phase != 2) {
+    r = dec_fwd_chain(h, enc, targets, T, 1, st); if (r) return r;
+    if (par) { fork_to(h, 0, st, sd); h->gws_cur = h->gws2; }
+    r = dec_fwd_loss(h, targets, T, stepw, 1, sd); if (r) return r;
+    r = dec_bwd_out(h, 1.0f, sd); if (r) return r;
+    h->gws_cur = h->gws;
+    if (rec) {
+      r = fwd_rec(h, enc, T, 1, st); if (r) return r;
+      r = bwd_rec_chain(h, h->c.lambda_recon, h->dHsrec, st); if (r) return r;
+      if (par) join_from(h, 1, st, sd);              // the decoder BPTT needs dHs_out; scal[2] is final
+      hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 5, h->c.lambda_recon, h->scal + 6);
+      if (phase == 1) {                              // no decoder BPTT to hide behind: stay on the main stream
+        r = bwd_rec_deferred(h, st); if (r) return r;
+      }
     }
+    if (phase == 1) return RECNET_OK;
+  }
+  if (phase == 0 && rec) {
+    if (par) { fork_to(h, 2, st, sd); h->gws_cur = h->gws2; }
     r = bwd_rec_deferred(h, sd); if (r) return r;
     h->gws_cur = h->gws;
-    // total = dec_loss + lambda_recon * rec_loss (both parts are final here)
-    hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 5, h->c.lambda_recon, h->scal + 6);
   }
   r = dec_bwd_chain(h, dh, st); if (r) return r;
   r = dec_bwd_deferred(h, enc, targets, st); if (r) return r;
-  if (par) join_from(h, 3, st, sd);
+  if (phase == 0 && rec && par) join_from(h, 3, st, sd);
   h->fwd_dec_done = 0;
   return RECNET_OK;
 }
@@ -1086,6 +1094,23 @@ int recnet_train_step_fwd_bwd_dev(recnet_handle* h, const float* enc, const int6
   int r = fwd_bwd(h, enc, targets, T, step_weight, st); if (r) return r;
   if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
   h->fwd_dec_done = 0;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_train_step_part_dev(recnet_handle* h, int32_t part, const float* enc, const int64_t* targets, int32_t T,
+                               const float* step_weight, uint32_t seed_base, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  if (part != 1 && part != 2) return fail(RECNET_EINVAL, "part must be 1 or 2");
+  if (!h->dec_bound || (h->kind != RECNET_REC_NONE && !h->rec_bound)) return fail(RECNET_ESTATE, "models not bound");
+  if (!h->dGd.out_weight || (h->kind != RECNET_REC_NONE && !h->rG.out_weight)) return fail(RECNET_ESTATE, "gradients not bound");
+  if (!enc || !targets || !step_weight) return fail(RECNET_EINVAL, "null argument");
+  if (check_T(h, T)) return fail(RECNET_EINVAL, "T out of range");
+  hipStream_t st = (hipStream_t)stream;
+  if (part == 1) hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, (int32_t*)(h->ctrl + 1), h->ctrl, seed_base);
+  else if (h->T_last != T) return fail(RECNET_ESTATE, "part 2 without a matching part 1");
+  int r = fwd_bwd(h, enc, targets, T, step_weight, st, part); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
   LAUNCH_OK();
   return RECNET_OK;
 }

@@ -273,6 +273,12 @@ class Engine:
                    "recnet_train_step_fwd_bwd_dev")
         self.T = T
 
+    def train_step_part_dev(self, part, enc, targets, T, step_weight, seed_base):
+        _lib.check(self.lib.recnet_train_step_part_dev(self.handle, int(part), _ptr(enc), _ptr(targets), int(T),
+                                                       _ptr(step_weight), seed_base & 0xFFFFFFFF, _ptr(self.scalars),
+                                                       _stream()), "recnet_train_step_part_dev")
+        self.T = T
+
     def optimizer_step_dev(self, flags):
         _lib.check(self.lib.recnet_optimizer_step_dev(self.handle, int(flags), _ptr(self.scalars), _stream()),
                    "recnet_optimizer_step_dev")
