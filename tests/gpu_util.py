@@ -8,9 +8,12 @@ from oracle import recnet_oracle as O
 from tests import golden_util as GU
 
 TOL = {
-    # precision: (loss rel, hidden abs, per-tensor grad ||d||/||g||, param abs after steps)
-    "f32": dict(loss=2e-5, hid=2e-5, grad=2e-4, param=2e-6),
-    "bf16": dict(loss=3e-3, hid=1.5e-2, grad=4e-2, param=6e-5),   # 3 Adam steps of lr 1e-5: a sign flip of a tiny gradient moves a parameter by up to 2*lr per step
+    # The parity bars of SURVEY.md §8d.  precision: loss rel, hidden-state abs, per-tensor gradient ||d||/||g||,
+    # parameter abs after the optimiser steps.  Measured worst cases over the golden set (tools/parity_report.py):
+    # f32 path: hidden 2.4e-7, loss 1.9e-7, gradient 6.8e-7; bf16 path: hidden 3.0e-3, loss 1.0e-5, gradient 7.3e-3.
+    "f32": dict(loss=1e-5, hid=1e-5, grad=1e-4, param=2e-6, cos=0.999999),
+    # bf16: 3 Adam steps of lr 1e-5: a sign flip of a tiny gradient moves a parameter by up to 2*lr per step
+    "bf16": dict(loss=1e-3, hid=1e-2, grad=2e-2, param=6e-5, cos=0.9995),
 }
 
 
@@ -43,6 +46,12 @@ def load_case(name):
         decP, recP = GU.group(g, "dec_init"), (GU.group(g, "rec_init") if kind else None)
         enc, targets = torch.from_numpy(g["enc"]), torch.from_numpy(g["targets"])
     return g, dims, kind, decP, recP, enc, targets
+
+
+def cosine(a, b):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
 
 
 def rel_err(a, b):

@@ -10,7 +10,7 @@ import torch
 import recnet_amd as R
 from oracle import recnet_oracle as O
 from tests import golden_util as GU
-from tests.gpu_util import TOL, load_case, make_models, oracle_grads, rel_err
+from tests.gpu_util import TOL, cosine, load_case, make_models, oracle_grads, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -91,11 +91,17 @@ def test_autograd_api_losses_and_grads(name, prec):
             key = "%s_grad/%s" % (grp, k)
             if key in g:
                 e = rel_err(gg, g[key])
+                if np.linalg.norm(g[key]) > 0 and cosine(gg, g[key]) < tol["cos"]:
+                    bad.append((grp, k, "cosine", cosine(gg, g[key])))
             else:
                 e = abs(np.linalg.norm(gg.astype(np.float64)) - ref_n) / max(ref_n, 1e-12)
                 sl = g["%s_gslice/%s" % (grp, k)]
                 e = max(e, float(np.abs(gg.reshape(-1)[:64] - sl).max() / max(np.abs(sl).max(), 1e-12)) * 0.25)
-            if e > tol["grad"]:
+            # full-shape cases: the regulariser gradient lambda * p / ||p|| dominates the reconstructor's weight
+            # gradients at initialisation, and the reference's float32 CPU ||p|| is itself ~1e-4 off on these
+            # multi-million-element tensors (see REG_SLACK above)
+            lim = tol["grad"] if key in g else max(tol["grad"], REG_SLACK)
+            if e > lim:
                 bad.append((grp, k, e))
     assert not bad, bad
 
