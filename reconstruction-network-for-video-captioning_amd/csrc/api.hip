@@ -40,7 +40,7 @@ struct recnet_handle {
   int B, F, D, E, H, A, V, R, RA, Tm, kind, prec, cml;
   int lp;                // 1: operand copies / packed weights are bf16 (DMA-staged GEMM); 0: fp32 (exact path)
   // leading dimensions (elements) of the operand buffers: multiples of 8
-  int ldD, ldE, ldH, ldV, ldA, ld4H, ldWS, ldR, ld4R, ldRA, ldHR;
+  int ldD, ldE, ldH, ldV, ldA, ld4H, ldWS, ldR, ld4R, ldRA, ldHR, ldRA4;
   // workspace
   char* ws = nullptr; size_t ws_bytes = 0; size_t need = 0;
   uint32_t* ctrl;        // [0] seed slot, [1] step slot (int32)
@@ -56,7 +56,7 @@ struct recnet_handle {
   // ---- reconstructor
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
-  void *mpd_lp, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr;
+  void *mpd_lp, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_a, *Wih_b, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   size_t gws_floats, slab_floats;
   float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
@@ -86,6 +86,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->ldD = pad8(h->D); h->ldE = pad8(h->E); h->ldH = pad8(h->H); h->ldV = pad8(h->V); h->ldA = pad8(h->A);
   h->ld4H = pad8(4 * h->H); h->ldWS = pad8(4 * h->H + RN_FCH * h->A);
   h->ldR = pad8(h->R); h->ld4R = pad8(4 * h->R); h->ldRA = pad8(h->RA); h->ldHR = pad8(h->H + h->R);
+  h->ldRA4 = pad8(RN_TCH * h->RA);
   const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
                ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
@@ -149,9 +150,10 @@ static size_t carve(recnet_handle* h, char* base) {
     h->Ud = take(Tm * B * RA);
     h->Hr = take(F * B * R); h->Cr = take(F * B * R); h->acts_r = take(F * B * 4 * R);
     h->beta = take(F * B * Tm); h->Whr = take(F * B * RA); h->outl = take(F * B * R); h->dHr = take(F * B * R);
-    h->dUd = take(Tm * B * RA); h->dwacc_r = take(B * RA);
+    h->dUd = take(Tm * B * RA); h->dwacc_r = take(RN_TCH * B * RA);
     h->Xcat_r = takev(F * B * ldHR); h->Hr_lp = takev(F * B * ldR); h->dout_lp = takev(F * B * ldR);
-    h->dGr = takev(F * B * ld4R); h->dUd_lp = takev(Tm * B * ldRA); h->dWhr = takev(F * B * ldRA);
+    h->dGr = takev(F * B * ld4R); h->dUd_lp = takev(Tm * B * ldRA); h->dWhr = takev(F * B * (size_t)h->ldRA4);
+    h->dWhrs = takev(F * B * ldRA); h->Wr4_w = takev(RN_TCH * RA * ldR);
     h->Ur_w = takev(RA * ldH); h->Wr_w = takev(RA * ldR); h->Wihh_w = takev(4 * R * ldHR);
     h->slab2 = take(16 * B * R);
   }
@@ -457,6 +459,8 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
     } else {
       pack_block(h, h->Ur_w, h->ldH, h->rP.attn_U_weight, H, RA, H, 1.f, st);
       pack_block(h, h->Wr_w, h->ldR, h->rP.attn_W_weight, R, RA, R, 1.f, st);
+      for (int j = 0; j < RN_TCH; ++j)   // [W_r ; W_r ; W_r ; W_r]: sums the per-chunk dWhr partials in the GEMM's K loop
+        pack_block(h, at_off(h, h->Wr4_w, (size_t)j * RA * h->ldR), h->ldR, h->rP.attn_W_weight, R, RA, R, 1.f, st);
       const size_t n = (size_t)4 * R * h->ldHR;    // [W_ih | W_hh | 0]
       if (h->lp) hipLaunchKernelGGL(pack2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->Wihh_w, h->ldHR, h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
       else hipLaunchKernelGGL(pack2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->Wihh_w, h->ldHR, h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
@@ -778,7 +782,7 @@ static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStr
   a.B = B; a.T = T; a.H = H; a.R = R; a.A = RA;
   a.Hs = h->Hs; a.Ud = h->Ud; a.ab = h->rP.attn_b; a.w = h->rP.attn_w_weight;
   a.dHs = dhid_out; a.dUd = h->dUd; a.dwacc = h->dwacc_r; a.slab = h->slab;
-  a.ld_dwhr = h->ldRA; a.dUd_lp = h->dUd_lp; a.ld_dUd = h->ldRA;
+  a.ld_dwhr = h->ldRA4; a.dUd_lp = h->dUd_lp; a.ld_dUd = h->ldRA;
   a.dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
   const int Asz = RA <= 256 ? 256 : RA;
   const size_t sm = (size_t)(H + 2 * T + 2 * Asz + 16) * 4;
@@ -791,10 +795,10 @@ static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStr
     S1 = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)s * B * ld4R), ld4R, h->Wihh_w, 1, ldHR, B, H + R, 4 * R, st);
     a.s = s; a.S = S1; a.first = (s == F - 1); a.last = (s == 0);
     a.Whr = h->Whr + (size_t)s * B * RA; a.beta = h->beta + (size_t)s * B * T;
-    a.dWhr = at_off(h, h->dWhr, (size_t)s * B * h->ldRA);
-    LAUNCH_AT(h, loc_attn_bwd_kernel, dim3(B), dim3(256), sm, st, a);
-    if (s > 0)   // d hr_{s-1} (attention path) = dWhr_s . W_r
-      S2 = gemm_slabs(h, RN_TAG_REC_ATT_BWD, at_off(h, h->dWhr, (size_t)s * B * h->ldRA), h->ldRA, h->Wr_w, 1, h->ldR, B, R, RA, st, h->slab2);
+    a.dWhr = at_off(h, h->dWhr, (size_t)s * B * h->ldRA4);
+    LAUNCH_AT(h, loc_attn_bwd_kernel, dim3(B, RN_TCH), dim3(256), sm, st, a);
+    if (s > 0)   // d hr_{s-1} (attention path) = (dWhr_s chunk partials) . [W_r ; .. ; W_r]
+      S2 = gemm_slabs(h, RN_TAG_REC_ATT_BWD, at_off(h, h->dWhr, (size_t)s * B * h->ldRA4), h->ldRA4, h->Wr4_w, 1, h->ldR, B, R, RN_TCH * RA, st, h->slab2);
   }
   gemm(h, h->dUd_lp, 0, h->ldRA, h->Ur_w, 1, h->ldH, dhid_out, H, nullptr, TB, H, RA, 1.f, 1, st);
   return RECNET_OK;
@@ -803,15 +807,20 @@ static int bwd_rec_local_deferred(recnet_handle* h, hipStream_t st) {
   const int B = h->B, F = h->F, H = h->H, R = h->R, RA = h->RA, T = h->T_last, TB = T * B, FB = F * B;
   const int ld4R = h->ld4R, ldHR = h->ldHR;
   gemm(h, h->dUd_lp, 1, h->ldRA, h->Hs_lp, 1, h->ldH, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
+  {
+    const size_t n = (size_t)FB * h->ldRA;
+    if (h->lp) hipLaunchKernelGGL(sum_chunks_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->dWhrs, h->ldRA, (const bf16_t*)h->dWhr, h->ldRA4, FB, RA, RN_TCH);
+    else hipLaunchKernelGGL(sum_chunks_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->dWhrs, h->ldRA, (const float*)h->dWhr, h->ldRA4, FB, RA, RN_TCH);
+  }
   if (F > 1) {
-    gemm(h, at_off(h, h->dWhr, (size_t)B * h->ldRA), 1, h->ldRA, h->Hr_lp, 1, h->ldR, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
+    gemm(h, at_off(h, h->dWhrs, (size_t)B * h->ldRA), 1, h->ldRA, h->Hr_lp, 1, h->ldR, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
     gemm(h, at_off(h, h->dGr, (size_t)B * ld4R), 1, ld4R, h->Hr_lp, 1, h->ldR, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (F - 1) * B, 1.f, 0, st);
   } else {
     hipMemsetAsync(h->rG.attn_W_weight, 0, (size_t)RA * R * 4, st);
     hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)4 * R * R * 4, st);
   }
-  colsum_at(h, h->dWhr, FB, RA, h->ldRA, h->rG.attn_b, st);
-  colsum_t<float>(h->dwacc_r, B, RA, RA, h->rG.attn_w_weight, st);
+  colsum_at(h, h->dWhrs, FB, RA, h->ldRA, h->rG.attn_b, st);
+  colsum_t<float>(h->dwacc_r, RN_TCH * B, RA, RA, h->rG.attn_w_weight, st);
   gemm(h, h->dGr, 1, ld4R, h->Xcat_r, 1, ldHR, h->rG.rnn_weight_ih_l0, H, nullptr, 4 * R, H, FB, 1.f, 0, st);
   colsum_at(h, h->dGr, FB, 4 * R, ld4R, h->rG.rnn_bias_ih_l0, st);
   copyf(h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, 4 * R, st);

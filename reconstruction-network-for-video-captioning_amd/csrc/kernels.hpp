@@ -806,9 +806,12 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   }
 }
 
-// Attention backward of reconstructor step s, one workgroup per caption.  dx_s comes from the x columns of
-// dGr_s . [W_ih | W_hh] (split-K slabs); outputs: dHs += (1/T) beta dx, dUd += dz, dWhr_s (operand of the next small
-// GEMM dWhr_s . W_r and of the deferred dW_r), dw accumulator.
+// Attention backward of reconstructor step s, one workgroup per (caption, chunk of decoder steps t'), RN_TCH
+// chunks (t' = ch, ch + RN_TCH, ...).  dx_s comes from the x columns of dGr_s . [W_ih | W_hh] (split-K slabs);
+// outputs: dHs[t'] += (1/T) beta dx and dUd[t'] += dz for the chunk's own t' (no conflicts between chunks), the
+// chunk's partial dWhr_s written side by side [chunk 0 | .. | chunk RN_TCH-1] (summed by the K loop of the next
+// GEMM against [W_r ; .. ; W_r], like the decoder's dWh), and the dw accumulator per chunk.
+#define RN_TCH 4
 struct LocBwdArgs {
   int s, B, T, H, R, A, S;
   const float* slab;      // [S][B][H+R]
@@ -817,8 +820,8 @@ struct LocBwdArgs {
   const float* beta;      // [B][T] of step s
   float* dHs;             // [T][B][H] accumulated over s
   float* dUd;             // [T][B][A] accumulated over s
-  void* dWhr; int ld_dwhr;   // AT [B][ld] of step s
-  float* dwacc;           // [B][A]
+  void* dWhr; int ld_dwhr;   // AT [B][ld] of step s: RN_TCH partial blocks of A columns
+  float* dwacc;           // [RN_TCH][B][A]
   int first;
   void* dUd_lp; int ld_dUd; int last;   // at s == 0 also emit the AT copy of dUd
   DropDesc dd;
@@ -830,47 +833,53 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   float* sdb = sdx + p.H;       // [T]
   float* sbt = sdb + p.T;       // [T] beta / T
   float* spart = sbt + p.T;     // [2][G][A]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = p.H, R = p.R, A = p.A, T = p.T;
   const int W2 = H + R;
   const size_t zs = (size_t)p.B * W2;
   const uint32_t key = drop_key(p.dd);
   const float invT = 1.0f / (float)T;
+  const int nt = (T - ch + RN_TCH - 1) / RN_TCH;        // decoder steps of this chunk
   for (int j = tid; j < H; j += 256)
     sdx[j] = sum_strided(p.slab + (size_t)b * W2 + j, zs, p.S) * drop_at(p.dd, key, p.s, b, H, j);
   for (int t = tid; t < T; t += 256) sbt[t] = p.beta[(size_t)b * T + t] * invT;
   __syncthreads();
-  for (int t = wave; t < T; t += 4) {
+  for (int i = wave; i < nt; i += 4) {
+    const int t = ch + i * RN_TCH;
     const float* hs = p.Hs + ((size_t)t * p.B + b) * H;
     float s = 0.f;
     for (int h = lane; h < H; h += 64) s += sdx[h] * hs[h];
     s = wave_sum(s);
     if (lane == 0) sdb[t] = s * invT;
   }
-  // dHs[t',b,:] += (1/T) beta[t'] dx     (independent read-modify-writes, issued in groups of 4 steps)
+  // dHs[t',b,:] += (1/T) beta[t'] dx for the chunk's t' (independent read-modify-writes, four in flight)
+  const size_t st = (size_t)p.B * H * RN_TCH;
   for (int h = tid; h < H; h += 256) {
     const float dx = sdx[h];
-    int t = 0;
-    for (; t + 4 <= T; t += 4) {
-      float* d0 = p.dHs + ((size_t)t * p.B + b) * H + h;
-      const size_t st = (size_t)p.B * H;
+    float* d0 = p.dHs + ((size_t)ch * p.B + b) * H + h;
+    int i = 0;
+    for (; i + 4 <= nt; i += 4) {
+      float* d = d0 + (size_t)i * st;
       float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-      if (!p.first) { v0 = d0[0]; v1 = d0[st]; v2 = d0[2 * st]; v3 = d0[3 * st]; }
-      d0[0] = v0 + sbt[t] * dx; d0[st] = v1 + sbt[t + 1] * dx; d0[2 * st] = v2 + sbt[t + 2] * dx; d0[3 * st] = v3 + sbt[t + 3] * dx;
+      if (!p.first) { v0 = d[0]; v1 = d[st]; v2 = d[2 * st]; v3 = d[3 * st]; }
+      const int t = ch + i * RN_TCH;
+      d[0] = v0 + sbt[t] * dx; d[st] = v1 + sbt[t + RN_TCH] * dx; d[2 * st] = v2 + sbt[t + 2 * RN_TCH] * dx;
+      d[3 * st] = v3 + sbt[t + 3 * RN_TCH] * dx;
     }
-    for (; t < T; ++t) {
-      float* d0 = p.dHs + ((size_t)t * p.B + b) * H + h;
-      d0[0] = (p.first ? 0.f : d0[0]) + sbt[t] * dx;
+    for (; i < nt; ++i) {
+      float* d = d0 + (size_t)i * st;
+      d[0] = (p.first ? 0.f : d[0]) + sbt[ch + i * RN_TCH] * dx;
     }
   }
   __syncthreads();
-  // (t', k) plane: thread -> k = tid % A, step group gi = tid / A
+  // (t', k) plane: thread -> k = tid % A, group gi = tid / A
   const int G = (A <= 256) ? 256 / A : 1;
   auto tk = [&](int k2, int g2) {
     const float whk = p.Whr[(size_t)b * A + k2] + p.ab[k2];
     const float wk = p.w[k2];
     float dwh = 0.f, dw = 0.f;
-    for (int t = g2; t < T; t += G) {
+    for (int i = g2; i < nt; i += G) {
+      const int t = ch + i * RN_TCH;
       const size_t o = ((size_t)t * p.B + b) * A + k2;
       const float tz = rn_tanh(whk + p.Ud[o]);
       const float dz = sdb[t] * wk * (1.f - tz * tz);
@@ -887,18 +896,19 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   else for (int k2 = tid; k2 < A; k2 += 256) tk(k2, 0);
   __syncthreads();
   AT* dwr = reinterpret_cast<AT*>(p.dWhr) + (size_t)b * p.ld_dwhr;
-  for (int k2 = tid; k2 < p.ld_dwhr; k2 += 256) {
+  for (int k2 = tid; k2 < A; k2 += 256) {
     float a = 0.f, c = 0.f;
-    if (k2 < A) for (int j = 0; j < G; ++j) { a += spart[j * A + k2]; c += spart[(G + j) * A + k2]; }
-    dwr[k2] = (AT)a;
-    if (k2 < A) {
-      const size_t o2 = (size_t)b * A + k2;
-      p.dwacc[o2] = p.first ? c : p.dwacc[o2] + c;
-    }
+    for (int j = 0; j < G; ++j) { a += spart[j * A + k2]; c += spart[(G + j) * A + k2]; }
+    dwr[ch * A + k2] = (AT)a;
+    const size_t o2 = ((size_t)ch * p.B + b) * A + k2;
+    p.dwacc[o2] = p.first ? c : p.dwacc[o2] + c;
   }
+  if (ch == 0) for (int j = RN_TCH * A + tid; j < p.ld_dwhr; j += 256) dwr[j] = (AT)0.f;
   if (p.last)
-    for (int t = 0; t < T; ++t)
+    for (int i = 0; i < nt; ++i) {
+      const int t = ch + i * RN_TCH;
       for (int j = A + tid; j < p.ld_dUd; j += 256) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + j] = (AT)0.f;
+    }
 }
 
 // =============================================================================================
