@@ -754,7 +754,7 @@ static int fwd_rec_local(recnet_handle* h, const float* enc, int T, int train, h
     a.s = s; a.S = Sa; a.slab = s > 0 ? h->slab : nullptr;
     a.Whr_out = h->Whr + (size_t)s * B * RA; a.beta_out = h->beta + (size_t)s * B * T;
     a.xcat = at_off(h, h->Xcat_r, (size_t)s * B * ldHR);
-    LAUNCH_AT(h, loc_attn_fwd_kernel, dim3(B), dim3(256), sm, st, a);
+    LAUNCH_AT(h, loc_attn_fwd_kernel, dim3(B, cdiv(H, 256)), dim3(256), sm, st, a);
     const int Sb = gemm_slabs(h, RN_TAG_REC_FWD, at_off(h, h->Xcat_r, (size_t)s * B * ldHR), ldHR, h->Wihh_w, 0, ldHR, B, 4 * R, H + R, st);
     lstm_pw(h, R, Sb, 4 * R, nullptr, 0, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0,
             s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->Hr + (size_t)s * B * R,

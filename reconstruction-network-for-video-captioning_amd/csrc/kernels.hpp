@@ -775,17 +775,26 @@ struct LocAttnArgs {
   void* xcat; int xcat_ld;   // AT row [x (H) | hr (R) | pad]: x -> [0,H)
   DropDesc dd;
 };
+// grid (B, ceil(H / 256)): every workgroup recomputes the (cheap) scores beta, then each thread owns one column h
 template <typename AT>
 __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* swh = smem;            // [A]
   float* sbeta = swh + p.A;     // [T]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y * 256 + tid;
   const size_t zs = (size_t)p.B * p.A;
+  // Hs[t', b, h] for this thread's column: issued before anything that depends on the scores (T <= 32 fast path)
+  float hv[32];
+  const bool fastT = p.T <= 32;
+  if (fastT) {
+#pragma unroll
+    for (int t = 0; t < 32; ++t) hv[t] = (t < p.T && h < p.H) ? p.Hs[((size_t)t * p.B + b) * p.H + h] : 0.f;
+  }
   for (int k = tid; k < p.A; k += 256) {
     const float v = p.slab ? sum_strided(p.slab + (size_t)b * p.A + k, zs, p.S) : 0.f;
     swh[k] = v;
-    p.Whr_out[(size_t)b * p.A + k] = v;
+    if (blockIdx.y == 0) p.Whr_out[(size_t)b * p.A + k] = v;
   }
   __syncthreads();
   for (int t = wave; t < p.T; t += 4) {
@@ -793,17 +802,24 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
     float s = 0.f;
     for (int k = lane; k < p.A; k += 64) s += p.w[k] * rn_tanh(swh[k] + ud[k] + p.ab[k]);
     s = wave_sum(s);
-    if (lane == 0) { sbeta[t] = s; p.beta_out[(size_t)b * p.T + t] = s; }
+    if (lane == 0) { sbeta[t] = s; if (blockIdx.y == 0) p.beta_out[(size_t)b * p.T + t] = s; }
   }
   __syncthreads();
+  if (h >= p.H) return;
   const uint32_t key = drop_key(p.dd);
   const float invT = 1.0f / (float)p.T;
   AT* xr = reinterpret_cast<AT*>(p.xcat) + (size_t)b * p.xcat_ld;
-  for (int h = tid; h < p.H; h += 256) {
-    float s = 0.f;
-    for (int t = 0; t < p.T; ++t) s += sbeta[t] * p.Hs[((size_t)t * p.B + b) * p.H + h];
-    xr[h] = (AT)(s * invT * drop_at(p.dd, key, p.s, b, p.H, h));
+  float s0 = 0.f, s1 = 0.f;
+  if (fastT) {
+#pragma unroll
+    for (int t = 0; t < 32; t += 2) {
+      if (t < p.T) s0 += sbeta[t] * hv[t];
+      if (t + 1 < p.T) s1 += sbeta[t + 1] * hv[t + 1];
+    }
+  } else {
+    for (int t = 0; t < p.T; ++t) s0 += sbeta[t] * p.Hs[((size_t)t * p.B + b) * p.H + h];
   }
+  xr[h] = (AT)((s0 + s1) * invT * drop_at(p.dd, key, p.s, b, p.H, h));
 }
 
 // Attention backward of reconstructor step s, one workgroup per (caption, chunk of decoder steps t'), RN_TCH
