@@ -27,7 +27,8 @@ static inline int ew_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)
 struct OptGroup {
   std::vector<TensorDesc> tab;      // host copy
   std::vector<int2> chunks;
-  TensorDesc* d_tab = nullptr; int2* d_chunks = nullptr;
+  TensorDesc* d_tab = nullptr; int2* d_chunks = nullptr; PackDesc* d_pack = nullptr;
+  std::vector<PackDesc> pack;
   float* d_partial = nullptr; float* d_pnorm = nullptr; float* d_gnorm = nullptr;
   int ntens = 0, nchunks = 0;
   bool bound = false;
@@ -164,6 +165,7 @@ static size_t carve(recnet_handle* h, char* base) {
                             : (RA * R + RA * H + 2 * RA + 4 * R * 2 * H + 4 * R * R + 8 * R + R * R + R);
     size_t maxch = nparams / RN_CHUNK + 16;
     o.d_tab = (TensorDesc*)take(16 * sizeof(TensorDesc) / 4);
+    o.d_pack = (PackDesc*)take(16 * sizeof(PackDesc) / 4);
     o.d_chunks = (int2*)take(maxch * 2);
     o.d_partial = take(maxch);
     o.d_pnorm = take(16);
@@ -232,9 +234,42 @@ int recnet_set_shard(recnet_handle* h, int32_t global_batch_size, int32_t batch_
 
 size_t recnet_workspace_bytes(const recnet_handle* h) { return h ? h->need : 0; }
 
+static inline void* at_off(const recnet_handle* h, void* p, size_t elems);
+// destinations of the packed operand images, per parameter tensor (same order as dec_list / rec_list)
+static void build_pack_tables(recnet_handle* h, int g) {
+  OptGroup& o = h->og[g];
+  o.pack.assign(o.ntens, PackDesc());
+  for (auto& pd : o.pack) { pd.ndst = 0; pd.cols = 1; }
+  auto add = [&](int t, int cols, void* dst, int ld, int c0, int nc) {
+    PackDesc& pd = o.pack[t]; pd.cols = cols;
+    PackDst& d = pd.d[pd.ndst++]; d.dst = dst; d.ld = ld; d.c0 = c0; d.nc = nc; d.pad = 0;
+  };
+  const int H = h->H, D = h->D, E = h->E, A = h->A, R = h->R, RA = h->RA;
+  if (g == 0) {
+    for (int j = 0; j < RN_FCH; ++j) add(2, H, at_off(h, h->Wcomb, (size_t)(4 * H + j * A) * h->ldH), h->ldH, 0, H);   // attn_W
+    add(3, D, h->U_w, h->ldD, 0, D);                                        // attn_U
+    add(5, E + D, h->We_w, h->ldE, 0, E); add(5, E + D, h->Wc_w, h->ldD, E, D);   // rnn.weight_ih_l0
+    add(6, H, h->Wcomb, h->ldH, 0, H);                                      // rnn.weight_hh_l0
+    add(9, H, h->Wo_w, h->ldH, 0, H);                                       // out.weight
+  } else if (h->kind == RECNET_REC_GLOBAL) {
+    add(0, 2 * H, h->Wih_a, h->ldH, 0, H); add(0, 2 * H, h->Wih_b, h->ldH, H, H);
+    add(1, R, h->Whh_w, h->ldR, 0, R);
+    add(4, R, h->Wor_w, h->ldR, 0, R);
+  } else if (h->kind == RECNET_REC_LOCAL) {
+    add(1, R, h->Wr_w, h->ldR, 0, R);
+    for (int j = 0; j < RN_TCH; ++j) add(1, R, at_off(h, h->Wr4_w, (size_t)j * RA * h->ldR), h->ldR, 0, R);
+    add(2, H, h->Ur_w, h->ldH, 0, H);
+    add(4, H, h->Wihh_w, h->ldHR, 0, H);
+    add(5, R, at_off(h, h->Wihh_w, (size_t)H), h->ldHR, 0, R);
+    add(8, R, h->Wor_w, h->ldR, 0, R);
+  }
+}
+
 static int upload_tables(recnet_handle* h, int g) {
   OptGroup& o = h->og[g];
   if (!o.bound || !h->ws) return RECNET_OK;
+  build_pack_tables(h, g);
+  HIPCHK(hipMemcpy(o.d_pack, o.pack.data(), o.pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(o.d_tab, o.tab.data(), o.tab.size() * sizeof(TensorDesc), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(o.d_chunks, o.chunks.data(), o.chunks.size() * sizeof(int2), hipMemcpyHostToDevice));
   return RECNET_OK;
@@ -348,7 +383,7 @@ int recnet_bind_reconstructor(recnet_handle* h, const recnet_reconstructor_tenso
   do { if ((h)->lp) hipLaunchKernelGGL((kern<bf16_t>), grid, block, smem, st, __VA_ARGS__);     \
        else hipLaunchKernelGGL((kern<float>), grid, block, smem, st, __VA_ARGS__); } while (0)
 
-static inline void* at_off(const recnet_handle* h, void* p, size_t elems) {
+inline void* at_off(const recnet_handle* h, void* p, size_t elems) {
   return (char*)p + elems * (h->lp ? 2 : 4);
 }
 
@@ -873,10 +908,11 @@ static int optimizer_step(recnet_handle* h, int flags, hipStream_t st) {
     hp.one_m_b1 = (float)(1.0 - h->c.adam_beta1); hp.beta2f = (float)h->c.adam_beta2; hp.one_m_b2 = (float)(1.0 - h->c.adam_beta2);
     hp.amsgrad = g == 0 ? h->c.decoder_use_amsgrad : h->c.reconstructor_use_amsgrad;
     hp.reg_coef = coef;
+    // the kernel also writes the packed operand images of the tensors it updates (no separate re-pack pass)
     hipLaunchKernelGGL(adam_chunk_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, hp, o.d_pnorm, clip,
-                       (const int32_t*)(h->ctrl + 1));
+                       (const int32_t*)(h->ctrl + 1), (const PackDesc*)o.d_pack, h->lp);
   }
-  return pack_weights(h, st);
+  return RECNET_OK;
 }
 
 // ================================================================================================

@@ -931,6 +931,11 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
 // norms, clipping and multi-tensor Adam (train.py:69,103,129,149,186,270-273)
 // =============================================================================================
 struct TensorDesc { float* p; float* g; float* m; float* v; float* vmax; int n; int chunk0; int nchunks; int pad; };
+// Where the packed operand image(s) of a parameter tensor live: element (r, c) of a [rows][cols] tensor goes to
+// dst[r * ld + (c - c0)] for every destination whose column window [c0, c0 + nc) contains c.  The Adam kernel
+// writes them directly, so the weights are re-packed (bf16) in the same pass that updates them.
+struct PackDst { void* dst; int ld; int c0; int nc; int pad; };
+struct PackDesc { int ndst; int cols; PackDst d[6]; };
 #define RN_CHUNK 8192
 
 // partial[chunk] = sum over the chunk of p^2 (mode 0) or (g + coef * p / ||p||)^2 (mode 1)
@@ -1004,7 +1009,8 @@ struct AdamHyper { double lr, beta1, beta2; float eps, wd, one_m_b1, beta2f, one
 // p <- p - (lr / bc1) * m / (sqrt(v̂) / sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
                                                          AdamHyper hp, const float* __restrict__ pnorm,
-                                                         const float* __restrict__ clip, const int32_t* __restrict__ step_ptr) {
+                                                         const float* __restrict__ clip, const int32_t* __restrict__ step_ptr,
+                                                         const PackDesc* __restrict__ pack, int lp) {
   __shared__ float sc[2];
   if (threadIdx.x == 0) {
     const double st = (double)(*step_ptr);
@@ -1021,6 +1027,8 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
   const float nrm = pnorm ? pnorm[ch.x] : 0.f;
   const float k = (nrm > 0.f) ? hp.reg_coef / nrm : 0.f;
   const float cl = clip ? *clip : 1.f;
+  PackDesc pk; pk.ndst = 0; pk.cols = 1;
+  if (pack) pk = pack[ch.x];
   for (int i = ch.y + threadIdx.x; i < end; i += 256) {
     const float p = td.p[i];
     float g = (td.g[i] + k * p) * cl;
@@ -1032,6 +1040,16 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
     float vh = v;
     if (hp.amsgrad) { vh = fmaxf(td.vmax[i], v); td.vmax[i] = vh; }
     const float denom = sqrtf(vh) / bc2s + hp.eps;
-    td.p[i] = p - step_size * (m / denom);
+    const float pn = p - step_size * (m / denom);
+    td.p[i] = pn;
+    if (pk.ndst) {
+      const int r = i / pk.cols, c = i - r * pk.cols;
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+        if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc) {
+          const size_t o = (size_t)r * pk.d[d].ld + (c - pk.d[d].c0);
+          if (lp) reinterpret_cast<bf16_t*>(pk.d[d].dst)[o] = (bf16_t)pn; else reinterpret_cast<float*>(pk.d[d].dst)[o] = pn;
+        }
+    }
   }
 }
