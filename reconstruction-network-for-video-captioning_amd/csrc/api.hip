@@ -434,6 +434,12 @@ static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const v
 }
 template <typename ST>
 static void colsum_t(const ST* X, int rows, int cols, int ld, float* out, hipStream_t st) {
+  if (rows >= 64 && (ld & 7) == 0 && (((uintptr_t)X) & 15) == 0) {
+    int rs = rows / 96; rs = rs < 1 ? 1 : (rs > 64 ? 64 : rs);
+    hipMemsetAsync(out, 0, (size_t)cols * 4, st);
+    hipLaunchKernelGGL(colsum_vec_kernel<ST>, dim3(cdiv(cols, 512), rs), dim3(256), 0, st, X, rows, cols, ld, out);
+    return;
+  }
   int rs = rows >= 512 ? 8 : 1;
   if (rs > 1) hipMemsetAsync(out, 0, (size_t)cols * 4, st);
   hipLaunchKernelGGL(colsum_kernel<ST>, dim3(cdiv(cols, 64), rs), dim3(256), 0, st, X, rows, cols, ld, out, rs > 1 ? 1 : 0);

@@ -70,6 +70,46 @@ template <> struct Raw8<float> {
   __device__ __forceinline__ float at(int j) const { return j < 4 ? a[j] : b[j - 4]; }
 };
 
+// out[c] += sum_r X[r*ld + c], 16-byte loads: a wave covers 512 columns of one row per instruction, the four waves of a
+// workgroup take rows r0 + w, r0 + w + 4, ...; grid (ceil(cols / 512), row splits); `out` pre-zeroed (float atomics,
+// one per column per workgroup).  Needs ld % 8 == 0 and a 16-byte aligned base (true for every operand buffer).
+template <typename ST>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const ST* __restrict__ X, int rows, int cols, int ld,
+                                                         float* __restrict__ out) {
+  __shared__ float sm[4][64][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + lane * 8;
+  const int rs = gridDim.y, per = (rows + rs - 1) / rs;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c0 < cols) {
+    int r = r0 + wave;
+    for (; r + 4 < r1; r += 8) {          // two rows in flight
+      Raw8<ST> a, b;
+      a.load(X + (size_t)r * ld + c0); b.load(X + (size_t)(r + 4) * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += a.at(j) + b.at(j);
+    }
+    for (; r < r1; r += 4) {
+      Raw8<ST> a; a.load(X + (size_t)r * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += a.at(j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sm[wave][lane][j] = acc[j];
+  __syncthreads();
+  if (wave == 0 && c0 < cols) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = sm[0][lane][j] + sm[1][lane][j] + sm[2][lane][j] + sm[3][lane][j];
+      if (c0 + j < cols) atomicAdd(out + c0 + j, v);
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t drop_key(const DropDesc& dd) { return rn_site_key(*dd.seed, dd.site); }
 __device__ __forceinline__ float drop_at(const DropDesc& dd, uint32_t key, int t, int b, int N, int j) {
   const uint32_t idx = ((uint32_t)t * (uint32_t)dd.Bg + (uint32_t)(dd.boff + b)) * (uint32_t)N + (uint32_t)j;
