@@ -989,7 +989,24 @@ __global__ __launch_bounds__(256) void sumsq_chunk_kernel(const TensorDesc* __re
   float k = 0.f;
   if (mode == 1) { const float nrm = pnorm[ch.x]; k = nrm > 0.f ? coef / nrm : 0.f; }
   float s = 0.f;
-  for (int i = ch.y + threadIdx.x; i < end; i += 256) {
+  // chunks start at multiples of RN_CHUNK elements of a 16-byte aligned tensor: float4 loads for the whole quads
+  const bool al = ((((uintptr_t)td.p) | ((uintptr_t)(mode ? td.g : td.p))) & 15) == 0;
+  int i0 = ch.y;
+  if (al) {
+    const int nq = (end - ch.y) >> 2;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(td.p + ch.y);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>((mode ? td.g : td.p) + ch.y);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      const f32x4 pv = p4[q];
+      f32x4 x = pv;
+      if (mode) { const f32x4 gv = g4[q]; x = gv + k * pv; }
+      s += x[0] * x[0]; s1 += x[1] * x[1]; s2 += x[2] * x[2]; s3 += x[3] * x[3];
+    }
+    s = (s + s1) + (s2 + s3);
+    i0 = ch.y + (nq << 2);
+  }
+  for (int i = i0 + threadIdx.x; i < end; i += 256) {
     const float x = mode == 0 ? td.p[i] : td.g[i] + k * td.p[i];
     s += x * x;
   }
