@@ -511,6 +511,12 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
 }
 
 static void launch_dec_cell(recnet_handle* h, const DecCellArgs& a, hipStream_t st) {
+  static const int vec_env = getenv("RN_DEC_VEC") ? atoi(getenv("RN_DEC_VEC")) : 1;
+  if (vec_env && h->lp && (h->H & 7) == 0 && h->F <= 32 && h->A <= 128 && (h->ld4H & 7) == 0) {
+    const size_t smv = (size_t)(h->A + ((h->F + 3) & ~3) + 4 * 512 + 16) * 4;
+    hipLaunchKernelGGL(dec_cell_vec_kernel<bf16_t>, dim3(h->B, cdiv(h->H, 512)), dim3(256), smv, st, a);
+    return;
+  }
   // units per workgroup: 256 (1024 threads) when H allows, so a caption is covered by H/256 workgroups
   int uc = h->H >= 256 ? 256 : (h->H >= 128 ? 128 : 64);
   static const char* e = getenv("RN_DEC_UC");

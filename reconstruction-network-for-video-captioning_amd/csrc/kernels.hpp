@@ -388,6 +388,112 @@ __global__ __launch_bounds__(1024) void dec_cell_kernel(const DecCellArgs p) {
     for (int j = H + tid; j < p.ld_hlp; j += NT) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + j] = (AT)0.f;
 }
 
+// Vector form of dec_cell_kernel for the bf16 path (H % 8 == 0, F <= 32, A <= 128): wave = gate, each lane owns 8
+// consecutive hidden units, so every P / Xe / slab access is a 16-byte load and a wave-instruction covers 1 KiB of
+// one row (the generic kernel reads P with 2-byte loads, 128 B per instruction).  One workgroup covers 512 units
+// x 4 gates of one caption; all loads are issued before the scores are computed.
+template <typename AT>
+__global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* swh = smem;            // [A]
+  float* sa = swh + p.A;        // [F] (+ pad to 16 B)
+  float* spre = sa + ((p.F + 3) & ~3);   // [4][512]
+  const int b = blockIdx.x, u0 = blockIdx.y * 512, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
+  const size_t zs = (size_t)p.B * WS;
+  const int u = u0 + lane * 8;
+  const bool live = u < H;                    // H % 8 == 0: a lane's 8 units are all inside or all outside
+  const int col = g * H + u;
+  Raw8<AT> pv[32];
+  float pre[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pre[j] = 0.f;
+  if (live) {
+    const AT* pp = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp + col;
+#pragma unroll
+    for (int f = 0; f < 32; ++f) { if (f < F) pv[f].load(pp + (size_t)f * p.ldp); else pv[f].zero(); }
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p.Xe + (size_t)b * W4 + col);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(p.Xe + (size_t)b * W4 + col + 4);
+    pre[0] = x0[0]; pre[1] = x0[1]; pre[2] = x0[2]; pre[3] = x0[3]; pre[4] = x1[0]; pre[5] = x1[1]; pre[6] = x1[2]; pre[7] = x1[3];
+    if (p.slab) {
+      for (int z = 0; z < p.S; ++z) {
+        const float* sp = p.slab + z * zs + (size_t)b * WS + col;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        pre[0] += s0[0]; pre[1] += s0[1]; pre[2] += s0[2]; pre[3] += s0[3];
+        pre[4] += s1[0]; pre[5] += s1[1]; pre[6] += s1[2]; pre[7] += s1[3];
+      }
+    }
+  }
+  // score operands: wave g handles frames g, g + 4, ...; lane handles k = lane, lane + 64
+  float uvr[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int f = g + 4 * i;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = lane + 64 * j;
+      uvr[i][j] = (f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+    }
+  }
+  for (int k = tid; k < A; k += 256) {
+    const float v = p.slab ? sum_strided(p.slab + (size_t)b * WS + W4 + k, zs, p.S) : 0.f;
+    swh[k] = v;
+    if (p.Wh_out && blockIdx.y == 0) p.Wh_out[(size_t)b * A + k] = v;
+  }
+  __syncthreads();
+  {
+    float wk[2], bk[2], hk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = lane + 64 * j;
+      wk[j] = k < A ? p.w[k] : 0.f; bk[j] = k < A ? p.ab[k] : 0.f; hk[j] = k < A ? swh[k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = g + 4 * i;
+      if (f < F) {
+        float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
+        if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
+        s = wave_sum(s);
+        if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+      }
+    }
+  }
+  __syncthreads();
+  if (live) {
+    float c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = 0.f;
+#pragma unroll
+    for (int f = 0; f < 32; ++f)
+      if (f < F) {
+        const float a = sa[f];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] += a * pv[f].at(j);
+      }
+    const float invF = 1.0f / (float)F;
+    float* dst = spre + g * 512 + lane * 8;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{pre[0] + c[0] * invF, pre[1] + c[1] * invF, pre[2] + c[2] * invF, pre[3] + c[3] * invF};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{pre[4] + c[4] * invF, pre[5] + c[5] * invF, pre[6] + c[6] * invF, pre[7] + c[7] * invF};
+  }
+  __syncthreads();
+  for (int ul = tid; ul < 512; ul += 256) {
+    const int uu = u0 + ul;
+    if (uu >= H) break;
+    const size_t o = (size_t)b * H + uu;
+    const LstmOut r = lstm_point(spre[ul], spre[512 + ul], spre[1024 + ul], spre[1536 + ul], p.c_prev ? p.c_prev[o] : 0.f);
+    p.h_out[o] = r.h;
+    p.c_out[o] = r.c;
+    if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)r.h;
+    if (p.acts) {
+      float* a = p.acts + (size_t)b * W4 + uu;
+      a[0] = r.i; a[H] = r.f; a[2 * H] = r.g; a[3 * H] = r.o;
+    }
+  }
+  if (p.h_lp && blockIdx.y == 0)
+    for (int j = H + tid; j < p.ld_hlp; j += 256) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + j] = (AT)0.f;
+}
+
 // =============================================================================================
 // decoder recurrent step, backward: one workgroup per (caption, frame chunk), RN_FCH chunks.
 //   dh_t = dHs[t] + (dgates_{t+1} | dWh_{t+1}) . [W_hh ; W ; .. ; W] (split-K slabs) -> LSTM pointwise backward
