@@ -140,10 +140,27 @@ int recnet_pack_weights(recnet_handle* h, void* stream);
 
 /* ---- Decoder.forward, models/decoder.py:45-70: ONE decode step (the API eval.py's greedy / beam
  * search drive, eval.py:22,48).  tokens [B] int64; h_in/c_in/h_out/c_out [B,H]; enc [B,F,D];
- * logits [B,V].  `train` != 0 applies the embedding / logits dropout with (seed, t). */
+ * logits [B,V].  `train` != 0 applies the embedding / logits dropout with (seed, t).  enc == NULL reuses the invariants
+ * of the previous call / of recnet_decoder_prepare. */
 int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_in, const float* c_in,
                         const float* enc, float* logits, float* h_out, float* c_out, int32_t train,
                         uint32_t seed, int32_t t, void* stream);
+
+/* Compute the loop invariants of `enc` once (Uv = enc . U^T, P = enc . W_ih[:, E:]^T); later recnet_decoder_step calls
+ * with enc == NULL reuse them (the search loops of eval.py call the step 31 x beam times on the same features). */
+int recnet_decoder_prepare(recnet_handle* h, const float* enc, void* stream);
+
+/* ---- greedy_search, eval.py:19-33, as one device-side loop (no per-sample Python, no host sync): start from <SOS> and
+ * zero state (eval.py:131-141), argmax feedback.  tokens_out [caption_max_len+1][B] int64 (time-major);
+ * n_steps_out (device int32) = number of steps the reference's loop produces (it stops after the first step whose
+ * tokens are all <PAD>, eval.py:30): rows >= n_steps are to be ignored. */
+int recnet_greedy_search(recnet_handle* h, const float* enc, int64_t* tokens_out, int32_t* n_steps_out, void* stream);
+/* ---- beam_search, eval.py:36-120: log(sigmoid(logit)) scores (eval.py:61), cumulative score divided by
+ * length^0.7 at every step (eval.py:53-59, length = position of the hypothesis' last <EOS>, else t+1), top beam_width of
+ * beam_width * V continuations (eval.py:64).  best_out [caption_max_len+1][B] = the top-1 hypothesis (eval.py:119),
+ * n_steps_out as above (eval.py:116).  beam_width <= 8. */
+int recnet_beam_search(recnet_handle* h, const float* enc, int32_t beam_width, int64_t* best_out, int32_t* n_steps_out,
+                       void* stream);
 
 /* ---- forward_decoder, train.py:17-75 (teacher forcing, train.py:38,45).
  * enc [B,F,D]; targets [caption_max_len+1, B] int64 (time-major, <PAD>=0, <EOS>=2);

@@ -7,6 +7,7 @@ Host-side mirror of the reference interface for the hot path:
   train.py forward_decoder / forward_*_reconstructor / build_decoder / build_reconstructor
                                              -> api.*
   train.py:248-273 (the step body)           -> api.TrainStep (single stream, hipGraph-capturable)
+  eval.py greedy_search / beam_search        -> search.* (device-side loops)
 All compute goes through csrc/librecnet_hip.so (C ABI: include/recnet_hip.h).
 """
 from .config import TrainConfig, make_config  # noqa: F401
@@ -15,3 +16,4 @@ from .api import (build_decoder, build_reconstructor, forward_decoder, forward_g
                   forward_local_reconstructor, clip_grad_norm_, TrainStep, GraphedStep, FusedAdam, decode_len,
                   step_weights)
 from .dp import DataParallelTrainStep, shard_bounds  # noqa: F401
+from .search import greedy_search, beam_search  # noqa: F401

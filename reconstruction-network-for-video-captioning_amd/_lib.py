@@ -124,3 +124,6 @@ EXPORTS["recnet_gemm_bf16"] = (_i, [C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_
                                   C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_train_step_part_dev"] = (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_uint32,
                                               C.c_void_p, C.c_void_p])
+EXPORTS["recnet_decoder_prepare"] = (_i, [C.c_void_p, C.c_void_p, C.c_void_p])
+EXPORTS["recnet_greedy_search"] = (_i, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
+EXPORTS["recnet_beam_search"] = (_i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p, C.c_void_p])

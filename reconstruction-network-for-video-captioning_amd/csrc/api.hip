@@ -59,6 +59,9 @@ struct recnet_handle {
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void *mpd_lp, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_a, *Wih_b, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
+  // inference search scratch (beam width <= 8)
+  float *sr_logits, *sr_scores, *sr_h[2], *sr_c[2], *sr_hn, *sr_cn, *sr_cum[2], *sr_vals;
+  int64_t *sr_tok[2], *sr_hist[2]; int32_t *sr_eos[2], *sr_idx;
   size_t gws_floats, slab_floats;
   float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
   hipStream_t s2 = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int overlap = 1;
@@ -134,6 +137,15 @@ static size_t carve(recnet_handle* h, char* base) {
   h->gws_floats = (size_t)16 << 20;   // 64 MiB of split-K slabs for the batched GEMMs
   h->gws = take(h->gws_floats);
   h->gws2 = take(h->gws_floats);
+  {
+    const size_t W = 8;
+    h->sr_logits = take(B * V); h->sr_scores = take(W * B * V);
+    for (int i = 0; i < 2; ++i) {
+      h->sr_h[i] = take(W * B * H); h->sr_c[i] = take(W * B * H); h->sr_cum[i] = take(W * B);
+      h->sr_tok[i] = (int64_t*)take(2 * W * B); h->sr_hist[i] = (int64_t*)take(2 * W * B * Tm); h->sr_eos[i] = (int32_t*)take(W * B);
+    }
+    h->sr_hn = take(W * B * H); h->sr_cn = take(W * B * H); h->sr_vals = take(W * B); h->sr_idx = (int32_t*)take(W * B);
+  }
   if (h->kind != RECNET_REC_NONE) {
     h->bsum_r = take(4 * R);
     h->dcr_carry = take(B * R);
@@ -471,6 +483,10 @@ static void param_norms(recnet_handle* h, int g, float* sum_out, hipStream_t st)
   hipLaunchKernelGGL(sumsq_chunk_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, 0, (const float*)nullptr, 0.f, o.d_partial);
   hipLaunchKernelGGL(tensor_norm_kernel, dim3(o.ntens), dim3(256), 0, st, o.d_tab, o.d_partial, o.d_pnorm);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(64), 0, st, o.d_pnorm, o.ntens, 0.f, (float*)nullptr, (float*)nullptr, sum_out);
+}
+__global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 // out = a + k * b
 __global__ void axpb_kernel(const float* a, const float* b, float k, float* out) { *out = *a + k * *b; }
@@ -937,16 +953,11 @@ int recnet_pack_weights(recnet_handle* h, void* stream) {
   return RECNET_OK;
 }
 
-int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_in, const float* c_in,
-                        const float* enc, float* logits, float* h_out, float* c_out, int32_t train,
-                        uint32_t seed, int32_t t, void* stream) {
-  REQUIRE_WS(h);
-  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
-  if (!tokens || !enc || !logits || !h_out || !c_out) return fail(RECNET_EINVAL, "null argument");
-  hipStream_t st = (hipStream_t)stream;
+// One decode step on already prepared loop invariants (Uv, P, bias sum): embedding, input projection,
+// h . [W_hh ; attn_W]^T, cell kernel, vocabulary projection.  Rows [0,B) / [B,2B) of Hs_lp are scratch.
+static int dec_step_core(recnet_handle* h, const int64_t* tokens, const float* h_in, const float* c_in, float* logits,
+                         float* h_out, float* c_out, int train, int t, hipStream_t st) {
   const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A, V = h->V;
-  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
-  dec_invariants(h, enc, st);   // the reference recomputes attn_U(encoder_outputs) on every call too (decoder.py:54)
   embed_fwd(h, nullptr, tokens, B, train, t, st);
   gemm(h, h->emb_lp, 0, h->ldE, h->We_w, 0, h->ldE, h->Xe, 4 * H, h->bsum_d, B, 4 * H, E, 1.f, 0, st);
   int S = 0;
@@ -965,6 +976,99 @@ int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_
     hipLaunchKernelGGL(logits_drop_kernel, dim3(ew_blocks((size_t)B * V)), dim3(256), 0, st, logits, B, V,
                        mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train), t);
   h->fwd_dec_done = 0;
+  return RECNET_OK;
+}
+
+int recnet_decoder_prepare(recnet_handle* h, const float* enc, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
+  if (!enc) return fail(RECNET_EINVAL, "null argument");
+  dec_invariants(h, enc, (hipStream_t)stream);
+  h->fwd_dec_done = 0;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_in, const float* c_in,
+                        const float* enc, float* logits, float* h_out, float* c_out, int32_t train,
+                        uint32_t seed, int32_t t, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
+  if (!tokens || !logits || !h_out || !c_out) return fail(RECNET_EINVAL, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
+  if (enc) dec_invariants(h, enc, st);   // enc == NULL: reuse what recnet_decoder_prepare / the last call computed
+  int r = dec_step_core(h, tokens, h_in, c_in, logits, h_out, c_out, train, t, st); if (r) return r;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_greedy_search(recnet_handle* h, const float* enc, int64_t* tokens_out, int32_t* n_steps_out, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
+  if (!enc || !tokens_out || !n_steps_out) return fail(RECNET_EINVAL, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = h->B, H = h->H, V = h->V, Tm = h->Tm;
+  dec_invariants(h, enc, st);
+  hipMemsetAsync(n_steps_out, 0, 4, st);
+  hipMemsetAsync(h->sr_h[0], 0, (size_t)B * H * 4, st);
+  hipMemsetAsync(h->sr_c[0], 0, (size_t)B * H * 4, st);
+  // <SOS> = 1 for every caption (eval.py:131)
+  hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, h->sr_tok[0], (int64_t)1, B);
+  const int64_t* tok = h->sr_tok[0];
+  int cur = 0;
+  for (int t = 0; t < Tm; ++t) {
+    int r = dec_step_core(h, tok, h->sr_h[cur], h->sr_c[cur], h->sr_logits, h->sr_h[cur ^ 1], h->sr_c[cur ^ 1], 0, t, st);
+    if (r) return r;
+    int64_t* out_t = tokens_out + (size_t)t * B;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, st, h->sr_logits, V, V, out_t);
+    hipLaunchKernelGGL(search_stop_kernel, dim3(1), dim3(256), 0, st, out_t, B, t, n_steps_out);
+    tok = out_t; cur ^= 1;
+  }
+  hipLaunchKernelGGL(search_finish_kernel, dim3(1), dim3(1), 0, st, n_steps_out, Tm);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_beam_search(recnet_handle* h, const float* enc, int32_t beam_width, int64_t* best_out, int32_t* n_steps_out,
+                       void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
+  if (!enc || !best_out || !n_steps_out) return fail(RECNET_EINVAL, "null argument");
+  if (beam_width < 1 || beam_width > 8) return fail(RECNET_EINVAL, "beam_width must be in [1, 8]");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = h->B, H = h->H, V = h->V, Tm = h->Tm, bw = beam_width;
+  dec_invariants(h, enc, st);
+  hipMemsetAsync(n_steps_out, 0, 4, st);
+  // one initial hypothesis per caption: <SOS>, zero state, log-prob 0, no <EOS> (eval.py:37-42)
+  hipMemsetAsync(h->sr_h[0], 0, (size_t)B * H * 4, st);
+  hipMemsetAsync(h->sr_c[0], 0, (size_t)B * H * 4, st);
+  hipMemsetAsync(h->sr_cum[0], 0, (size_t)B * 4, st);
+  hipMemsetAsync(h->sr_hist[0], 0, (size_t)B * Tm * 8, st);
+  hipMemsetAsync(h->sr_eos[0], 0xFF, (size_t)B * 4, st);       // -1
+  hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, h->sr_tok[0], (int64_t)1, B);
+  int cur = 0, nb = 1;
+  for (int t = 0; t < Tm; ++t) {
+    for (int i = 0; i < nb; ++i) {
+      int r = dec_step_core(h, h->sr_tok[cur] + (size_t)i * B, h->sr_h[cur] + (size_t)i * B * H, h->sr_c[cur] + (size_t)i * B * H,
+                            h->sr_logits, h->sr_hn + (size_t)i * B * H, h->sr_cn + (size_t)i * B * H, 0, t, st);
+      if (r) return r;
+      hipLaunchKernelGGL(beam_score_kernel, dim3(B), dim3(256), 0, st, h->sr_logits, h->sr_cum[cur], h->sr_eos[cur], h->sr_scores,
+                         B, V, nb, i, t);
+    }
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(B), dim3(256), 0, st, h->sr_scores, nb * V, bw, h->sr_vals, h->sr_idx);
+    BeamUpdArgs u;
+    u.B = B; u.H = H; u.V = V; u.Tm = Tm; u.bw = bw; u.t = t;
+    u.vals = h->sr_vals; u.idx = h->sr_idx; u.h_next = h->sr_hn; u.c_next = h->sr_cn;
+    u.last_eos_old = h->sr_eos[cur]; u.hist_old = h->sr_hist[cur];
+    u.h_new = h->sr_h[cur ^ 1]; u.c_new = h->sr_c[cur ^ 1]; u.cum_new = h->sr_cum[cur ^ 1];
+    u.last_eos_new = h->sr_eos[cur ^ 1]; u.hist_new = h->sr_hist[cur ^ 1]; u.tok_new = h->sr_tok[cur ^ 1];
+    hipLaunchKernelGGL(beam_update_kernel, dim3(bw, B), dim3(128), 0, st, u);
+    hipLaunchKernelGGL(search_stop_kernel, dim3(1), dim3(256), 0, st, h->sr_tok[cur ^ 1], bw * B, t, n_steps_out);
+    cur ^= 1; nb = bw;
+  }
+  hipLaunchKernelGGL(search_finish_kernel, dim3(1), dim3(1), 0, st, n_steps_out, Tm);
+  hipLaunchKernelGGL(beam_best_kernel, dim3(cdiv(B * Tm, 256)), dim3(256), 0, st, h->sr_hist[cur], best_out, B, Tm);
   LAUNCH_OK();
   return RECNET_OK;
 }

@@ -186,11 +186,39 @@ class Engine:
     def pack_weights(self):
         _lib.check(self.lib.recnet_pack_weights(self.handle, _stream()), "recnet_pack_weights")
 
+    def decoder_prepare(self, enc):
+        d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
+        _lib.check(self.lib.recnet_decoder_prepare(self.handle, _ptr(enc), _stream()), "recnet_decoder_prepare")
+
+    def greedy_search(self, enc):
+        """eval.py:19-33 on the device.  Returns (tokens [Tm, B] int64, n_steps int32[1]) device tensors."""
+        d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
+        Tm = self.hyper["caption_max_len"] + 1
+        toks = torch.zeros(Tm, d["B"], dtype=torch.int64, device=self.device)
+        n = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.recnet_greedy_search(self.handle, _ptr(enc), _ptr(toks), _ptr(n), _stream()),
+                   "recnet_greedy_search")
+        return toks, n
+
+    def beam_search(self, enc, beam_width):
+        """eval.py:36-120 on the device.  Returns (best [Tm, B] int64, n_steps int32[1])."""
+        d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
+        Tm = self.hyper["caption_max_len"] + 1
+        best = torch.zeros(Tm, d["B"], dtype=torch.int64, device=self.device)
+        n = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.recnet_beam_search(self.handle, _ptr(enc), int(beam_width), _ptr(best), _ptr(n), _stream()),
+                   "recnet_beam_search")
+        return best, n
+
     def decoder_step(self, tokens, h_in, c_in, enc, train=False, seed=0, t=0):
         d = self.dims
         B = d["B"]
         _chk_tensor(tokens, (B,), torch.int64, "tokens")
-        _chk_tensor(enc, (B, d["F"], d["D"]), torch.float32, "encoder_outputs")
+        if enc is not None:
+            _chk_tensor(enc, (B, d["F"], d["D"]), torch.float32, "encoder_outputs")
         logits = torch.empty(B, d["V"], dtype=torch.float32, device=self.device)
         h_out = torch.empty(B, d["H"], dtype=torch.float32, device=self.device)
         c_out = torch.empty_like(h_out)

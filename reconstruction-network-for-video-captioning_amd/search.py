@@ -1,0 +1,53 @@
+"""Inference search with the reference's signatures (eval.py:19-33 greedy_search, eval.py:36-120 beam_search),
+run as device-side loops in the HIP library (recnet_greedy_search / recnet_beam_search): no per-sample Python
+list building, no host synchronisation per step — one read-back at the end.
+
+Differences from the reference that a caller can observe: `input` / `hidden` must be the start state the
+reference's own `evaluate()` builds (<SOS> tokens, zero hidden state, eval.py:131-141) — that is the only
+state the reference ever passes; beam_width <= 8."""
+import torch
+
+from .engine import Engine
+
+
+def _engine(decoder, encoder_outputs):
+    B, F = encoder_outputs.shape[0], encoder_outputs.shape[1]
+    key = (B, F, encoder_outputs.device)
+    eng = decoder._step_engines.get(key)
+    if eng is None:
+        eng = Engine(decoder.dims(B, F), None, decoder.precision, decoder.hyper(), device=encoder_outputs.device)
+        eng.bind_decoder({k: v.data for k, v in decoder.named_tensors().items()})
+        decoder._step_engines[key] = eng
+    pver = tuple(p._version for p in decoder.parameters())
+    if getattr(eng, "_pver", None) != pver:
+        eng.pack_weights()
+        eng._pver = pver
+    eng._inv_sig = None          # the search recomputes the invariants itself
+    return eng
+
+
+def _check_start(config, input, hidden):
+    if not bool((input == 1).all()):
+        raise NotImplementedError("search starts from <SOS> (eval.py:131)")
+    h = hidden[0] if isinstance(hidden, (tuple, list)) else hidden
+    if bool((h != 0).any()):
+        raise NotImplementedError("search starts from the zero hidden state (eval.py:134-141)")
+
+
+def greedy_search(config, decoder, input, hidden, encoder_outputs):
+    """eval.py:19-33.  Returns output_indices: list over steps of lists over the batch (python ints), like the
+    reference's list of lists of 0-d tensors."""
+    _check_start(config, input, hidden)
+    eng = _engine(decoder, encoder_outputs)
+    toks, n = eng.greedy_search(encoder_outputs.contiguous())
+    n = int(n.item())
+    return toks[:n].cpu().tolist()
+
+
+def beam_search(config, beam_width, vocab, decoder, input, hidden, encoder_outputs):
+    """eval.py:36-120.  Returns top1_output_list: one token list per caption."""
+    _check_start(config, input, hidden)
+    eng = _engine(decoder, encoder_outputs)
+    best, n = eng.beam_search(encoder_outputs.contiguous(), beam_width)
+    n = int(n.item())
+    return best[:n].t().cpu().tolist()
