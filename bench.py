@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--feed", type=int, default=0, help="1: every step takes a fresh HOST batch through feed.DeviceFeeder "
+                    "(pinned staging + H2D on a side stream); reports the PCIe-inclusive rate, not the headline value")
     args = ap.parse_args()
 
     import torch
@@ -132,6 +134,18 @@ def main():
     runner = lambda: step(enc, targets, T, w)
     if args.graph:
         runner = R.GraphedStep(step, enc, targets, T, w)
+    if args.feed:
+        # PCIe-inclusive variant: host batches -> pinned staging -> H2D (side stream) -> the step's input buffers
+        import itertools
+        from recnet_amd.feed import DeviceFeeder
+        host = [(synthetic_features(Bg, F, D, seed=77 + i).numpy(), targets_g.numpy()) for i in range(3)]
+        feeder = DeviceFeeder(itertools.cycle(host), dev, 30, shard=(lo, hi), threaded=args.feed == 1)
+        inner = runner
+
+        def runner():
+            e, t, _, wd = next(feeder)
+            enc.copy_(e); targets.copy_(t); w.copy_(wd)
+            inner()
     for _ in range(args.warmup):
         runner()
     sync_all()
@@ -158,7 +172,7 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
                                    "D=R=%d, V=4188, E=468, H=512, A=128, T=31, dropout 0.5" % (args.rec, B, F, D),
-                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "grad_allreduce": bool(step.reduce),
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
                        "loss": round(sc["total_loss"], 5)},
             "roofline": prof,
         }

@@ -73,3 +73,26 @@ def test_bf16_search_mostly_agrees():
     assert out.shape == g["greedy"].shape
     agree = (out[:2] == g["greedy"][:2]).mean()
     assert agree >= 0.75, agree
+
+
+def test_device_feeder_delivers_batches_and_normalisers():
+    """DeviceFeeder: pinned double-buffered H2D on a side stream; T and step weights from the host."""
+    from recnet_amd import feed
+    rng = np.random.RandomState(1)
+    batches = []
+    for i in range(5):
+        lens = rng.randint(2, 12, size=6)
+        caps = [feed.pad_caption(rng.randint(3, 50, size=L), 30) for L in lens]
+        vids = [rng.randn(28, 16).astype(np.float32) for _ in lens]
+        batches.append(feed.collate_batch(vids, caps, 6))
+    n = 0
+    for (enc, tg), (e, t, T, w) in zip(batches, feed.DeviceFeeder(iter(batches), "cuda", 30)):
+        n += 1                                           # the device buffers are recycled: check while iterating
+        assert np.array_equal(e.cpu().numpy(), enc) and np.array_equal(t.cpu().numpy(), tg)
+        masks = tg > 0
+        assert T == R.decode_len(masks) and np.allclose(w.cpu().numpy(), R.step_weights(masks, T))
+    assert n == 5
+    # rank shard: only captions [2,5) on the device, normalisers still global
+    e, t, T, w = next(iter(feed.DeviceFeeder(iter(batches[:1]), "cuda", 30, shard=(2, 5))))
+    assert tuple(e.shape) == (3, 28, 16) and np.array_equal(t.cpu().numpy(), batches[0][1][:, 2:5])
+    assert np.allclose(w.cpu().numpy(), R.step_weights(batches[0][1] > 0, T))
