@@ -28,16 +28,16 @@ def build_models(R, cfg_over, V):
     return C, dec, rec
 
 
-def cpu_baseline(kind, B, F, D, V, steps, warmup):
+def cpu_baseline(kind, B, F, D, V, steps, warmup, cell="LSTM"):
     """The oracle (CPU port of the reference algorithm, oracle/recnet_oracle.py) timed on this host."""
     import torch
     from oracle import recnet_oracle as O
     # small per-step ops: more than ~32 threads only adds synchronisation cost to the CPU port
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     torch.manual_seed(0)
-    decP = O.init_decoder_params(V, D=D)
-    recP = O.init_rec_params(kind, R=D) if kind else None
-    st = O.TrainState(decP, recP, kind)
+    decP = O.init_decoder_params(V, D=D, cell=cell)
+    recP = O.init_rec_params(kind, R=D, cell=cell) if kind else None
+    st = O.TrainState(decP, recP, kind, cell=cell, rec_cell=cell)
     enc, targets, masks = O.synthetic_batch(B, F, D, V)
     drop = O.Dropper("rng")
     ts = []
@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"], help="recurrent cell of decoder and reconstructor "
+                    "(the north-star workload is LSTM; GRU is config.py:31's literal default)")
     ap.add_argument("--feed", type=int, default=0, help="1: every step takes a fresh HOST batch through feed.DeviceFeeder "
                     "(pinned staging + H2D on a side stream); reports the PCIe-inclusive rate, not the headline value")
     args = ap.parse_args()
@@ -116,7 +118,8 @@ def main():
     kind = None if args.rec == "none" else args.rec
     C, dec, rec = build_models(R, dict(batch_size=B, use_recon=kind is not None, reconstructor_type=kind or "global",
                                        encoder_output_len=F, encoder_output_size=D, reconstructor_hidden_size=D,
-                                       precision=args.precision, device=str(dev)), V)
+                                       precision=args.precision, device=str(dev), decoder_model=args.cell,
+                                       reconstructor_model=args.cell), V)
     Bg = B * world
     targets_g = synthetic_targets(Bg, V, seed=1234)
     lo, hi = R.shard_bounds(Bg, world, rank)
@@ -171,13 +174,13 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
-                                   "D=R=%d, V=4188, E=468, H=512, A=128, T=31, dropout 0.5" % (args.rec, B, F, D),
+                                   "D=R=%d, V=4188, E=468, H=512, A=128, T=31, dropout 0.5, %s cells" % (args.rec, B, F, D, args.cell),
                        "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
                        "loss": round(sc["total_loss"], 5)},
             "roofline": prof,
         }
         if not args.no_cpu_baseline and world == 1:
-            v, cores, med = cpu_baseline(kind, B, F, D, V, args.cpu_steps, 1)
+            v, cores, med = cpu_baseline(kind, B, F, D, V, args.cpu_steps, 1, args.cell)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "captions/s", "cores": cores, "kind": "port",
                                    "sample": "1 warm-up + %d timed train steps of the same workload (B=%d, T=31) by "
                                              "oracle/recnet_oracle.py on torch-CPU; median %.2f s/step" % (args.cpu_steps, B, med)}

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RECNET_ABI_VERSION 1
+#define RECNET_ABI_VERSION 2
 #define RECNET_OK 0
 #define RECNET_EINVAL (-1)      /* bad dimension / null pointer / unsupported variant */
 #define RECNET_ESTATE (-2)      /* call order violated (e.g. backward before forward) */
@@ -29,6 +29,8 @@ extern "C" {
 #define RECNET_REC_NONE 0
 #define RECNET_REC_GLOBAL 1     /* models/global_reconstructor.py */
 #define RECNET_REC_LOCAL 2      /* models/local_reconstructor.py  */
+#define RECNET_CELL_LSTM 0      /* torch.nn.LSTM, gate rows (i, f, g, o) */
+#define RECNET_CELL_GRU 1       /* torch.nn.GRU, gate rows (r, z, n); the hidden state is a single tensor (train.py:33-35) */
 #define RECNET_PREC_F32 0       /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
 #define RECNET_PREC_BF16 1      /* bf16 MFMA operands, fp32 accumulate / state / losses */
 
@@ -49,6 +51,8 @@ typedef struct recnet_config {
   int32_t global_batch_size;          /* data parallel: B summed over ranks (== B single GPU)         */
   int32_t batch_offset;               /* data parallel: global index of this rank's first caption     */
   int32_t decoder_use_amsgrad, reconstructor_use_amsgrad;       /* config.py:90-91 */
+  int32_t decoder_cell;               /* RECNET_CELL_*: decoder_model                    config.py:31  */
+  int32_t reconstructor_cell;         /* RECNET_CELL_*: reconstructor_model              config.py:77  */
   float embedding_scale;              /*                                                config.py:59  */
   float embedding_dropout;            /*                                                config.py:58  */
   float decoder_out_dropout;          /* dropout applied to the logits, decoder.py:69   config.py:70  */

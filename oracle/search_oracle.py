@@ -7,15 +7,15 @@ import torch
 from . import recnet_oracle as O
 
 
-def greedy_search(P, enc, caption_max_len=30):
+def greedy_search(P, enc, caption_max_len=30, cell="LSTM"):
     """eval.py:19-33 with the start state of eval.py:131-141.  Returns [n_steps][B] int64."""
     B = enc.shape[0]
     H = P["rnn.weight_hh_l0"].shape[1]
     tok = torch.full((1, B), O.SOS, dtype=torch.long)
-    hid = O.zero_hidden(B, H, "LSTM")
+    hid = O.zero_hidden(B, H, cell)
     out = []
     for t in range(caption_max_len + 1):
-        logits, hid = O.decoder_step(P, tok, hid, enc, t=t)
+        logits, hid = O.decoder_step(P, tok, hid, enc, cell=cell, t=t)
         top = logits.argmax(dim=1)                                   # :24 topk(1)
         tok = top.view(1, -1)
         out.append(top.numpy().copy())
@@ -24,19 +24,19 @@ def greedy_search(P, enc, caption_max_len=30):
     return np.stack(out)
 
 
-def beam_search(P, enc, beam_width, caption_max_len=30):
+def beam_search(P, enc, beam_width, caption_max_len=30, cell="LSTM"):
     """eval.py:36-120.  Returns the top-1 hypothesis per caption, [B][n_steps] int64."""
     B = enc.shape[0]
     H = P["rnn.weight_hh_l0"].shape[1]
     V = P["out.weight"].shape[0]
     toks = [torch.full((1, B), O.SOS, dtype=torch.long)]
-    hids = [O.zero_hidden(B, H, "LSTM")]
+    hids = [O.zero_hidden(B, H, cell)]
     cums = [torch.zeros(B)]                                          # :39-40 log(1)
     hist = np.zeros((1, B, 0), dtype=np.int64)                       # [beam][B][t]
     for t in range(caption_max_len + 1):
         scores, nxt = [], []
         for i in range(len(toks)):
-            logits, nh = O.decoder_step(P, toks[i], hids[i], enc, t=t)
+            logits, nh = O.decoder_step(P, toks[i], hids[i], enc, cell=cell, t=t)
             nxt.append(nh)
             seq_len = np.full(B, t + 1, dtype=np.float64)            # :53-54
             for b in range(B):
@@ -52,9 +52,12 @@ def beam_search(P, enc, beam_width, caption_max_len=30):
         new_hist = np.zeros((beam_width, B, t + 1), dtype=np.int64)
         toks2, hids2, cums2 = [], [], []
         for k in range(beam_width):
-            h = torch.stack([nxt[src[b, k]][0][0, b] for b in range(B)]).unsqueeze(0)   # :78-93
-            c = torch.stack([nxt[src[b, k]][1][0, b] for b in range(B)]).unsqueeze(0)
-            hids2.append((h, c))
+            if cell == "LSTM":
+                h = torch.stack([nxt[src[b, k]][0][0, b] for b in range(B)]).unsqueeze(0)   # :78-93
+                c = torch.stack([nxt[src[b, k]][1][0, b] for b in range(B)]).unsqueeze(0)
+                hids2.append((h, c))
+            else:                                                    # :94-102, single hidden tensor
+                hids2.append(torch.stack([nxt[src[b, k]][0, b] for b in range(B)]).unsqueeze(0))
             toks2.append(torch.from_numpy(tok[:, k].copy()).view(1, -1))
             cums2.append(vals[:, k].clone())                         # :75 (the length-normalised value is carried on)
             for b in range(B):

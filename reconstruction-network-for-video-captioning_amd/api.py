@@ -107,6 +107,7 @@ def _dims(dec_model, B, F, rec_model=None):
     d = dec_model.dims(B, F)
     if rec_model is not None:
         d["R"] = rec_model.hidden_size
+        d["rec_cell"] = rec_model.model_name
         if rec_model.kind == "local":
             d["RA"] = rec_model.attn_size
     return d
@@ -145,7 +146,7 @@ class FusedAdam(torch.optim.Optimizer):
             eng = Engine(m.dims(1, 1), None, m.precision, self._hyper, device=next(m.parameters()).device)
         else:
             d = dict(B=1, F=1, D=m.hidden_size, E=4, H=m.decoder_hidden_size, A=4, V=8, R=m.hidden_size,
-                     RA=getattr(m, "attn_size", 0))
+                     RA=getattr(m, "attn_size", 0), rec_cell=m.model_name)
             eng = Engine(d, m.kind, m.precision, self._hyper, device=next(m.parameters()).device)
         ms.bind(eng, self._which)
         ms.engines[("opt",)] = eng
@@ -188,8 +189,6 @@ def clip_grad_norm_(model_dict, max_norm):
 # ----------------------------------------------------------------------------- builders
 def build_decoder(n_vocabs, C=TrainConfig):
     """train.py:134-160."""
-    if C.decoder_model != "LSTM":
-        raise NotImplementedError("decoder_model=%r: the HIP path implements LSTM" % (C.decoder_model,))
     model = Decoder(model_name=C.decoder_model, n_layers=C.decoder_n_layers, encoder_size=C.encoder_output_size,
                     embedding_size=C.embedding_size, embedding_scale=C.embedding_scale,
                     hidden_size=C.decoder_hidden_size, attn_size=C.decoder_attn_size, output_size=n_vocabs,
@@ -206,8 +205,6 @@ def build_decoder(n_vocabs, C=TrainConfig):
 
 def build_reconstructor(C=TrainConfig):
     """train.py:163-197."""
-    if C.reconstructor_model != "LSTM":
-        raise NotImplementedError("reconstructor_model=%r: the HIP path implements LSTM" % (C.reconstructor_model,))
     prec = getattr(C, "precision", "bf16")
     if C.reconstructor_type == "local":
         model = LocalReconstructor(model_name=C.reconstructor_model, n_layers=C.reconstructor_n_layers,
@@ -306,7 +303,7 @@ def _forward_reconstructor(kind, decoder_hiddens, encoder_outputs, reconstructor
     T, _, B, H = decoder_hiddens.shape
     F = encoder_outputs.shape[1]
     d = dict(B=B, F=F, D=encoder_outputs.shape[2], E=4, H=H, A=4, V=8, R=model.hidden_size,
-             RA=getattr(model, "attn_size", 0))
+             RA=getattr(model, "attn_size", 0), rec_cell=model.model_name)
     eng = _engine_for(reconstructor, ("rec", B, F), lambda: Engine(d, kind, model.precision, reconstructor["_hyper"],
                                                                    device=encoder_outputs.device), 1)
     eng.pack_weights()

@@ -39,6 +39,7 @@ static inline int pad8(int n) { return (n + 7) & ~7; }
 struct recnet_handle {
   recnet_config c;
   int B, F, D, E, H, A, V, R, RA, Tm, kind, prec, cml;
+  int dgru = 0, rgru = 0; // recurrent cell of the decoder / reconstructor: 0 LSTM, 1 GRU (4-block gate layout, kernels.hpp)
   int lp;                // 1: operand copies / packed weights are bf16 (DMA-staged GEMM); 0: fp32 (exact path)
   // leading dimensions (elements) of the operand buffers: multiples of 8
   int ldD, ldE, ldH, ldV, ldA, ld4H, ldWS, ldR, ld4R, ldRA, ldHR, ldRA4;
@@ -48,6 +49,7 @@ struct recnet_handle {
   float* scal;           // [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
   // ---- decoder: fp32 state
   float *slab2 = nullptr;   // second slab buffer (local reconstructor backward: dWhr . W_r)
+  float *bsum4 = nullptr;   // [4 max(H,R)] column sums of the gate gradients (source of both bias gradients)
   float *bsum_d, *Uv, *Xe, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws, *dHs, *dHsrec, *dc_carry, *dUv,
       *dwacc, *demb, *stepw, *msep;
   // ---- decoder: operand copies (AT = bf16 | float)
@@ -98,6 +100,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->stepw = take(Tm);
   h->msep = take(1024);
   h->bsum_d = take(4 * H);
+  h->bsum4 = take(4 * (H > R ? H : R));
   h->Uv = take(B * F * A);
   h->Xe = take(Tm * B * 4 * H);
   h->Hs = take(Tm * B * H);
@@ -208,6 +211,8 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     return fail(RECNET_EINVAL, "non-positive dimension");
   if (c.reconstructor_type < 0 || c.reconstructor_type > 2) return fail(RECNET_EINVAL, "unknown reconstructor_type");
   if (c.precision != RECNET_PREC_F32 && c.precision != RECNET_PREC_BF16) return fail(RECNET_EINVAL, "unknown precision");
+  if (c.decoder_cell < 0 || c.decoder_cell > 1 || c.reconstructor_cell < 0 || c.reconstructor_cell > 1)
+    return fail(RECNET_EINVAL, "unknown recurrent cell (0 = LSTM, 1 = GRU)");
   if (c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_hidden_size <= 0)
     return fail(RECNET_EINVAL, "reconstructor_hidden_size");
   if (c.reconstructor_type == RECNET_REC_LOCAL && c.reconstructor_hidden_size != c.encoder_output_size)
@@ -225,6 +230,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->RA = c.reconstructor_type == RECNET_REC_LOCAL ? c.reconstructor_attn_size : 0;
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
+  h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   h->need = carve(h, nullptr);
   *out = h;
   return RECNET_OK;
@@ -252,27 +258,36 @@ static void build_pack_tables(recnet_handle* h, int g) {
   OptGroup& o = h->og[g];
   o.pack.assign(o.ntens, PackDesc());
   for (auto& pd : o.pack) { pd.ndst = 0; pd.cols = 1; }
-  auto add = [&](int t, int cols, void* dst, int ld, int c0, int nc) {
+  auto addr = [&](int t, int cols, void* dst, int ld, int c0, int nc, int r0, int nr) {
     PackDesc& pd = o.pack[t]; pd.cols = cols;
-    PackDst& d = pd.d[pd.ndst++]; d.dst = dst; d.ld = ld; d.c0 = c0; d.nc = nc; d.pad = 0;
+    PackDst& d = pd.d[pd.ndst++]; d.dst = dst; d.ld = ld; d.c0 = c0; d.nc = nc; d.r0 = r0; d.nr = nr;
+  };
+  auto add = [&](int t, int cols, void* dst, int ld, int c0, int nc) { addr(t, cols, dst, ld, c0, nc, 0, 1 << 30); };
+  // recurrent weights into the 4-block gate layout: W_ih rows as they are (GRU: 3 blocks, the 4th stays zero);
+  // W_hh of a GRU: blocks (r, z) in place, block n -> packed block 3, packed block 2 stays zero
+  auto add_ih = [&](int t, int cols, void* dst, int ld, int c0, int nc) { add(t, cols, dst, ld, c0, nc); };
+  auto add_hh = [&](int gru, int Hd, int t, int cols, void* dst, int ld, int c0, int nc) {
+    if (!gru) { add(t, cols, dst, ld, c0, nc); return; }
+    addr(t, cols, dst, ld, c0, nc, 0, 2 * Hd);
+    addr(t, cols, at_off(h, dst, (size_t)3 * Hd * ld), ld, c0, nc, 2 * Hd, Hd);
   };
   const int H = h->H, D = h->D, E = h->E, A = h->A, R = h->R, RA = h->RA;
   if (g == 0) {
     for (int j = 0; j < RN_FCH; ++j) add(2, H, at_off(h, h->Wcomb, (size_t)(4 * H + j * A) * h->ldH), h->ldH, 0, H);   // attn_W
     add(3, D, h->U_w, h->ldD, 0, D);                                        // attn_U
-    add(5, E + D, h->We_w, h->ldE, 0, E); add(5, E + D, h->Wc_w, h->ldD, E, D);   // rnn.weight_ih_l0
-    add(6, H, h->Wcomb, h->ldH, 0, H);                                      // rnn.weight_hh_l0
+    add_ih(5, E + D, h->We_w, h->ldE, 0, E); add_ih(5, E + D, h->Wc_w, h->ldD, E, D);   // rnn.weight_ih_l0
+    add_hh(h->dgru, H, 6, H, h->Wcomb, h->ldH, 0, H);                       // rnn.weight_hh_l0
     add(9, H, h->Wo_w, h->ldH, 0, H);                                       // out.weight
   } else if (h->kind == RECNET_REC_GLOBAL) {
-    add(0, 2 * H, h->Wih_a, h->ldH, 0, H); add(0, 2 * H, h->Wih_b, h->ldH, H, H);
-    add(1, R, h->Whh_w, h->ldR, 0, R);
+    add_ih(0, 2 * H, h->Wih_a, h->ldH, 0, H); add_ih(0, 2 * H, h->Wih_b, h->ldH, H, H);
+    add_hh(h->rgru, R, 1, R, h->Whh_w, h->ldR, 0, R);
     add(4, R, h->Wor_w, h->ldR, 0, R);
   } else if (h->kind == RECNET_REC_LOCAL) {
     add(1, R, h->Wr_w, h->ldR, 0, R);
     for (int j = 0; j < RN_TCH; ++j) add(1, R, at_off(h, h->Wr4_w, (size_t)j * RA * h->ldR), h->ldR, 0, R);
     add(2, H, h->Ur_w, h->ldH, 0, H);
-    add(4, H, h->Wihh_w, h->ldHR, 0, H);
-    add(5, R, at_off(h, h->Wihh_w, (size_t)H), h->ldHR, 0, R);
+    add_ih(4, H, h->Wihh_w, h->ldHR, 0, H);
+    add_hh(h->rgru, R, 5, R, at_off(h, h->Wihh_w, (size_t)H), h->ldHR, 0, R);
     add(8, R, h->Wor_w, h->ldR, 0, R);
   }
 }
@@ -346,7 +361,8 @@ int recnet_bind_decoder(recnet_handle* h, const recnet_decoder_tensors* param, c
   h->dP = *param;
   if (grad) h->dGd = *grad; else memset(&h->dGd, 0, sizeof(h->dGd));
   const size_t V = h->V, E = h->E, H = h->H, A = h->A, D = h->D;
-  std::vector<size_t> n = {A, V * E, A * H, A * D, A, 4 * H * (E + D), 4 * H * H, 4 * H, 4 * H, V * H, V};
+  const size_t NG = h->dgru ? 3 : 4;
+  std::vector<size_t> n = {A, V * E, A * H, A * D, A, NG * H * (E + D), NG * H * H, NG * H, NG * H, V * H, V};
   auto G = dec_list(grad);
   if (G.empty()) G.assign(P.size(), nullptr);
   auto M = dec_list(exp_avg), Vv = dec_list(exp_avg_sq), Vm = dec_list(max_exp_avg_sq);
@@ -371,8 +387,9 @@ int recnet_bind_reconstructor(recnet_handle* h, const recnet_reconstructor_tenso
   if (grad) h->rG = *grad; else memset(&h->rG, 0, sizeof(h->rG));
   const size_t H = h->H, R = h->R, RA = h->RA;
   std::vector<size_t> n;
-  if (local) { n = {RA, RA * R, RA * H, RA, 4 * R * H, 4 * R * R, 4 * R, 4 * R, R * R, R}; }
-  else { n = {4 * R * 2 * H, 4 * R * R, 4 * R, 4 * R, R * R, R}; }
+  const size_t NG = h->rgru ? 3 : 4;
+  if (local) { n = {RA, RA * R, RA * H, RA, NG * R * H, NG * R * R, NG * R, NG * R, R * R, R}; }
+  else { n = {NG * R * 2 * H, NG * R * R, NG * R, NG * R, R * R, R}; }
   auto G = rec_list(grad, local);
   if (G.empty()) G.assign(P.size(), nullptr);
   auto M = rec_list(exp_avg, local), Vv = rec_list(exp_avg_sq, local), Vm = rec_list(max_exp_avg_sq, local);
@@ -462,6 +479,18 @@ static void colsum_at(recnet_handle* h, const void* X, int rows, int cols, int l
 }
 // fork: `side` continues after everything enqueued on `main` so far; join: `main` waits for `side`.  Under
 // stream capture these become graph edges, so independent work runs in parallel branches of the hipGraph.
+static void gate_bias_grad(recnet_handle* h, const void* dG, int rows, int Hd, int ld, float* dbih, float* dbhh, int gru, hipStream_t st) {
+  colsum_at(h, dG, rows, 4 * Hd, ld, h->bsum4, st);
+  hipLaunchKernelGGL(gate_bias_grad_kernel, dim3(cdiv(4 * Hd, 256)), dim3(256), 0, st, h->bsum4, dbih, dbhh, Hd, gru);
+}
+// dW_hh = dG^T . Hprev over `rows` rows.  LSTM: the 4 gate blocks as they are.  GRU: master blocks (r, z) come from
+// packed blocks (0, 1) and master block n from packed block 3 (the hidden-side n pre-activation, see gru_point).
+static void dW_hh(recnet_handle* h, int gru, int Hd, const void* dG, int ld_dg, const void* Hprev, int ld_h, float* dW, int rows,
+                  hipStream_t st) {
+  if (!gru) { gemm(h, dG, 1, ld_dg, Hprev, 1, ld_h, dW, Hd, nullptr, 4 * Hd, Hd, rows, 1.f, 0, st); return; }
+  gemm(h, dG, 1, ld_dg, Hprev, 1, ld_h, dW, Hd, nullptr, 2 * Hd, Hd, rows, 1.f, 0, st);
+  gemm(h, at_off(h, (void*)dG, (size_t)3 * Hd), 1, ld_dg, Hprev, 1, ld_h, dW + (size_t)2 * Hd * Hd, Hd, nullptr, Hd, Hd, rows, 1.f, 0, st);
+}
 static void fork_to(recnet_handle* h, int e, hipStream_t main, hipStream_t side) {
   hipEventRecord(h->ev[e], main); hipStreamWaitEvent(side, h->ev[e], 0);
 }
@@ -495,14 +524,30 @@ __global__ void export_scalars_kernel(const float* scal, recnet_scalars* out) {
   out->rec_reg = scal[4]; out->rec_loss = scal[5]; out->total_loss = scal[6]; out->dec_grad_norm = scal[7];
 }
 
+static inline GateMap gmap_ih(int gru) { GateMap m; m.m[0] = 0; m.m[1] = 1; m.m[2] = 2; m.m[3] = gru ? -1 : 3; return m; }
+static inline GateMap gmap_hh(int gru) { GateMap m; m.m[0] = 0; m.m[1] = 1; m.m[2] = gru ? -1 : 2; m.m[3] = gru ? 2 : 3; return m; }
+// recurrent weight image in the 4-block gate layout: dst[4 Hd][ld] = [src1 cols | src2 cols | 0]
+static void pack_gates(recnet_handle* h, void* dst, int ld_dst, int Hd, const float* src1, int ld1, int c1, GateMap m1,
+                       const float* src2, int ld2, int c2, GateMap m2, hipStream_t st) {
+  const size_t n = (size_t)4 * Hd * ld_dst;
+  if (h->lp) hipLaunchKernelGGL(pack_gates_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)dst, ld_dst, Hd, src1, ld1, c1, m1, src2, ld2, c2, m2);
+  else hipLaunchKernelGGL(pack_gates_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)dst, ld_dst, Hd, src1, ld1, c1, m1, src2, ld2, c2, m2);
+}
+static void gate_bias(const float* bih, const float* bhh, float* out, int Hd, int gru, hipStream_t st) {
+  hipLaunchKernelGGL(gate_bias_kernel, dim3(cdiv(4 * Hd, 256)), dim3(256), 0, st, bih, bhh, out, Hd, gru);
+}
+// both bias gradients from the 4-block gate gradients dG [rows][4 Hd]
+static void gate_bias_grad(recnet_handle* h, const void* dG, int rows, int Hd, int ld, float* dbih, float* dbhh, int gru, hipStream_t st);
+
 // Packed operand images of the weights (AT, zero padded leading dimensions), refreshed after every optimiser step.
 static int pack_weights(recnet_handle* h, hipStream_t st) {
   const int H = h->H, D = h->D, E = h->E, A = h->A, V = h->V, R = h->R, RA = h->RA;
   if (h->dec_bound) {
     pack_block(h, h->U_w, h->ldD, h->dP.attn_U_weight, D, A, D, 1.f, st);
-    pack_block(h, h->Wc_w, h->ldD, h->dP.rnn_weight_ih_l0 + E, E + D, 4 * H, D, 1.f, st);
-    pack_block(h, h->We_w, h->ldE, h->dP.rnn_weight_ih_l0, E + D, 4 * H, E, 1.f, st);
-    pack_block(h, h->Wcomb, h->ldH, h->dP.rnn_weight_hh_l0, H, 4 * H, H, 1.f, st);      // [W_hh ; W ; W ; W ; W]
+    const GateMap none = gmap_ih(0);
+    pack_gates(h, h->Wc_w, h->ldD, H, h->dP.rnn_weight_ih_l0 + E, E + D, D, gmap_ih(h->dgru), nullptr, 0, 0, none, st);
+    pack_gates(h, h->We_w, h->ldE, H, h->dP.rnn_weight_ih_l0, E + D, E, gmap_ih(h->dgru), nullptr, 0, 0, none, st);
+    pack_gates(h, h->Wcomb, h->ldH, H, h->dP.rnn_weight_hh_l0, H, H, gmap_hh(h->dgru), nullptr, 0, 0, none, st);   // [W_hh ; W ; W ; W ; W]
     for (int j = 0; j < RN_FCH; ++j)
       pack_block(h, at_off(h, h->Wcomb, (size_t)(4 * H + j * A) * h->ldH), h->ldH, h->dP.attn_W_weight, H, A, H, 1.f, st);
     pack_block(h, h->Wo_w, h->ldH, h->dP.out_weight, H, V, H, 1.f, st);
@@ -510,17 +555,17 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
   if (h->rec_bound) {
     pack_block(h, h->Wor_w, h->ldR, h->rP.out_weight, R, R, R, 1.f, st);
     if (h->kind == RECNET_REC_GLOBAL) {
-      pack_block(h, h->Wih_a, h->ldH, h->rP.rnn_weight_ih_l0, 2 * H, 4 * R, H, 1.f, st);
-      pack_block(h, h->Wih_b, h->ldH, h->rP.rnn_weight_ih_l0 + H, 2 * H, 4 * R, H, 1.f, st);
-      pack_block(h, h->Whh_w, h->ldR, h->rP.rnn_weight_hh_l0, R, 4 * R, R, 1.f, st);
+      const GateMap none = gmap_ih(0);
+      pack_gates(h, h->Wih_a, h->ldH, R, h->rP.rnn_weight_ih_l0, 2 * H, H, gmap_ih(h->rgru), nullptr, 0, 0, none, st);
+      pack_gates(h, h->Wih_b, h->ldH, R, h->rP.rnn_weight_ih_l0 + H, 2 * H, H, gmap_ih(h->rgru), nullptr, 0, 0, none, st);
+      pack_gates(h, h->Whh_w, h->ldR, R, h->rP.rnn_weight_hh_l0, R, R, gmap_hh(h->rgru), nullptr, 0, 0, none, st);
     } else {
       pack_block(h, h->Ur_w, h->ldH, h->rP.attn_U_weight, H, RA, H, 1.f, st);
       pack_block(h, h->Wr_w, h->ldR, h->rP.attn_W_weight, R, RA, R, 1.f, st);
       for (int j = 0; j < RN_TCH; ++j)   // [W_r ; W_r ; W_r ; W_r]: sums the per-chunk dWhr partials in the GEMM's K loop
         pack_block(h, at_off(h, h->Wr4_w, (size_t)j * RA * h->ldR), h->ldR, h->rP.attn_W_weight, R, RA, R, 1.f, st);
-      const size_t n = (size_t)4 * R * h->ldHR;    // [W_ih | W_hh | 0]
-      if (h->lp) hipLaunchKernelGGL(pack2_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->Wihh_w, h->ldHR, h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
-      else hipLaunchKernelGGL(pack2_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->Wihh_w, h->ldHR, h->rP.rnn_weight_ih_l0, H, H, h->rP.rnn_weight_hh_l0, R, R, 4 * R);
+      // [W_ih | W_hh | 0]
+      pack_gates(h, h->Wihh_w, h->ldHR, R, h->rP.rnn_weight_ih_l0, H, H, gmap_ih(h->rgru), h->rP.rnn_weight_hh_l0, R, R, gmap_hh(h->rgru), st);
     }
   }
   return RECNET_OK;
@@ -544,7 +589,7 @@ static void launch_dec_cell(recnet_handle* h, const DecCellArgs& a, hipStream_t 
 // loop-invariant products of the decoder: Uv = enc . U^T (decoder.py:54) and P = enc . W_ih[:, E:]^T
 static void dec_invariants(recnet_handle* h, const float* enc, hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, H = h->H, A = h->A;
-  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, 4 * H);
+  gate_bias(h->dP.rnn_bias_ih_l0, h->dP.rnn_bias_hh_l0, h->bsum_d, H, h->dgru, st);
   pack_block(h, h->enc_lp, h->ldD, enc, D, B * F, D, 1.f, st);
   gemm(h, h->enc_lp, 0, h->ldD, h->U_w, 0, h->ldD, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
   gemm_to_at(h, h->enc_lp, 0, h->ldD, h->Wc_w, 0, h->ldD, h->P, h->ld4H, B * F, 4 * H, D, st);
@@ -568,14 +613,15 @@ static int dec_fwd_chain(recnet_handle* h, const float* enc, const int64_t* targ
   DecCellArgs a;
   a.B = B; a.F = F; a.H = H; a.A = A;
   a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
-  a.ld_hlp = h->ldH;
+  a.ld_hlp = h->ldH; a.gru = h->dgru;
+  const float* prev_state = h->dgru ? h->Hs : h->Cs;   // what the pointwise part carries: h_{t-1} (GRU) / c_{t-1}
   for (int t = 0; t < T; ++t) {
     int S = 0;
     if (t > 0)   // h_{t-1} . [W_hh ; attn_W]^T  -> recurrent gate part + Wh of the attention
       S = gemm_slabs(h, RN_TAG_DEC_FWD, at_off(h, h->Hs_lp, (size_t)(t - 1) * B * h->ldH), h->ldH, h->Wcomb, 0, h->ldH, B, 4 * H + A, H, st);
     a.t = t; a.S = S; a.slab = t > 0 ? h->slab : nullptr;
     a.Xe = h->Xe + (size_t)t * B * 4 * H;
-    a.c_prev = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
+    a.c_prev = t > 0 ? prev_state + (size_t)(t - 1) * B * H : nullptr;
     a.h_out = h->Hs + (size_t)t * B * H; a.c_out = h->Cs + (size_t)t * B * H;
     a.h_lp = at_off(h, h->Hs_lp, (size_t)t * B * h->ldH);
     a.acts = h->acts + (size_t)t * B * 4 * H;
@@ -632,7 +678,8 @@ static int dec_bwd_chain(recnet_handle* h, const float* dhid, hipStream_t st) {
   DecCellBwdArgs a;
   a.B = B; a.F = F; a.H = H; a.A = A;
   a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
-  a.dUv = h->dUv; a.dwacc = h->dwacc; a.ld_dgx = ldWS; a.dUv_lp = h->dUv_lp; a.ld_dUv = h->ldA;
+  a.dUv = h->dUv; a.dwacc = h->dwacc; a.ld_dgx = ldWS; a.dUv_lp = h->dUv_lp; a.ld_dUv = h->ldA; a.gru = h->dgru;
+  const float* prev_state = h->dgru ? h->Hs : h->Cs;
   const int Asz = A <= 256 ? 256 : A;
   const size_t sm = (size_t)(4 * H + F + 2 * Asz + 16) * 4;
   int S = 0;
@@ -641,7 +688,7 @@ static int dec_bwd_chain(recnet_handle* h, const float* dhid, hipStream_t st) {
     a.dHs = h->dHs + (size_t)t * B * H; a.dHs2 = dhid ? dhid + (size_t)t * B * H : nullptr;
     a.acts = h->acts + (size_t)t * B * 4 * H;
     a.c = h->Cs + (size_t)t * B * H;
-    a.c_prev = t > 0 ? h->Cs + (size_t)(t - 1) * B * H : nullptr;
+    a.c_prev = t > 0 ? prev_state + (size_t)(t - 1) * B * H : nullptr;
     a.dc_in = h->dc_carry + (size_t)((t + 1) & 1) * B * H; a.dc_out = h->dc_carry + (size_t)(t & 1) * B * H;
     a.dGx = at_off(h, h->dGx, (size_t)t * B * ldWS);
     a.Wh = h->Wh + (size_t)t * B * A;
@@ -659,7 +706,8 @@ static int dec_bwd_deferred(recnet_handle* h, const float* enc, const int64_t* t
   hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(TB), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
                      h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train));
-  gemm(h, h->dGx, 1, ldWS, h->emb_lp, 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, 4 * H, E, TB, 1.f, 0, st);
+  const int GH = (h->dgru ? 3 : 4) * H;   // rows of the master W_ih / W_hh: gate blocks (r, z, n) or (i, f, g, o)
+  gemm(h, h->dGx, 1, ldWS, h->emb_lp, 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, GH, E, TB, 1.f, 0, st);
   // ctx_t = (1/F) sum_f a_t[f] enc[b,f] for every step (only needed here), then dW_ih[:, E:] = dgates^T . ctx
   {
     dim3 grid(B, cdiv(h->ldD, 256));
@@ -671,7 +719,7 @@ static int dec_bwd_deferred(recnet_handle* h, const float* enc, const int64_t* t
       else hipLaunchKernelGGL(ctx_all_slow_kernel<float>, grid, dim3(256), 0, st, h->att, enc, (float*)h->ctx_lp, h->ldD, T, B, F, D);
     }
   }
-  gemm(h, h->dGx, 1, ldWS, h->ctx_lp, 1, h->ldD, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, 4 * H, D, TB, 1.f, 0, st);
+  gemm(h, h->dGx, 1, ldWS, h->ctx_lp, 1, h->ldD, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, GH, D, TB, 1.f, 0, st);
   // dWh_t = sum of its RN_FCH frame-chunk partials (operand of dW_attn and source of d attn_b)
   {
     const size_t n = (size_t)TB * h->ldA;
@@ -680,14 +728,13 @@ static int dec_bwd_deferred(recnet_handle* h, const float* enc, const int64_t* t
   }
   // dW_hh = sum_{t>=1} dgates_t^T h_{t-1} ; dW_attn = sum_{t>=1} dWh_t^T h_{t-1}   (h_{-1} = 0)
   if (T > 1) {
-    gemm(h, at_off(h, h->dGx, (size_t)B * ldWS), 1, ldWS, h->Hs_lp, 1, h->ldH, h->dGd.rnn_weight_hh_l0, H, nullptr, 4 * H, H, (T - 1) * B, 1.f, 0, st);
+    dW_hh(h, h->dgru, H, at_off(h, h->dGx, (size_t)B * ldWS), ldWS, h->Hs_lp, h->ldH, h->dGd.rnn_weight_hh_l0, (T - 1) * B, st);
     gemm(h, at_off(h, h->dWhs, (size_t)B * h->ldA), 1, h->ldA, h->Hs_lp, 1, h->ldH, h->dGd.attn_W_weight, H, nullptr, A, H, (T - 1) * B, 1.f, 0, st);
   } else {
-    hipMemsetAsync(h->dGd.rnn_weight_hh_l0, 0, (size_t)4 * H * H * 4, st);
+    hipMemsetAsync(h->dGd.rnn_weight_hh_l0, 0, (size_t)GH * H * 4, st);
     hipMemsetAsync(h->dGd.attn_W_weight, 0, (size_t)A * H * 4, st);
   }
-  colsum_at(h, h->dGx, TB, 4 * H, ldWS, h->dGd.rnn_bias_ih_l0, st);
-  copyf(h->dGd.rnn_bias_ih_l0, h->dGd.rnn_bias_hh_l0, 4 * H, st);
+  gate_bias_grad(h, h->dGx, TB, H, ldWS, h->dGd.rnn_bias_ih_l0, h->dGd.rnn_bias_hh_l0, h->dgru, st);
   gemm(h, h->dUv_lp, 1, h->ldA, h->enc_lp, 1, h->ldD, h->dGd.attn_U_weight, D, nullptr, A, D, B * F, 1.f, 0, st);
   colsum_at(h, h->dWhs, TB, A, h->ldA, h->dGd.attn_b, st);
   colsum_t<float>(h->dwacc, RN_FCH * B, A, A, h->dGd.attn_w_weight, st);
@@ -705,7 +752,7 @@ static void lstm_pw(recnet_handle* h, int Hd, int S, int slab_ld, const float* X
                     const float* c_prev, float* h_out, void* h_lp, int hlp_ld, void* h_lp2, int hlp2_ld, float* c_out,
                     float* acts, hipStream_t st) {
   LstmPwArgs p;
-  p.B = h->B; p.Hd = Hd; p.S = S; p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld;
+  p.B = h->B; p.Hd = Hd; p.S = S; p.gru = h->rgru; p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld;
   p.X = X; p.x_ld = x_ld; p.b1 = b1; p.b2 = b2; p.c_prev = c_prev; p.h_out = h_out; p.h_ld = Hd;
   p.h_lp = h_lp; p.hlp_ld = hlp_ld; p.hlp_pad_from = Hd; p.h_lp2 = h_lp2; p.hlp2_ld = hlp2_ld; p.c_out = c_out; p.acts = acts;
   LAUNCH_AT(h, lstm_pw_kernel, dim3(cdiv((long)h->B * Hd, 256)), dim3(256), 0, st, p);
@@ -719,7 +766,7 @@ static void mean_over_t(recnet_handle* h, const float* X, int T, int Cn, float s
 static int fwd_rec_global(recnet_handle* h, const float* enc, int T, int train, hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R;
   param_norms(h, 1, h->scal + 4, st);
-  hipLaunchKernelGGL(add2_kernel, dim3(cdiv(4 * R, 256)), dim3(256), 0, st, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, 4 * R);
+  gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, R, h->rgru, st);
   // mean-pooled decoder states, rescaled by caption_max_len / T (global_reconstructor.py:33-37): (cml / T^2) sum_t h_t
   mean_over_t(h, h->Hs, T, H, (float)h->cml / ((float)T * (float)T), h->mp, nullptr, 0, st);
   {
@@ -735,7 +782,7 @@ static int fwd_rec_global(recnet_handle* h, const float* enc, int T, int train, 
     int S = 0;
     if (t > 0) S = gemm_slabs(h, RN_TAG_REC_FWD, at_off(h, h->Hr_lp, (size_t)(t - 1) * B * h->ldR), h->ldR, h->Whh_w, 0, h->ldR, B, 4 * R, R, st);
     lstm_pw(h, R, S, 4 * R, h->Xg + (size_t)t * B * 4 * R, 4 * R, nullptr, nullptr,
-            t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->Hr + (size_t)t * B * R,
+            t > 0 ? (h->rgru ? h->Hr : h->Cr) + (size_t)(t - 1) * B * R : nullptr, h->Hr + (size_t)t * B * R,
             at_off(h, h->Hr_lp, (size_t)t * B * h->ldR), h->ldR, nullptr, 0, h->Cr + (size_t)t * B * R,
             h->acts_r + (size_t)t * B * 4 * R, st);
   }
@@ -755,7 +802,7 @@ static void lstm_bwd(recnet_handle* h, int Hd, int S, int slab_ld, int slab_col0
                      float dh_scale, const float* acts, const float* c, const float* c_prev, float* dc_carry, int first,
                      void* dG, int ld_dg, hipStream_t st, const float* slab2 = nullptr, int S2 = 0) {
   LstmBwdArgs p;
-  p.B = h->B; p.Hd = Hd; p.S = S; p.dh_direct = dh_direct; p.dhd_ld = dhd_ld; p.dh_scale = dh_scale;
+  p.B = h->B; p.Hd = Hd; p.S = S; p.gru = h->rgru; p.dh_direct = dh_direct; p.dhd_ld = dhd_ld; p.dh_scale = dh_scale;
   p.slab = h->slab; p.slab_stride = (size_t)h->B * slab_ld; p.slab_ld = slab_ld; p.slab_col0 = slab_col0;
   p.slab2 = slab2; p.slab2_stride = (size_t)h->B * Hd; p.S2 = S2;
   p.acts = acts; p.c = c; p.c_prev = c_prev; p.dc_carry = dc_carry; p.first = first; p.dG = dG; p.ld_dg = ld_dg;
@@ -773,7 +820,7 @@ static int bwd_rec_global(recnet_handle* h, float gscale, float* dhid_out, hipSt
   int S = 0;
   for (int t = T - 1; t >= 0; --t) {
     lstm_bwd(h, R, S, R, 0, h->dhrmean, R, 1.0f / (float)T, h->acts_r + (size_t)t * B * 4 * R, h->Cr + (size_t)t * B * R,
-             t > 0 ? h->Cr + (size_t)(t - 1) * B * R : nullptr, h->dcr_carry, t == T - 1, at_off(h, h->dGr, (size_t)t * B * ld4R), ld4R, st);
+             t > 0 ? (h->rgru ? h->Hr : h->Cr) + (size_t)(t - 1) * B * R : nullptr, h->dcr_carry, t == T - 1, at_off(h, h->dGr, (size_t)t * B * ld4R), ld4R, st);
     if (t > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)t * B * ld4R), ld4R, h->Whh_w, 1, h->ldR, B, R, 4 * R, st);
   }
   // input-side gradients, batched
@@ -788,14 +835,14 @@ static int bwd_rec_global(recnet_handle* h, float gscale, float* dhid_out, hipSt
 }
 static int bwd_rec_global_deferred(recnet_handle* h, hipStream_t st) {
   const int B = h->B, H = h->H, R = h->R, T = h->T_last, TB = T * B, ld4R = h->ld4R;
-  gemm(h, h->dGr, 1, ld4R, h->Hs_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
-  gemm(h, h->dGr, 1, ld4R, h->mpd_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, 4 * R, H, TB, 1.f, 0, st);
+  const int GR = (h->rgru ? 3 : 4) * R;
+  gemm(h, h->dGr, 1, ld4R, h->Hs_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, GR, H, TB, 1.f, 0, st);
+  gemm(h, h->dGr, 1, ld4R, h->mpd_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, GR, H, TB, 1.f, 0, st);
   if (T > 1)
-    gemm(h, at_off(h, h->dGr, (size_t)B * ld4R), 1, ld4R, h->Hr_lp, 1, h->ldR, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (T - 1) * B, 1.f, 0, st);
+    dW_hh(h, h->rgru, R, at_off(h, h->dGr, (size_t)B * ld4R), ld4R, h->Hr_lp, h->ldR, h->rG.rnn_weight_hh_l0, (T - 1) * B, st);
   else
-    hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)4 * R * R * 4, st);
-  colsum_at(h, h->dGr, TB, 4 * R, ld4R, h->rG.rnn_bias_ih_l0, st);
-  copyf(h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, 4 * R, st);
+    hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)GR * R * 4, st);
+  gate_bias_grad(h, h->dGr, TB, R, ld4R, h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, h->rgru, st);
   return RECNET_OK;
 }
 
@@ -804,6 +851,7 @@ static int fwd_rec_local(recnet_handle* h, const float* enc, int T, int train, h
   const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R, RA = h->RA, ldHR = h->ldHR;
   const size_t esz = h->lp ? 2 : 4;
   param_norms(h, 1, h->scal + 4, st);
+  gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, R, h->rgru, st);
   // Ud = hiddens . U_r^T   (local_reconstructor.py:42, hoisted)
   gemm(h, h->Hs_lp, 0, h->ldH, h->Ur_w, 0, h->ldH, h->Ud, RA, nullptr, T * B, RA, H, 1.f, 0, st);
   hipMemsetAsync(h->Xcat_r, 0, (size_t)F * B * ldHR * esz, st);   // hr_{-1} = 0 and the zero padding of every row
@@ -819,8 +867,8 @@ static int fwd_rec_local(recnet_handle* h, const float* enc, int T, int train, h
     a.xcat = at_off(h, h->Xcat_r, (size_t)s * B * ldHR);
     LAUNCH_AT(h, loc_attn_fwd_kernel, dim3(B, cdiv(H, 256)), dim3(256), sm, st, a);
     const int Sb = gemm_slabs(h, RN_TAG_REC_FWD, at_off(h, h->Xcat_r, (size_t)s * B * ldHR), ldHR, h->Wihh_w, 0, ldHR, B, 4 * R, H + R, st);
-    lstm_pw(h, R, Sb, 4 * R, nullptr, 0, h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0,
-            s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->Hr + (size_t)s * B * R,
+    lstm_pw(h, R, Sb, 4 * R, nullptr, 0, h->bsum_r, nullptr,
+            s > 0 ? (h->rgru ? h->Hr : h->Cr) + (size_t)(s - 1) * B * R : nullptr, h->Hr + (size_t)s * B * R,
             at_off(h, h->Hr_lp, (size_t)s * B * h->ldR), h->ldR,
             s + 1 < F ? at_off(h, h->Xcat_r, (size_t)(s + 1) * B * ldHR + H) : nullptr, ldHR, h->Cr + (size_t)s * B * R,
             h->acts_r + (size_t)s * B * 4 * R, st);
@@ -853,7 +901,7 @@ static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStr
   int S1 = 0, S2 = 0;
   for (int s = F - 1; s >= 0; --s) {
     lstm_bwd(h, R, S1, H + R, H, h->dHr + (size_t)s * B * R, R, 1.0f, h->acts_r + (size_t)s * B * 4 * R, h->Cr + (size_t)s * B * R,
-             s > 0 ? h->Cr + (size_t)(s - 1) * B * R : nullptr, h->dcr_carry, s == F - 1, at_off(h, h->dGr, (size_t)s * B * ld4R), ld4R, st,
+             s > 0 ? (h->rgru ? h->Hr : h->Cr) + (size_t)(s - 1) * B * R : nullptr, h->dcr_carry, s == F - 1, at_off(h, h->dGr, (size_t)s * B * ld4R), ld4R, st,
              h->slab2, S2);
     S1 = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)s * B * ld4R), ld4R, h->Wihh_w, 1, ldHR, B, H + R, 4 * R, st);
     a.s = s; a.S = S1; a.first = (s == F - 1); a.last = (s == 0);
@@ -868,7 +916,7 @@ static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStr
 }
 static int bwd_rec_local_deferred(recnet_handle* h, hipStream_t st) {
   const int B = h->B, F = h->F, H = h->H, R = h->R, RA = h->RA, T = h->T_last, TB = T * B, FB = F * B;
-  const int ld4R = h->ld4R, ldHR = h->ldHR;
+  const int ld4R = h->ld4R, ldHR = h->ldHR, GR = (h->rgru ? 3 : 4) * R;
   gemm(h, h->dUd_lp, 1, h->ldRA, h->Hs_lp, 1, h->ldH, h->rG.attn_U_weight, H, nullptr, RA, H, TB, 1.f, 0, st);
   {
     const size_t n = (size_t)FB * h->ldRA;
@@ -877,16 +925,15 @@ static int bwd_rec_local_deferred(recnet_handle* h, hipStream_t st) {
   }
   if (F > 1) {
     gemm(h, at_off(h, h->dWhrs, (size_t)B * h->ldRA), 1, h->ldRA, h->Hr_lp, 1, h->ldR, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
-    gemm(h, at_off(h, h->dGr, (size_t)B * ld4R), 1, ld4R, h->Hr_lp, 1, h->ldR, h->rG.rnn_weight_hh_l0, R, nullptr, 4 * R, R, (F - 1) * B, 1.f, 0, st);
+    dW_hh(h, h->rgru, R, at_off(h, h->dGr, (size_t)B * ld4R), ld4R, h->Hr_lp, h->ldR, h->rG.rnn_weight_hh_l0, (F - 1) * B, st);
   } else {
     hipMemsetAsync(h->rG.attn_W_weight, 0, (size_t)RA * R * 4, st);
-    hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)4 * R * R * 4, st);
+    hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)GR * R * 4, st);
   }
   colsum_at(h, h->dWhrs, FB, RA, h->ldRA, h->rG.attn_b, st);
   colsum_t<float>(h->dwacc_r, RN_TCH * B, RA, RA, h->rG.attn_w_weight, st);
-  gemm(h, h->dGr, 1, ld4R, h->Xcat_r, 1, ldHR, h->rG.rnn_weight_ih_l0, H, nullptr, 4 * R, H, FB, 1.f, 0, st);
-  colsum_at(h, h->dGr, FB, 4 * R, ld4R, h->rG.rnn_bias_ih_l0, st);
-  copyf(h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, 4 * R, st);
+  gemm(h, h->dGr, 1, ld4R, h->Xcat_r, 1, ldHR, h->rG.rnn_weight_ih_l0, H, nullptr, GR, H, FB, 1.f, 0, st);
+  gate_bias_grad(h, h->dGr, FB, R, ld4R, h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, h->rgru, st);
   return RECNET_OK;
 }
 
@@ -968,7 +1015,7 @@ static int dec_step_core(recnet_handle* h, const int64_t* tokens, const float* h
   DecCellArgs a;
   a.t = t; a.B = B; a.F = F; a.H = H; a.A = A; a.S = S; a.slab = h_in ? h->slab : nullptr;
   a.Xe = h->Xe; a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
-  a.c_prev = c_in; a.h_out = h_out; a.c_out = c_out; a.acts = nullptr; a.Wh_out = nullptr; a.att_out = nullptr;
+  a.gru = h->dgru; a.c_prev = h->dgru ? h_in : c_in; a.h_out = h_out; a.c_out = c_out; a.acts = nullptr; a.Wh_out = nullptr; a.att_out = nullptr;
   a.h_lp = at_off(h, h->Hs_lp, (size_t)B * h->ldH); a.ld_hlp = h->ldH;
   launch_dec_cell(h, a, st);
   gemm(h, at_off(h, h->Hs_lp, (size_t)B * h->ldH), 0, h->ldH, h->Wo_w, 0, h->ldH, logits, V, h->dP.out_bias, B, V, H, 1.f, 0, st);
@@ -994,7 +1041,7 @@ int recnet_decoder_step(recnet_handle* h, const int64_t* tokens, const float* h_
                         uint32_t seed, int32_t t, void* stream) {
   REQUIRE_WS(h);
   if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
-  if (!tokens || !logits || !h_out || !c_out) return fail(RECNET_EINVAL, "null argument");
+  if (!tokens || !logits || !h_out || (!c_out && !h->dgru)) return fail(RECNET_EINVAL, "null argument");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
   if (enc) dec_invariants(h, enc, st);   // enc == NULL: reuse what recnet_decoder_prepare / the last call computed
@@ -1063,6 +1110,7 @@ int recnet_beam_search(recnet_handle* h, const float* enc, int32_t beam_width, i
     u.last_eos_old = h->sr_eos[cur]; u.hist_old = h->sr_hist[cur];
     u.h_new = h->sr_h[cur ^ 1]; u.c_new = h->sr_c[cur ^ 1]; u.cum_new = h->sr_cum[cur ^ 1];
     u.last_eos_new = h->sr_eos[cur ^ 1]; u.hist_new = h->sr_hist[cur ^ 1]; u.tok_new = h->sr_tok[cur ^ 1];
+    u.n_steps = n_steps_out;
     hipLaunchKernelGGL(beam_update_kernel, dim3(bw, B), dim3(128), 0, st, u);
     hipLaunchKernelGGL(search_stop_kernel, dim3(1), dim3(256), 0, st, h->sr_tok[cur ^ 1], bw * B, t, n_steps_out);
     cur ^= 1; nb = bw;

@@ -178,6 +178,22 @@ __global__ void pack2_kernel(DT* __restrict__ dst, int ld_dst, const float* __re
     dst[i] = (DT)v;
   }
 }
+// Recurrent weights into the 4-block gate layout: packed row (q * Hd + u) takes master row (map[q] * Hd + u) of
+// src1 (columns [0,c1)) and of src2 (columns [c1, c1+c2)), zeros where map[q] < 0 and in the padding.
+// LSTM: map = {0,1,2,3}.  GRU: W_ih map {0,1,2,-1}, W_hh map {0,1,-1,2}  (see gru_point).
+struct GateMap { int m[4]; };
+template <typename DT>
+__global__ void pack_gates_kernel(DT* __restrict__ dst, int ld_dst, int Hd, const float* __restrict__ src1, int ld1, int c1,
+                                  GateMap map1, const float* __restrict__ src2, int ld2, int c2, GateMap map2) {
+  const size_t total = (size_t)4 * Hd * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst), q = r / Hd, u = r - q * Hd;
+    float v = 0.f;
+    if (c < c1) { if (map1.m[q] >= 0) v = src1[(size_t)(map1.m[q] * Hd + u) * ld1 + c]; }
+    else if (c < c1 + c2) { if (map2.m[q] >= 0) v = src2[(size_t)(map2.m[q] * Hd + u) * ld2 + (c - c1)]; }
+    dst[i] = (DT)v;
+  }
+}
 // dst[r][c] = sum_j src[r*ld_src + j*cols + c]  (sum of NCH side-by-side partial blocks), zero padded to ld_dst
 template <typename AT>
 __global__ void sum_chunks_kernel(AT* __restrict__ dst, int ld_dst, const AT* __restrict__ src, int ld_src, int rows,
@@ -220,6 +236,56 @@ __device__ __forceinline__ LstmGrad lstm_point_bwd(float dh, float dc_in, float 
   r.dg = dc * i * (1.f - g * g);
   r.dc_prev = dc * f;
   return r;
+}
+
+// =============================================================================================
+// GRU gate math (torch.nn.GRU order r, z, n) in the library's 4-block gate layout
+//   block 0 = r, block 1 = z (input + hidden parts summed), block 2 = W_in x + b_in, block 3 = W_hn h + b_hn :
+// the packed weights hold W_ih as blocks (r, z, n, 0) and W_hh as blocks (r, z, 0, n), so every GEMM, slab and
+// gate-gradient row of the LSTM path is reused as is and only this pointwise part differs.
+//   n = tanh(g2 + r * g3) ; h = (1 - z) n + z h_prev.  Saved activations: (r, z, n, g3).
+// =============================================================================================
+struct GruOut { float r, z, n, hn, h; };
+__device__ __forceinline__ GruOut gru_point(float g0, float g1, float g2, float g3, float h_prev) {
+  GruOut o;
+  o.r = rn_sigmoid(g0);
+  o.z = rn_sigmoid(g1);
+  o.hn = g3;
+  o.n = rn_tanh(g2 + o.r * g3);
+  o.h = (1.f - o.z) * o.n + o.z * h_prev;
+  return o;
+}
+// returns the gate-block gradients in (di, df, dg, d_o) = (d g0, d g1, d g2, d g3) and dc_prev = the direct part
+// of d h_prev (dh * z); the part through W_hh comes from the next GEMM like the LSTM's.
+__device__ __forceinline__ LstmGrad gru_point_bwd(float dh, float r, float z, float n, float hn, float h_prev) {
+  LstmGrad g;
+  const float dn = dh * (1.f - z) * (1.f - n * n);
+  g.dg = dn;
+  g.d_o = dn * r;
+  g.di = dn * hn * r * (1.f - r);
+  g.df = dh * (h_prev - n) * z * (1.f - z);
+  g.dc_prev = dh * z;
+  return g;
+}
+// bias of the 4-block gate layout: LSTM b_ih + b_hh ; GRU (b_ir + b_hr, b_iz + b_hz, b_in, b_hn)
+__global__ void gate_bias_kernel(const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ out,
+                                 int Hd, int gru) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * Hd) return;
+  if (!gru) { out[i] = bih[i] + bhh[i]; return; }
+  const int blk = i / Hd;
+  out[i] = blk < 2 ? bih[i] + bhh[i] : (blk == 2 ? bih[i] : bhh[i - Hd]);
+}
+// gradients of the two bias vectors from the column sums of the 4-block gate gradients
+__global__ void gate_bias_grad_kernel(const float* __restrict__ sum4, float* __restrict__ dbih, float* __restrict__ dbhh,
+                                      int Hd, int gru) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * Hd) return;
+  if (!gru) { dbih[i] = sum4[i]; dbhh[i] = sum4[i]; return; }
+  const int blk = i / Hd;
+  if (blk < 2) { dbih[i] = sum4[i]; dbhh[i] = sum4[i]; }
+  else if (blk == 2) dbih[i] = sum4[i];
+  else dbhh[i - Hd] = sum4[i];
 }
 
 // =============================================================================================
@@ -270,6 +336,7 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb
 #define RN_UC_MAX 256       // hidden units per workgroup = blockDim.x / 4 (one thread per gate per unit)
 struct DecCellArgs {
   int t, B, F, H, A, S;
+  int gru;                // 1: GRU pointwise (c_prev = h_{t-1}, c_out unused), see gru_point
   const float* slab;      // [S][B][4H+A] split-K partials of h_{t-1} . [W_hh ; W]^T, nullptr when h_{t-1} = 0
   const float* Xe;        // [B][4H] of step t (emb . W_e^T + b_ih + b_hh)
   const void* P;          // [B*F][ldp] AT
@@ -374,13 +441,20 @@ __global__ __launch_bounds__(1024) void dec_cell_kernel(const DecCellArgs p) {
   if (tid < UC && u0 + tid < H) {
     const int uu = u0 + tid;
     const size_t o = (size_t)b * H + uu;
-    const LstmOut r = lstm_point(spre[tid], spre[UC + tid], spre[2 * UC + tid], spre[3 * UC + tid], cprev);
-    p.h_out[o] = r.h;
-    p.c_out[o] = r.c;
-    if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)r.h;
+    float hv, a0, a1, a2, a3;
+    if (p.gru) {
+      const GruOut r = gru_point(spre[tid], spre[UC + tid], spre[2 * UC + tid], spre[3 * UC + tid], cprev);
+      hv = r.h; a0 = r.r; a1 = r.z; a2 = r.n; a3 = r.hn;
+    } else {
+      const LstmOut r = lstm_point(spre[tid], spre[UC + tid], spre[2 * UC + tid], spre[3 * UC + tid], cprev);
+      hv = r.h; a0 = r.i; a1 = r.f; a2 = r.g; a3 = r.o;
+      p.c_out[o] = r.c;
+    }
+    p.h_out[o] = hv;
+    if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)hv;
     if (p.acts) {
       float* a = p.acts + (size_t)b * W4 + uu;
-      a[0] = r.i; a[H] = r.f; a[2 * H] = r.g; a[3 * H] = r.o;
+      a[0] = a0; a[H] = a1; a[2 * H] = a2; a[3 * H] = a3;
     }
   }
   // zero padding of the operand copy (columns [H, ld_hlp)), once per row
@@ -481,13 +555,21 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
     const int uu = u0 + ul;
     if (uu >= H) break;
     const size_t o = (size_t)b * H + uu;
-    const LstmOut r = lstm_point(spre[ul], spre[512 + ul], spre[1024 + ul], spre[1536 + ul], p.c_prev ? p.c_prev[o] : 0.f);
-    p.h_out[o] = r.h;
-    p.c_out[o] = r.c;
-    if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)r.h;
+    const float cprev = p.c_prev ? p.c_prev[o] : 0.f;
+    float hv, a0, a1, a2, a3;
+    if (p.gru) {
+      const GruOut r = gru_point(spre[ul], spre[512 + ul], spre[1024 + ul], spre[1536 + ul], cprev);
+      hv = r.h; a0 = r.r; a1 = r.z; a2 = r.n; a3 = r.hn;
+    } else {
+      const LstmOut r = lstm_point(spre[ul], spre[512 + ul], spre[1024 + ul], spre[1536 + ul], cprev);
+      hv = r.h; a0 = r.i; a1 = r.f; a2 = r.g; a3 = r.o;
+      p.c_out[o] = r.c;
+    }
+    p.h_out[o] = hv;
+    if (p.h_lp) reinterpret_cast<AT*>(p.h_lp)[(size_t)b * p.ld_hlp + uu] = (AT)hv;
     if (p.acts) {
       float* a = p.acts + (size_t)b * W4 + uu;
-      a[0] = r.i; a[H] = r.f; a[2 * H] = r.g; a[3 * H] = r.o;
+      a[0] = a0; a[H] = a1; a[2 * H] = a2; a[3 * H] = a3;
     }
   }
   if (p.h_lp && blockIdx.y == 0)
@@ -507,6 +589,7 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
 #define RN_FCH 4
 struct DecCellBwdArgs {
   int t, B, F, H, A, S;
+  int gru;               // 1: GRU (c unused, c_prev = h_{t-1}, the carry holds dh * z instead of dc * f)
   const float* slab;     // [S][B][H] or nullptr (t == T-1)
   const float* dHs;      // [B][H] direct gradient of h_t from the vocabulary projection
   const float* dHs2;     // [B][H] direct gradient of h_t from the reconstructor, or nullptr
@@ -566,8 +649,9 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
     if (p.dHs2) dh += p.dHs2[o];
     if (p.slab) dh += sum_strided(p.slab + o, zs, p.S);
     const float* a = p.acts + (size_t)b * W4 + u;
-    const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_in[o], a[0], a[H], a[2 * H], a[3 * H], p.c[o],
-                                      p.c_prev ? p.c_prev[o] : 0.f);
+    const float carry = p.first ? 0.f : p.dc_in[o], cpv = p.c_prev ? p.c_prev[o] : 0.f;
+    const LstmGrad g = p.gru ? gru_point_bwd(dh + carry, a[0], a[H], a[2 * H], a[3 * H], cpv)
+                             : lstm_point_bwd(dh, carry, a[0], a[H], a[2 * H], a[3 * H], p.c[o], cpv);
     sdg[u] = g.di; sdg[H + u] = g.df; sdg[2 * H + u] = g.dg; sdg[3 * H + u] = g.d_o;
     if (ch == 0) {
       dgx[u] = (AT)g.di; dgx[H + u] = (AT)g.df; dgx[2 * H + u] = (AT)g.dg; dgx[3 * H + u] = (AT)g.d_o;
@@ -716,6 +800,7 @@ __global__ __launch_bounds__(256) void ctx_all_slow_kernel(const float* __restri
 // =============================================================================================
 struct LstmPwArgs {
   int B, Hd, S;
+  int gru;                                               // 1: GRU (c_prev = h_prev, c_out unused)
   const float* slab; size_t slab_stride; int slab_ld;   // [S] x [B][slab_ld], gate columns at [0, 4Hd)
   const float* X; int x_ld;                              // optional pre-computed input part [B][x_ld]
   const float* b1; const float* b2;                      // optional bias vectors [4Hd]
@@ -741,21 +826,29 @@ __global__ __launch_bounds__(256) void lstm_pw_kernel(const LstmPwArgs p) {
     g[q] = v;
   }
   const float cp = p.c_prev ? p.c_prev[(size_t)b * Hd + u] : 0.f;
-  const LstmOut r = lstm_point(g[0], g[1], g[2], g[3], cp);
-  p.h_out[(size_t)b * p.h_ld + u] = r.h;
+  float hv, a0, a1, a2, a3;
+  if (p.gru) {
+    const GruOut r = gru_point(g[0], g[1], g[2], g[3], cp);
+    hv = r.h; a0 = r.r; a1 = r.z; a2 = r.n; a3 = r.hn;
+  } else {
+    const LstmOut r = lstm_point(g[0], g[1], g[2], g[3], cp);
+    hv = r.h; a0 = r.i; a1 = r.f; a2 = r.g; a3 = r.o;
+    p.c_out[(size_t)b * Hd + u] = r.c;
+  }
+  p.h_out[(size_t)b * p.h_ld + u] = hv;
   if (p.h_lp) {
     AT* d = reinterpret_cast<AT*>(p.h_lp) + (size_t)b * p.hlp_ld;
-    d[u] = (AT)r.h;
+    d[u] = (AT)hv;
     if (u < p.hlp_ld - p.hlp_pad_from) d[p.hlp_pad_from + u] = (AT)0.f;
   }
-  if (p.h_lp2) reinterpret_cast<AT*>(p.h_lp2)[(size_t)b * p.hlp2_ld + u] = (AT)r.h;
-  p.c_out[(size_t)b * Hd + u] = r.c;
+  if (p.h_lp2) reinterpret_cast<AT*>(p.h_lp2)[(size_t)b * p.hlp2_ld + u] = (AT)hv;
   float* a = p.acts + (size_t)b * 4 * Hd + u;
-  a[0] = r.i; a[Hd] = r.f; a[2 * Hd] = r.g; a[3 * Hd] = r.o;
+  a[0] = a0; a[Hd] = a1; a[2 * Hd] = a2; a[3 * Hd] = a3;
 }
 
 struct LstmBwdArgs {
   int B, Hd, S;
+  int gru;
   const float* dh_direct; int dhd_ld; float dh_scale;    // optional [B][dhd_ld]
   const float* slab; size_t slab_stride; int slab_ld; int slab_col0;   // recurrent part: sum_z slab[z][b][col0+u]
   const float* slab2; size_t slab2_stride; int S2;                     // optional second product [S2][B][Hd]
@@ -773,8 +866,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs p) {
   if (p.S2) dh += sum_strided(p.slab2 + (size_t)b * Hd + u, p.slab2_stride, p.S2);
   const size_t o = (size_t)b * Hd + u;
   const float* a = p.acts + (size_t)b * 4 * Hd + u;
-  const LstmGrad g = lstm_point_bwd(dh, p.first ? 0.f : p.dc_carry[o], a[0], a[Hd], a[2 * Hd], a[3 * Hd], p.c[o],
-                                    p.c_prev ? p.c_prev[o] : 0.f);
+  const float carry = p.first ? 0.f : p.dc_carry[o], cpv = p.c_prev ? p.c_prev[o] : 0.f;
+  const LstmGrad g = p.gru ? gru_point_bwd(dh + carry, a[0], a[Hd], a[2 * Hd], a[3 * Hd], cpv)
+                           : lstm_point_bwd(dh, carry, a[0], a[Hd], a[2 * Hd], a[3 * Hd], p.c[o], cpv);
   AT* dg = reinterpret_cast<AT*>(p.dG) + (size_t)b * p.ld_dg;
   dg[u] = (AT)g.di; dg[Hd + u] = (AT)g.df; dg[2 * Hd + u] = (AT)g.dg; dg[3 * Hd + u] = (AT)g.d_o;
   if (u < p.ld_dg - 4 * Hd) dg[4 * Hd + u] = (AT)0.f;
@@ -1156,10 +1250,14 @@ struct BeamUpdArgs {
   const float* h_next; const float* c_next;              // [nb_old][B][H] states after this step
   const int32_t* last_eos_old; const int64_t* hist_old;  // [nb_old][B], [nb_old][B][Tm]
   float* h_new; float* c_new; float* cum_new; int32_t* last_eos_new; int64_t* hist_new; int64_t* tok_new;
+  const int32_t* n_steps;                                // != 0: the search already stopped (eval.py:116)
 };
 __global__ __launch_bounds__(128) void beam_update_kernel(const BeamUpdArgs p) {
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  const int flat = p.idx[b * p.bw + k];
+  int flat = p.idx[b * p.bw + k];
+  // The reference leaves its loop at the first step whose tokens are all <PAD>; the device loop has a fixed trip
+  // count, so from then on the hypotheses are carried over unchanged (same beam order, <PAD> appended).
+  if (*p.n_steps != 0) flat = k * p.V;
   const int src = flat / p.V, tok = flat % p.V;
   const size_t so = ((size_t)src * p.B + b), dn = ((size_t)k * p.B + b);
   for (int j = tid; j < p.H; j += 128) {
@@ -1188,7 +1286,9 @@ struct TensorDesc { float* p; float* g; float* m; float* v; float* vmax; int n; 
 // Where the packed operand image(s) of a parameter tensor live: element (r, c) of a [rows][cols] tensor goes to
 // dst[r * ld + (c - c0)] for every destination whose column window [c0, c0 + nc) contains c.  The Adam kernel
 // writes them directly, so the weights are re-packed (bf16) in the same pass that updates them.
-struct PackDst { void* dst; int ld; int c0; int nc; int pad; };
+// Rows: only source rows [r0, r0 + nr) are written, to destination row (r - r0) (dst is pre-offset) — the GRU's
+// 3-block weights land in the 4-block packed layout this way.
+struct PackDst { void* dst; int ld; int c0; int nc; int r0; int nr; };
 struct PackDesc { int ndst; int cols; PackDst d[6]; };
 #define RN_CHUNK 8192
 
@@ -1317,8 +1417,8 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
       const int r = i / pk.cols, c = i - r * pk.cols;
 #pragma unroll
       for (int d = 0; d < 6; ++d)
-        if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc) {
-          const size_t o = (size_t)r * pk.d[d].ld + (c - pk.d[d].c0);
+        if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc && r >= pk.d[d].r0 && r < pk.d[d].r0 + pk.d[d].nr) {
+          const size_t o = (size_t)(r - pk.d[d].r0) * pk.d[d].ld + (c - pk.d[d].c0);
           if (lp) reinterpret_cast<bf16_t*>(pk.d[d].dst)[o] = (bf16_t)pn; else reinterpret_cast<float*>(pk.d[d].dst)[o] = pn;
         }
     }

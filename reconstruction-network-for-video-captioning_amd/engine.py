@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import DECODER_KEYS, REC_KEYS
 
 _KIND = {None: _lib.REC_NONE, "none": _lib.REC_NONE, "global": _lib.REC_GLOBAL, "local": _lib.REC_LOCAL}
+_CELL = {"LSTM": 0, "GRU": 1}
 _PREC = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
 
 
@@ -98,6 +99,8 @@ class Engine:
         c.precision = _PREC[precision]
         c.global_batch_size = global_batch if global_batch else dims["B"]
         c.batch_offset = batch_offset
+        c.decoder_cell = _CELL[dims.get("dec_cell", "LSTM")]
+        c.reconstructor_cell = _CELL[dims.get("rec_cell", "LSTM")]
         c.decoder_use_amsgrad = int(bool(hy["decoder_use_amsgrad"]))
         c.reconstructor_use_amsgrad = int(bool(hy["reconstructor_use_amsgrad"]))
         for k in ("embedding_scale", "embedding_dropout", "decoder_out_dropout", "reconstructor_decoder_dropout",
@@ -131,21 +134,23 @@ class Engine:
     # ------------------------------------------------------------------ binding
     def decoder_shapes(self):
         d = self.dims
+        G = 3 if d.get("dec_cell", "LSTM") == "GRU" else 4
         return {"attn_b": (d["A"],), "embedding.weight": (d["V"], d["E"]), "attn_W.weight": (d["A"], d["H"]),
                 "attn_U.weight": (d["A"], d["D"]), "attn_w.weight": (1, d["A"]),
-                "rnn.weight_ih_l0": (4 * d["H"], d["E"] + d["D"]), "rnn.weight_hh_l0": (4 * d["H"], d["H"]),
-                "rnn.bias_ih_l0": (4 * d["H"],), "rnn.bias_hh_l0": (4 * d["H"],),
+                "rnn.weight_ih_l0": (G * d["H"], d["E"] + d["D"]), "rnn.weight_hh_l0": (G * d["H"], d["H"]),
+                "rnn.bias_ih_l0": (G * d["H"],), "rnn.bias_hh_l0": (G * d["H"],),
                 "out.weight": (d["V"], d["H"]), "out.bias": (d["V"],)}
 
     def rec_shapes(self):
         d = self.dims
         R, H = d.get("R", d["D"]), d["H"]
+        G = 3 if d.get("rec_cell", "LSTM") == "GRU" else 4
         s = {}
         if self.kind == "local":
             RA = d["RA"]
             s.update({"attn_b": (RA,), "attn_W.weight": (RA, R), "attn_U.weight": (RA, H), "attn_w.weight": (1, RA)})
-        s.update({"rnn.weight_ih_l0": (4 * R, H if self.kind == "local" else 2 * H), "rnn.weight_hh_l0": (4 * R, R),
-                  "rnn.bias_ih_l0": (4 * R,), "rnn.bias_hh_l0": (4 * R,), "out.weight": (R, R), "out.bias": (R,)})
+        s.update({"rnn.weight_ih_l0": (G * R, H if self.kind == "local" else 2 * H), "rnn.weight_hh_l0": (G * R, R),
+                  "rnn.bias_ih_l0": (G * R,), "rnn.bias_hh_l0": (G * R,), "out.weight": (R, R), "out.bias": (R,)})
         return s
 
     def bind_decoder(self, params, grads=None, exp_avg=None, exp_avg_sq=None, max_exp_avg_sq=None):

@@ -28,12 +28,14 @@ def _uniform(t, k):
         t.uniform_(-k, k)
 
 
-def _lstm_only(model_name, n_layers, what):
-    if model_name != "LSTM":
-        raise NotImplementedError("%s: the HIP path implements model_name='LSTM' (got %r); GRU is a SURVEY §8f "
-                                  "follow-up" % (what, model_name))
+def _gates(model_name, n_layers, what):
+    """Rows of the recurrent weights per hidden unit: 4 (LSTM: i, f, g, o) or 3 (GRU: r, z, n) — torch.nn.LSTM /
+    torch.nn.GRU, the two cells the reference offers (decoder.py:32-40)."""
+    if model_name not in ("LSTM", "GRU"):
+        raise NotImplementedError("%s: unknown model_name %r (the reference has 'LSTM' and 'GRU')" % (what, model_name))
     if n_layers != 1:
         raise NotImplementedError("%s: n_layers must be 1 (got %r)" % (what, n_layers))
+    return 4 if model_name == "LSTM" else 3
 
 
 class Decoder(nn.Module):
@@ -42,7 +44,7 @@ class Decoder(nn.Module):
     def __init__(self, model_name, n_layers, encoder_size, embedding_size, embedding_scale, hidden_size,
                  attn_size, output_size, embedding_dropout, dropout, out_dropout, precision="bf16"):
         super().__init__()
-        _lstm_only(model_name, n_layers, "Decoder")
+        G = _gates(model_name, n_layers, "Decoder")
         self.model_name, self.n_layers = model_name, n_layers
         self.encoder_size, self.embedding_size, self.embedding_scale = encoder_size, embedding_size, embedding_scale
         self.hidden_size, self.attn_size, self.output_size = hidden_size, attn_size, output_size
@@ -55,8 +57,8 @@ class Decoder(nn.Module):
         self.attn_W = _Weights(weight=(A, H))
         self.attn_U = _Weights(weight=(A, D))
         self.attn_w = _Weights(weight=(1, A))
-        self.rnn = _Weights(weight_ih_l0=(4 * H, E + D), weight_hh_l0=(4 * H, H), bias_ih_l0=(4 * H,),
-                            bias_hh_l0=(4 * H,))
+        self.rnn = _Weights(weight_ih_l0=(G * H, E + D), weight_hh_l0=(G * H, H), bias_ih_l0=(G * H,),
+                            bias_hh_l0=(G * H,))
         self.out = _Weights(weight=(V, H), bias=(V,))
         self.reset_parameters()
         self._step_engines = {}
@@ -79,7 +81,7 @@ class Decoder(nn.Module):
 
     def dims(self, B, F):
         return dict(B=B, F=F, D=self.encoder_size, E=self.embedding_size, H=self.hidden_size, A=self.attn_size,
-                    V=self.output_size)
+                    V=self.output_size, dec_cell=self.model_name)
 
     def hyper(self):
         return dict(embedding_scale=self.embedding_scale, embedding_dropout=self.embedding_dropout_p,
@@ -90,7 +92,7 @@ class Decoder(nn.Module):
 
     def forward(self, input, hidden, encoder_outputs):
         """One decode step — Decoder.forward, decoder.py:45-70.  input [1,B] int64, hidden=(h,c) each
-        [1,B,H], encoder_outputs [B,F,D] -> (logits [B,V], (h',c'))."""
+        [1,B,H] (LSTM) or a single tensor h (GRU, train.py:33-35), encoder_outputs [B,F,D] -> (logits [B,V], hidden')."""
         B, F = encoder_outputs.shape[0], encoder_outputs.shape[1]
         key = (B, F, encoder_outputs.device)
         eng = self._step_engines.get(key)
@@ -111,12 +113,13 @@ class Decoder(nn.Module):
                 eng.pack_weights()
                 eng._pver = pver
             eng._inv_sig = sig
-        h, c = hidden
+        gru = self.model_name == "GRU"
+        h, c = (hidden, hidden) if gru else hidden
         logits, h2, c2 = eng.decoder_step(input.reshape(-1).contiguous(), h[-1].contiguous(), c[-1].contiguous(),
                                           enc if fresh else None, train=self.training,
                                           seed=self.dropout_seed, t=self._calls)
         self._calls += 1
-        return logits, (h2.unsqueeze(0), c2.unsqueeze(0))
+        return logits, (h2.unsqueeze(0) if gru else (h2.unsqueeze(0), c2.unsqueeze(0)))
 
 
 class _Reconstructor(nn.Module):
@@ -138,14 +141,14 @@ class GlobalReconstructor(_Reconstructor):
     def __init__(self, model_name, n_layers, decoder_hidden_size, hidden_size, dropout, decoder_dropout,
                  caption_max_len, precision="bf16"):
         super().__init__()
-        _lstm_only(model_name, n_layers, "GlobalReconstructor")
+        G = _gates(model_name, n_layers, "GlobalReconstructor")
         self.model_name, self.n_layers = model_name, n_layers
         self.decoder_hidden_size, self.hidden_size = decoder_hidden_size, hidden_size
         self.dropout_p, self.decoder_dropout_p, self.caption_max_len = dropout, decoder_dropout, caption_max_len
         self.precision = precision
         H, R = decoder_hidden_size, hidden_size
-        self.rnn = _Weights(weight_ih_l0=(4 * R, 2 * H), weight_hh_l0=(4 * R, R), bias_ih_l0=(4 * R,),
-                            bias_hh_l0=(4 * R,))
+        self.rnn = _Weights(weight_ih_l0=(G * R, 2 * H), weight_hh_l0=(G * R, R), bias_ih_l0=(G * R,),
+                            bias_hh_l0=(G * R,))
         self.out = _Weights(weight=(R, R), bias=(R,))
         for p in self.parameters():
             _uniform(p, 1 / math.sqrt(R))
@@ -158,7 +161,7 @@ class LocalReconstructor(_Reconstructor):
     def __init__(self, model_name, n_layers, decoder_hidden_size, hidden_size, dropout, decoder_dropout, attn_size,
                  precision="bf16"):
         super().__init__()
-        _lstm_only(model_name, n_layers, "LocalReconstructor")
+        G = _gates(model_name, n_layers, "LocalReconstructor")
         self.model_name, self.n_layers = model_name, n_layers
         self.decoder_hidden_size, self.hidden_size = decoder_hidden_size, hidden_size
         self.dropout_p, self.decoder_dropout_p, self.attn_size = dropout, decoder_dropout, attn_size
@@ -168,8 +171,8 @@ class LocalReconstructor(_Reconstructor):
         self.attn_W = _Weights(weight=(A, R))
         self.attn_U = _Weights(weight=(A, H))
         self.attn_w = _Weights(weight=(1, A))
-        self.rnn = _Weights(weight_ih_l0=(4 * R, H), weight_hh_l0=(4 * R, R), bias_ih_l0=(4 * R,),
-                            bias_hh_l0=(4 * R,))
+        self.rnn = _Weights(weight_ih_l0=(G * R, H), weight_hh_l0=(G * R, R), bias_ih_l0=(G * R,),
+                            bias_hh_l0=(G * R,))
         self.out = _Weights(weight=(R, R), bias=(R,))
         _uniform(self.attn_W.weight, 1 / math.sqrt(R))
         _uniform(self.attn_U.weight, 1 / math.sqrt(H))

@@ -101,8 +101,13 @@ def configure(*, B, F, D, V, E, H, A, dec_cell, rec_kind, rec_cell, RA):
     C.caption_max_len = 30
 
 
+ONLY = None   # --only a,b,c : regenerate just these cases
+
+
 def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None, rec_cell="LSTM",
              RA=None, train_mode=True, n_steps=3, seed=0, drop_seed=42, full=True, formula_seed=None):
+    if ONLY is not None and name not in ONLY:
+        return
     RA = RA or A
     configure(B=B, F=F, D=D, V=V, E=E, H=H, A=A, dec_cell=dec_cell, rec_kind=rec_kind, rec_cell=rec_cell, RA=RA)
     torch.manual_seed(seed)
@@ -126,7 +131,8 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
     out = {"meta_dims": np.array([B, F, D, V, E, H, A, RA], dtype=np.int64),
            "meta_lens": np.array(lens, dtype=np.int64), "meta_drop_seed": np.array(drop_seed),
            "meta_train_mode": np.array(int(train_mode)), "meta_n_steps": np.array(n_steps),
-           "meta_formula_seed": np.array(-1 if formula_seed is None else formula_seed)}
+           "meta_formula_seed": np.array(-1 if formula_seed is None else formula_seed),
+           "meta_cells": np.array([int(dec_cell == "GRU"), int(rec_cell == "GRU")], dtype=np.int64)}
     if full:
         out["enc"] = enc.numpy()
     out["targets"] = targets.numpy()
@@ -242,6 +248,8 @@ SMALL = dict(B=5, F=6, D=72, V=97, E=20, H=40, A=24)
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if "--only" in sys.argv:
+        ONLY = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     run_case("dec_eval", lens=[7, 3, 8, 1, 5], train_mode=False, **SMALL)
     run_case("dec_train", lens=[7, 3, 8, 1, 5], **SMALL)
     run_case("dec_T31", lens=[30, 4, 11, 2, 30], n_steps=1, **SMALL)
@@ -255,6 +263,10 @@ if __name__ == "__main__":
              n_steps=1, **SMALL)
     run_case("gru_global_eval", lens=[5, 2, 6, 3, 1], dec_cell="GRU", rec_kind="global", rec_cell="LSTM",
              train_mode=False, n_steps=1, **SMALL)
+    # GRU cells (config.py:31 default decoder_model): the gru_* cases above plus 3-step runs
+    run_case("gru_dec_train", lens=[7, 3, 8, 1, 5], dec_cell="GRU", **SMALL)
+    run_case("gru_global_train", lens=[7, 3, 8, 1, 5], dec_cell="GRU", rec_kind="global", rec_cell="GRU", **SMALL)
+    run_case("gru_local_train3", lens=[6, 9, 2, 4, 4], dec_cell="LSTM", rec_kind="local", rec_cell="GRU", RA=16, **SMALL)
     # full-shape cases (SURVEY.md §8a C1..C3 dims): parameters from formula_params(seed) so they can be
     # regenerated without the reference; only outputs / norms / slices are stored.
     FULL = dict(F=28, D=1536, V=4188, E=468, H=512, A=128)
@@ -262,3 +274,7 @@ if __name__ == "__main__":
     run_case("full_dec_B8", B=8, lens=lens8, n_steps=1, full=False, formula_seed=7, **FULL)
     run_case("full_global_B8", B=8, lens=lens8, rec_kind="global", n_steps=1, full=False, formula_seed=7, **FULL)
     run_case("full_local_B8", B=8, lens=lens8, rec_kind="local", n_steps=1, full=False, formula_seed=7, **FULL)
+    run_case("full_gru_global_B8", B=8, lens=lens8, dec_cell="GRU", rec_kind="global", rec_cell="GRU", n_steps=1,
+             full=False, formula_seed=7, **FULL)
+    run_case("full_gru_local_B8", B=8, lens=lens8, dec_cell="GRU", rec_kind="local", rec_cell="GRU", n_steps=1,
+             full=False, formula_seed=7, **FULL)

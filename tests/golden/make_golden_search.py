@@ -52,14 +52,15 @@ class Vocab:
     pass
 
 
-def run(name, B, F, D, V, E, H, A, seed, beam_widths=(1, 3, 5), scale=1.0, eos_bias=0.0, pad_bias=0.0):
+def run(name, B, F, D, V, E, H, A, seed, beam_widths=(1, 3, 5), scale=1.0, eos_bias=0.0, pad_bias=0.0, cell="LSTM"):
     cfg = Cfg()
-    cfg.caption_max_len, cfg.batch_size, cfg.decoder_model = 30, B, "LSTM"
+    cfg.caption_max_len, cfg.batch_size, cfg.decoder_model = 30, B, cell
+    ref_eval.C.decoder_model = cell
     vocab = Vocab()
     vocab.word2idx = {"<PAD>": 0, "<SOS>": 1, "<EOS>": 2}
     vocab.n_vocabs = V
-    dec = RefDecoder("LSTM", 1, D, E, 1, H, A, V, 0.5, 0.5, 0.5)
-    P = formula_params(decoder_shapes(V, E, H, A, D), seed)
+    dec = RefDecoder(cell, 1, D, E, 1, H, A, V, 0.5, 0.5, 0.5)
+    P = formula_params(decoder_shapes(V, E, H, A, D, cell), seed)
     # make the vocabulary projection decisive enough that <EOS>/<PAD> actually occur and hypotheses differ
     P["out.weight"] = P["out.weight"] * scale
     P["out.bias"] = P["out.bias"] * scale
@@ -71,15 +72,16 @@ def run(name, B, F, D, V, E, H, A, seed, beam_widths=(1, 3, 5), scale=1.0, eos_b
     enc = torch.randn(B, F, D, generator=g)
     out = {"meta_dims": np.array([B, F, D, V, E, H, A], dtype=np.int64), "meta_seed": np.array(seed),
            "meta_scale": np.array(scale), "meta_eos_bias": np.array(eos_bias), "meta_pad_bias": np.array(pad_bias),
-           "enc": enc.numpy()}
+           "enc": enc.numpy(), "meta_cells": np.array([int(cell == "GRU"), 0], dtype=np.int64)}
+    zero = (lambda: (torch.zeros(1, B, H), torch.zeros(1, B, H))) if cell == "LSTM" else (lambda: torch.zeros(1, B, H))
     with torch.no_grad():
         inp = torch.full((1, B), 1, dtype=torch.long)
-        hid = (torch.zeros(1, B, H), torch.zeros(1, B, H))
+        hid = zero()
         gi = ref_eval.greedy_search(cfg, dec, inp, hid, enc)
         out["greedy"] = np.array([[int(x) for x in row] for row in gi], dtype=np.int64)      # [n_steps][B]
         for bw in beam_widths:
             inp = torch.full((1, B), 1, dtype=torch.long)
-            hid = (torch.zeros(1, B, H), torch.zeros(1, B, H))
+            hid = zero()
             bo = ref_eval.beam_search(cfg, bw, vocab, dec, inp, hid, enc)                      # list over b of token lists
             out["beam%d" % bw] = np.array(bo, dtype=np.int64)                                  # [B][n_steps]
     path = os.path.join(HERE, name + ".npz")
@@ -91,7 +93,15 @@ def run(name, B, F, D, V, E, H, A, seed, beam_widths=(1, 3, 5), scale=1.0, eos_b
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if "--gru-only" in sys.argv:
+        run("search_gru", B=6, F=5, D=72, V=97, E=20, H=40, A=24, seed=6, scale=8.0, eos_bias=1.2, cell="GRU")
+        run("search_gru_b", B=6, F=5, D=72, V=97, E=20, H=40, A=24, seed=11, scale=20.0, eos_bias=1.2, cell="GRU")
+        run("search_gru_stop", B=4, F=6, D=64, V=61, E=16, H=32, A=16, seed=9, scale=4.0, pad_bias=9.0, cell="GRU")
+        sys.exit(0)
     run("search_small", B=6, F=5, D=72, V=97, E=20, H=40, A=24, seed=5, scale=8.0)
     run("search_small_b", B=4, F=6, D=64, V=61, E=16, H=32, A=16, seed=9, scale=20.0)
     run("search_eos", B=6, F=5, D=72, V=97, E=20, H=40, A=24, seed=5, scale=8.0, eos_bias=1.2)
     run("search_stop", B=4, F=6, D=64, V=61, E=16, H=32, A=16, seed=9, scale=4.0, pad_bias=9.0)
+    run("search_gru", B=6, F=5, D=72, V=97, E=20, H=40, A=24, seed=6, scale=8.0, eos_bias=1.2, cell="GRU")
+    run("search_gru_b", B=6, F=5, D=72, V=97, E=20, H=40, A=24, seed=11, scale=20.0, eos_bias=1.2, cell="GRU")
+    run("search_gru_stop", B=4, F=6, D=64, V=61, E=16, H=32, A=16, seed=9, scale=4.0, pad_bias=9.0, cell="GRU")

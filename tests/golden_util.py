@@ -54,6 +54,14 @@ def rec_shapes(kind, H, R, A, cell="LSTM"):
     return s
 
 
+def cells_of(g):
+    """(decoder cell, reconstructor cell) of a golden case; cases written before GRU support are LSTM/LSTM."""
+    mc = g.get("meta_cells")
+    if mc is None:
+        return ("LSTM", "LSTM")
+    return tuple("GRU" if int(x) else "LSTM" for x in mc)
+
+
 def load(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     return {k: z[k] for k in z.files}

@@ -17,12 +17,13 @@ TOL = {
 }
 
 
-def make_models(dims, kind, precision, decP, recP, device="cuda", batch=None):
+def make_models(dims, kind, precision, decP, recP, device="cuda", batch=None, cells=("LSTM", "LSTM")):
     B, F, D, V, E, H, A, RA = dims
     C = R.make_config(batch_size=B, encoder_output_len=F, encoder_output_size=D, embedding_size=E,
                       decoder_hidden_size=H, decoder_attn_size=A, use_recon=kind is not None,
                       reconstructor_type=kind or "local", reconstructor_hidden_size=D,
-                      reconstructor_attn_size=RA, precision=precision, device=device)
+                      reconstructor_attn_size=RA, precision=precision, device=device, decoder_model=cells[0],
+                      reconstructor_model=cells[1])
     dec = R.build_decoder(V, C)
     dec["model"].load_state_dict({k: v.clone() for k, v in decP.items()})
     rec = None
@@ -38,9 +39,10 @@ def load_case(name):
     B, F, D, V, E, H, A, RA = dims
     kind = "global" if "global" in name else ("local" if "local" in name else None)
     fs = int(g["meta_formula_seed"])
+    cells = g["_cells"] = GU.cells_of(g)
     if fs >= 0:
-        decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), fs)
-        recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), fs + 1) if kind else None
+        decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, cells[0]), fs)
+        recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA, cells[1]), fs + 1) if kind else None
         enc, targets = GU.make_batch(B, F, D, V, g["meta_lens"], int(g["meta_batch_seed"]))
     else:
         decP, recP = GU.group(g, "dec_init"), (GU.group(g, "rec_init") if kind else None)
@@ -60,9 +62,9 @@ def rel_err(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
 
 
-def oracle_grads(decP, recP, kind, enc, targets, train, seed, B_global=None, b_offset=0):
+def oracle_grads(decP, recP, kind, enc, targets, train, seed, B_global=None, b_offset=0, cells=("LSTM", "LSTM")):
     """Reference gradients (incl. the regulariser term) from the CPU oracle's autograd."""
-    st = O.TrainState(decP, recP, kind)
+    st = O.TrainState(decP, recP, kind, cell=cells[0], rec_cell=cells[1])
     drop = O.Dropper("hash", seed=seed) if train else O.Dropper("eval")
     masks = targets > 0
     dl, rl, hid, ce, mse = st.losses(enc, targets, masks, drop)

@@ -15,8 +15,9 @@ from tests.gpu_util import TOL, cosine, load_case, make_models, oracle_grads, re
 pytestmark = pytest.mark.gpu
 
 SMALL = ["dec_eval", "dec_train", "dec_T31", "dec_T4_samelen", "global_train", "global_eval", "local_train",
-         "local_eval", "local_T31"]
-FULL = ["full_dec_B8", "full_global_B8", "full_local_B8"]
+         "local_eval", "local_T31", "gru_local_train", "gru_global_eval", "gru_dec_train", "gru_global_train",
+         "gru_local_train3"]
+FULL = ["full_dec_B8", "full_global_B8", "full_local_B8", "full_gru_global_B8", "full_gru_local_B8"]
 REG_SLACK = 3e-4
 
 
@@ -25,21 +26,24 @@ REG_SLACK = 3e-4
 def test_step_api_matches_reference(name, prec):
     """Decoder.forward (decoder.py:45-70) step by step: logits and (h, c) against the golden vectors."""
     g, dims, kind, decP, recP, enc, targets = load_case(name)
-    C, dec, _ = make_models(dims, None, prec, decP, None)
+    C, dec, _ = make_models(dims, None, prec, decP, None, cells=g["_cells"])
     model = dec["model"]
+    gru = g["_cells"][0] == "GRU"
     train = bool(int(g["meta_train_mode"]))
     model.train(train)
     model.dropout_seed = int(g["meta_drop_seed"])
     B, H = dims[0], dims[5]
     encd = enc.cuda()
     tok = torch.full((1, B), 1, dtype=torch.long, device="cuda")
-    hid = (torch.zeros(1, B, H, device="cuda"), torch.zeros(1, B, H, device="cuda"))
+    # hidden: (h, c) for LSTM, a single tensor for GRU (train.py:28-35)
+    hid = torch.zeros(1, B, H, device="cuda") if gru else (torch.zeros(1, B, H, device="cuda"), torch.zeros(1, B, H, device="cuda"))
     tol = TOL[prec]
     for t in range(int(g["T"])):
         logits, hid = model(tok, hid, encd)
         tok = targets[t].view(1, -1).cuda()
-        assert np.abs(hid[0][0].cpu().numpy() - g["step_h"][t]).max() <= tol["hid"], t
-        assert np.abs(hid[1][0].cpu().numpy() - g["step_c"][t]).max() <= 2 * tol["hid"], t
+        assert np.abs((hid if gru else hid[0])[0].cpu().numpy() - g["step_h"][t]).max() <= tol["hid"], t
+        if not gru:
+            assert np.abs(hid[1][0].cpu().numpy() - g["step_c"][t]).max() <= 2 * tol["hid"], t
         if "step_logits" in g:
             ref = g["step_logits"][t]
             assert np.abs(logits.cpu().numpy() - ref).max() <= tol["hid"] * 4 * max(1.0, np.abs(ref).max()), t
@@ -51,7 +55,7 @@ def test_autograd_api_losses_and_grads(name, prec):
     """forward_decoder / forward_*_reconstructor + loss.backward() (train.py:250-268) against the goldens:
     losses, hidden states, every parameter gradient (norm-regulariser term included)."""
     g, dims, kind, decP, recP, enc, targets = load_case(name)
-    C, dec, rec = make_models(dims, kind, prec, decP, recP)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP, cells=g["_cells"])
     train = bool(int(g["meta_train_mode"]))
     seed = int(g["meta_drop_seed"])
     dec["model"].train(train)
@@ -107,12 +111,13 @@ def test_autograd_api_losses_and_grads(name, prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["dec_train", "global_train", "local_train"])
+@pytest.mark.parametrize("name", ["dec_train", "global_train", "local_train", "gru_dec_train", "gru_global_train",
+                                  "gru_local_train3"])
 def test_fused_train_steps_match_reference_optimizer(name, prec):
     """TrainStep (train.py:248-273 fused: fwd, bwd, regulariser, clip, AMSGrad + Adam) for 3 iterations:
     parameters and Adam state against what the reference produced."""
     g, dims, kind, decP, recP, enc, targets = load_case(name)
-    C, dec, rec = make_models(dims, kind, prec, decP, recP)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP, cells=g["_cells"])
     step = R.TrainStep(dec, rec)
     encd, tg = enc.cuda(), targets.cuda()
     T, w = step.prepare(targets.numpy())
@@ -139,16 +144,19 @@ def test_fused_train_steps_match_reference_optimizer(name, prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("cells", [("LSTM", "LSTM"), ("GRU", "GRU"), ("GRU", "LSTM")])
 @pytest.mark.parametrize("kind", [None, "global", "local"])
-def test_fused_step_vs_oracle_ragged_shapes(kind, prec):
+def test_fused_step_vs_oracle_ragged_shapes(kind, prec, cells):
     """Shapes that are multiples of nothing (B=7, V=101, E=18, D=R=88, H=36, A=20, F=5), train mode with
-    dropout: fused fwd+bwd gradients against the CPU oracle's autograd."""
+    dropout: fused fwd+bwd gradients against the CPU oracle's autograd; LSTM and GRU cells."""
+    if kind is None and cells == ("GRU", "LSTM"):
+        pytest.skip("same as GRU/GRU without a reconstructor")
     dims = [7, 5, 88, 101, 18, 36, 20, 12]
     B, F, D, V, E, H, A, RA = dims
-    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 11)
-    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 12) if kind else None
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, cells[0]), 11)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA, cells[1]), 12) if kind else None
     enc, targets = GU.make_batch(B, F, D, V, [9, 2, 5, 12, 1, 7, 4], 77)
-    C, dec, rec = make_models(dims, kind, prec, decP, recP)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP, cells=cells)
     step = R.TrainStep(dec, rec)
     T, w = step.prepare(targets.numpy())
     step.fwd_bwd(enc.cuda(), targets.cuda(), T, w, seed=5)
@@ -156,7 +164,7 @@ def test_fused_step_vs_oracle_ragged_shapes(kind, prec):
     if kind:
         step.engine.add_reg_grad(1, 1.0)
     torch.cuda.synchronize()
-    ref = oracle_grads(decP, recP, kind, enc, targets, True, 5)
+    ref = oracle_grads(decP, recP, kind, enc, targets, True, 5, cells=cells)
     sc = step.engine.scalar_dict()
     tol = TOL[prec]
     assert abs(sc["dec_loss"] - ref["dec_loss"]) <= tol["loss"] * abs(ref["dec_loss"])

@@ -18,13 +18,16 @@ class _Cfg:
 
 def _decoder(g, P, prec):
     B, F, D, V, E, H, A = [int(x) for x in g["meta_dims"]]
-    dec = R.Decoder("LSTM", 1, D, E, 1, H, A, V, 0.5, 0.5, 0.5, precision=prec)
+    cell = g["_cell"]
+    dec = R.Decoder(cell, 1, D, E, 1, H, A, V, 0.5, 0.5, 0.5, precision=prec)
     dec.load_state_dict(P)
     dec = dec.cuda().eval()
     cfg = _Cfg()
-    cfg.batch_size = B
+    cfg.batch_size, cfg.decoder_model = B, cell
     inp = torch.full((1, B), 1, dtype=torch.long, device="cuda")
     hid = (torch.zeros(1, B, H, device="cuda"), torch.zeros(1, B, H, device="cuda"))
+    if cell == "GRU":
+        hid = hid[0]                                     # a single tensor (eval.py:136-141)
     return dec, cfg, inp, hid
 
 

@@ -60,7 +60,8 @@ def test_modules_have_the_reference_parameter_sets(name, kind):
 
 def test_unsupported_variants_raise_like_the_reference_enum_checks():
     with pytest.raises(NotImplementedError):
-        R.Decoder("GRU", 1, 8, 4, 1, 8, 4, 16, 0.5, 0.5, 0.5)
+        R.Decoder("RNN", 1, 8, 4, 1, 8, 4, 16, 0.5, 0.5, 0.5)
+    assert R.Decoder("GRU", 1, 8, 4, 1, 8, 4, 16, 0.5, 0.5, 0.5).rnn.weight_ih_l0.shape == (3 * 8, 4 + 8)   # nn.GRU rows
     with pytest.raises(NotImplementedError):
         R.LocalReconstructor("LSTM", 2, 8, 8, 0.5, 0.5, 4)
     C = R.make_config(reconstructor_type="middle", device="cpu")

@@ -8,14 +8,15 @@ from oracle import recnet_oracle as O
 from tests import golden_util as GU
 
 SMALL_CASES = ["dec_eval", "dec_train", "dec_T31", "dec_T4_samelen", "global_train", "global_eval",
-               "local_train", "local_eval", "local_T31", "gru_local_train", "gru_global_eval"]
-FULL_CASES = ["full_dec_B8", "full_global_B8", "full_local_B8"]
+               "local_train", "local_eval", "local_T31", "gru_local_train", "gru_global_eval", "gru_dec_train",
+               "gru_global_train", "gru_local_train3"]
+FULL_CASES = ["full_dec_B8", "full_global_B8", "full_local_B8", "full_gru_global_B8", "full_gru_local_B8"]
 
 
 def _setup(name):
     g = GU.load(name)
     B, F, D, V, E, H, A, RA = [int(x) for x in g["meta_dims"]]
-    cells = ("GRU", "GRU") if name.startswith("gru_local") else (("GRU", "LSTM") if name.startswith("gru_") else ("LSTM", "LSTM"))
+    cells = GU.cells_of(g)
     kind = "global" if "global" in name else ("local" if "local" in name else None)
     fs = int(g["meta_formula_seed"])
     if fs >= 0:

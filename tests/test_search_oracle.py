@@ -6,13 +6,14 @@ import torch
 from oracle import search_oracle as S
 from tests import golden_util as GU
 
-CASES = ["search_small", "search_small_b", "search_eos", "search_stop"]
+CASES = ["search_small", "search_small_b", "search_eos", "search_stop", "search_gru", "search_gru_b", "search_gru_stop"]
 
 
 def load_search_case(name):
     g = GU.load(name)
     B, F, D, V, E, H, A = [int(x) for x in g["meta_dims"]]
-    P = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), int(g["meta_seed"]))
+    g["_cell"] = GU.cells_of(g)[0]
+    P = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, g["_cell"]), int(g["meta_seed"]))
     sc = float(g["meta_scale"])
     P["out.weight"] = P["out.weight"] * sc
     P["out.bias"] = P["out.bias"] * sc
@@ -25,7 +26,7 @@ def load_search_case(name):
 def test_greedy_matches_reference(name):
     g, P, enc = load_search_case(name)
     with torch.no_grad():
-        out = S.greedy_search(P, enc)
+        out = S.greedy_search(P, enc, cell=g["_cell"])
     assert np.array_equal(out, g["greedy"])
 
 
@@ -34,5 +35,5 @@ def test_greedy_matches_reference(name):
 def test_beam_matches_reference(name, bw):
     g, P, enc = load_search_case(name)
     with torch.no_grad():
-        out = S.beam_search(P, enc, bw)
+        out = S.beam_search(P, enc, bw, cell=g["_cell"])
     assert np.array_equal(out, g["beam%d" % bw])
