@@ -176,6 +176,15 @@ int recnet_forward_decoder(recnet_handle* h, const float* enc, const int64_t* ta
                            const float* step_weight, int32_t train, uint32_t seed, float* hiddens_out,
                            recnet_scalars* scalars, void* stream);
 
+/* ---- forward_decoder without teacher forcing, train.py:46-51 — the validation pass (train.py:327 calls
+ * forward_decoder with the default teacher_forcing_ratio = 0): the input of step t+1 is the arg-max of the logits
+ * Decoder.forward returned at step t.  Same arguments and loss as recnet_forward_decoder (targets / masks only enter the
+ * loss and T); output_indices [T,B] int64 receives the fed-back tokens (train.py:50, `output_indices`).  Forward only:
+ * recnet_backward_decoder after it returns RECNET_ESTATE; the hidden states do feed recnet_forward_reconstructor. */
+int recnet_forward_decoder_free(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                                const float* step_weight, int32_t train, uint32_t seed, float* hiddens_out,
+                                int64_t* output_indices, recnet_scalars* scalars, void* stream);
+
 /* ---- forward_global_reconstructor (train.py:78-105) / forward_local_reconstructor (train.py:108-131),
  * selected by cfg.reconstructor_type.  Consumes the hidden states left by recnet_forward_decoder
  * (or `hiddens` [T,1,B,H] when not NULL).  mse_count = GLOBAL element count of the MSE mean

@@ -62,6 +62,8 @@ EXPORTS = {
     "recnet_decoder_step": (_i, [C.c_void_p] + [C.c_void_p] * 7 + [_i, C.c_uint32, _i, C.c_void_p]),
     "recnet_forward_decoder": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.c_void_p, _i, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "recnet_forward_decoder_free": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.c_void_p, _i, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "recnet_forward_reconstructor": (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, _i, C.c_uint32, C.c_void_p,
                                           C.c_void_p]),
     "recnet_backward_reconstructor": (_i, [C.c_void_p, C.c_void_p, _f, C.c_void_p, C.c_void_p]),

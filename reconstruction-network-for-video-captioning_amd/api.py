@@ -12,6 +12,8 @@ backward kernels and leaves the gradients in `param.grad` (views of one flat buf
 `TrainStep` is the same computation as one stream-ordered launch sequence with the regulariser
 gradient, clipping and both Adam updates fused in — the path bench.py times.
 """
+import random
+
 import numpy as np
 import torch
 
@@ -171,6 +173,44 @@ class FusedAdam(torch.optim.Optimizer):
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._ms.step))
 
+    def state_dict(self):
+        """torch.optim.Adam's layout ({'state': {i: {step, exp_avg, exp_avg_sq[, max_exp_avg_sq]}}, 'param_groups'}),
+        which is what the reference stores under 'dec_opt' / 'rec_opt' (train.py:404-406)."""
+        self._ensure_state()
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._ms.step))
+        return super().state_dict()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Accepts a torch.optim.Adam state_dict (the reference's checkpoints) or one of ours: the moments are copied
+        INTO the flat device buffers the HIP optimiser is bound to (torch's own load would re-point the state at fresh
+        tensors), the step count into the model state, the hyper-parameters into the param group."""
+        self._ensure_state()
+        params = self.param_groups[0]["params"]
+        saved = state_dict["state"]
+        ids = state_dict["param_groups"][0]["params"]
+        if len(ids) != len(params):
+            raise ValueError("optimizer state_dict has %d parameters, the model has %d" % (len(ids), len(params)))
+        step = None
+        for pid, p in zip(ids, params):
+            st = saved.get(pid, saved.get(str(pid)))
+            if st is None:                                # a parameter that never received a step
+                continue
+            mine = self.state[p]
+            for k in ("exp_avg", "exp_avg_sq") + (("max_exp_avg_sq",) if self._ms.amsgrad else ()):
+                if k not in st:
+                    raise KeyError("optimizer state lacks %r (amsgrad mismatch?)" % k)
+                mine[k].copy_(st[k].to(mine[k].device, torch.float32).reshape(mine[k].shape))
+            step = int(float(st["step"])) if step is None else step
+        self._ms.step = step or 0
+        g, sg = self.param_groups[0], state_dict["param_groups"][0]
+        for k in ("lr", "betas", "eps", "weight_decay", "amsgrad"):
+            if k in sg:
+                g[k] = sg[k]
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._ms.step))
+
     def zero_grad(self, set_to_none=True):
         # every backward overwrites the flat gradient buffer (the reference zero_grad()s before each
         # backward, train.py:265-267), so dropping the references is all that is needed
@@ -276,10 +316,13 @@ def _engine_for(model_dict, key, factory, which):
 
 
 def forward_decoder(decoder, encoder_outputs, targets, target_masks, teacher_forcing_ratio=0., seed=None):
-    """train.py:17-75 (teacher-forced).  Returns (loss, hiddens [T,1,B,H], output_indices)."""
-    if teacher_forcing_ratio < 1.0:
-        raise NotImplementedError("free-running decoding (teacher_forcing_ratio < 1, the validation branch "
-                                  "train.py:46-51) is outside the train-step hot path")
+    """train.py:17-75.  Returns (loss, hiddens [T,1,B,H], output_indices).
+
+    Teacher forcing is drawn like the reference does (`random.random() <= teacher_forcing_ratio`, train.py:38).  The
+    teacher-forced pass (training: config.py:71 ratio 1.0) is differentiable; output_indices is empty.  The free-running
+    pass (validation, train.py:327 — the default ratio 0) feeds the arg-max back on the device, returns
+    output_indices [T,B] and is forward-only: loss and hiddens carry no autograd graph."""
+    use_teacher_forcing = random.random() <= teacher_forcing_ratio
     model = decoder["model"]
     B, F = encoder_outputs.shape[0], encoder_outputs.shape[1]
     masks = _host_masks(targets, target_masks)
@@ -291,6 +334,11 @@ def forward_decoder(decoder, encoder_outputs, targets, target_masks, teacher_for
     eng.pack_weights()
     seed = decoder["_C"].dropout_seed + decoder["_state"].step if seed is None else seed
     decoder["_last_seed"] = seed
+    if not use_teacher_forcing:
+        with torch.no_grad():
+            hid, out = eng.forward_decoder_free(encoder_outputs.contiguous(), targets.contiguous(), T, stepw,
+                                                train=model.training, seed=seed)
+            return eng.scalars[2].clone(), hid, out
     loss, hid = _DecoderSeq.apply(eng, decoder["_state"], encoder_outputs.contiguous(), targets.contiguous(), T,
                                   stepw, model.training, seed, *decoder["_state"].params().values())
     return loss, hid, torch.zeros(0, dtype=torch.long)

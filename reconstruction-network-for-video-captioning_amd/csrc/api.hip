@@ -594,28 +594,43 @@ static void dec_invariants(recnet_handle* h, const float* enc, hipStream_t st) {
   gemm(h, h->enc_lp, 0, h->ldD, h->U_w, 0, h->ldD, h->Uv, A, nullptr, B * F, A, D, 1.f, 0, st);
   gemm_to_at(h, h->enc_lp, 0, h->ldD, h->Wc_w, 0, h->ldD, h->P, h->ld4H, B * F, 4 * H, D, st);
 }
-static void embed_fwd(recnet_handle* h, const int64_t* targets, const int64_t* tokens, int rows, int train, int t0, hipStream_t st) {
+static void embed_fwd(recnet_handle* h, const int64_t* targets, const int64_t* tokens, int rows, int train, int t0, hipStream_t st,
+                      size_t row0 = 0) {
   const DropDesc dd = mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train);
-  if (h->lp) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(rows), dim3(128), 0, st, h->dP.embedding_weight, targets, tokens, (bf16_t*)h->emb_lp, h->ldE, h->B, h->E, h->V, h->c.embedding_scale, dd, t0);
-  else hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(rows), dim3(128), 0, st, h->dP.embedding_weight, targets, tokens, (float*)h->emb_lp, h->ldE, h->B, h->E, h->V, h->c.embedding_scale, dd, t0);
+  void* dst = at_off(h, h->emb_lp, row0 * h->ldE);
+  if (h->lp) hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, dim3(rows), dim3(128), 0, st, h->dP.embedding_weight, targets, tokens, (bf16_t*)dst, h->ldE, h->B, h->E, h->V, h->c.embedding_scale, dd, t0);
+  else hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(rows), dim3(128), 0, st, h->dP.embedding_weight, targets, tokens, (float*)dst, h->ldE, h->B, h->E, h->V, h->c.embedding_scale, dd, t0);
 }
 
 // ---------------------------------------------------------------------------------------------- decoder forward
 // the dependent chain: invariants, embeddings, T x (GEMM + cell kernel)
-static int dec_fwd_chain(recnet_handle* h, const float* enc, const int64_t* targets, int T, int train, hipStream_t st) {
-  const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A;
+// free_tokens != nullptr: free-running decoding (train.py:46-51) — the input of step t+1 is the argmax of step t's
+// (dropped-out) logits, written to free_tokens [T][B]; the per-step embedding / input projection / vocabulary projection
+// then sit inside the chain.  Forward only.
+static int dec_fwd_chain(recnet_handle* h, const float* enc, const int64_t* targets, int T, int train, hipStream_t st,
+                         int64_t* free_tokens = nullptr) {
+  const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A, V = h->V;
   param_norms(h, 0, h->scal + 1, st);
   dec_invariants(h, enc, st);
-  // all T teacher-forced input embeddings at once    (decoder.py:46-48, train.py:25,45)
-  embed_fwd(h, targets, nullptr, T * B, train, 0, st);
-  // Xe = emb . W_ih[:, :E]^T + b_ih + b_hh
-  gemm(h, h->emb_lp, 0, h->ldE, h->We_w, 0, h->ldE, h->Xe, 4 * H, h->bsum_d, T * B, 4 * H, E, 1.f, 0, st);
+  if (!free_tokens) {
+    // all T teacher-forced input embeddings at once    (decoder.py:46-48, train.py:25,45)
+    embed_fwd(h, targets, nullptr, T * B, train, 0, st);
+    // Xe = emb . W_ih[:, :E]^T + b_ih + b_hh
+    gemm(h, h->emb_lp, 0, h->ldE, h->We_w, 0, h->ldE, h->Xe, 4 * H, h->bsum_d, T * B, 4 * H, E, 1.f, 0, st);
+  } else {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, h->sr_tok[0], (int64_t)1, B);   // <SOS>, train.py:25
+  }
   DecCellArgs a;
   a.B = B; a.F = F; a.H = H; a.A = A;
   a.P = h->P; a.ldp = h->ld4H; a.Uv = h->Uv; a.ab = h->dP.attn_b; a.w = h->dP.attn_w_weight;
   a.ld_hlp = h->ldH; a.gru = h->dgru;
   const float* prev_state = h->dgru ? h->Hs : h->Cs;   // what the pointwise part carries: h_{t-1} (GRU) / c_{t-1}
   for (int t = 0; t < T; ++t) {
+    if (free_tokens) {
+      embed_fwd(h, nullptr, t == 0 ? h->sr_tok[0] : free_tokens + (size_t)(t - 1) * B, B, train, t, st, (size_t)t * B);
+      gemm(h, at_off(h, h->emb_lp, (size_t)t * B * h->ldE), 0, h->ldE, h->We_w, 0, h->ldE, h->Xe + (size_t)t * B * 4 * H, 4 * H,
+           h->bsum_d, B, 4 * H, E, 1.f, 0, st);
+    }
     int S = 0;
     if (t > 0)   // h_{t-1} . [W_hh ; attn_W]^T  -> recurrent gate part + Wh of the attention
       S = gemm_slabs(h, RN_TAG_DEC_FWD, at_off(h, h->Hs_lp, (size_t)(t - 1) * B * h->ldH), h->ldH, h->Wcomb, 0, h->ldH, B, 4 * H + A, H, st);
@@ -627,14 +642,27 @@ static int dec_fwd_chain(recnet_handle* h, const float* enc, const int64_t* targ
     a.acts = h->acts + (size_t)t * B * 4 * H;
     a.Wh_out = h->Wh + (size_t)t * B * A; a.att_out = h->att + (size_t)t * B * F;
     launch_dec_cell(h, a, st);
+    if (free_tokens) {   // logits_t, then argmax of what Decoder.forward returns (the dropped-out logits, decoder.py:68-69)
+      float* lg = h->logits + (size_t)t * B * V;
+      gemm(h, at_off(h, h->Hs_lp, (size_t)t * B * h->ldH), 0, h->ldH, h->Wo_w, 0, h->ldH, lg, V, h->dP.out_bias, B, V, H, 1.f, 0, st);
+      const float* pick = lg;
+      if (train && h->c.decoder_out_dropout > 0.f) {
+        copyf(lg, h->sr_logits, (size_t)B * V, st);
+        hipLaunchKernelGGL(logits_drop_kernel, dim3(ew_blocks((size_t)B * V)), dim3(256), 0, st, h->sr_logits, B, V,
+                           mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train), t);
+        pick = h->sr_logits;
+      }
+      hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, st, pick, V, V, free_tokens + (size_t)t * B);
+    }
   }
   h->T_last = T; h->train_last = train;
   return RECNET_OK;
 }
 // vocabulary projection + loss for all steps (decoder.py:68-69, train.py:54-68); independent of the reconstructor
-static int dec_fwd_loss(recnet_handle* h, const int64_t* targets, int T, const float* stepw, int train, hipStream_t st) {
+static int dec_fwd_loss(recnet_handle* h, const int64_t* targets, int T, const float* stepw, int train, hipStream_t st,
+                        int have_logits = 0) {
   const int B = h->B, H = h->H, V = h->V;
-  gemm(h, h->Hs_lp, 0, h->ldH, h->Wo_w, 0, h->ldH, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
+  if (!have_logits) gemm(h, h->Hs_lp, 0, h->ldH, h->Wo_w, 0, h->ldH, h->logits, V, h->dP.out_bias, T * B, V, H, 1.f, 0, st);
   copyf(stepw, h->stepw, T, st);
   {
     const DropDesc dd = mkdrop(h, RN_SITE_DEC_LOGIT, h->c.decoder_out_dropout, train);
@@ -647,11 +675,12 @@ static int dec_fwd_loss(recnet_handle* h, const int64_t* targets, int T, const f
   return RECNET_OK;
 }
 static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw,
-                       int train, float* hiddens_out, hipStream_t st) {
-  int r = dec_fwd_chain(h, enc, targets, T, train, st); if (r) return r;
-  r = dec_fwd_loss(h, targets, T, stepw, train, st); if (r) return r;
+                       int train, float* hiddens_out, hipStream_t st, int64_t* free_tokens = nullptr) {
+  int r = dec_fwd_chain(h, enc, targets, T, train, st, free_tokens); if (r) return r;
+  r = dec_fwd_loss(h, targets, T, stepw, train, st, free_tokens != nullptr); if (r) return r;
   if (hiddens_out) copyf(h->Hs, hiddens_out, (size_t)T * h->B * h->H, st);
-  h->fwd_dec_done = 1; h->fwd_rec_done = 0; h->rec_bwd_done = 0;
+  // 2: hidden states are valid for the reconstructor's forward, but there is no backward through a free-running pass
+  h->fwd_dec_done = free_tokens ? 2 : 1; h->fwd_rec_done = 0; h->rec_bwd_done = 0;
   return RECNET_OK;
 }
 
@@ -1138,6 +1167,21 @@ int recnet_forward_decoder(recnet_handle* h, const float* enc, const int64_t* ta
   return RECNET_OK;
 }
 
+int recnet_forward_decoder_free(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
+                                const float* step_weight, int32_t train, uint32_t seed, float* hiddens_out,
+                                int64_t* output_indices, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  if (!h->dec_bound) return fail(RECNET_ESTATE, "decoder not bound");
+  if (!enc || !targets || !step_weight || !output_indices) return fail(RECNET_EINVAL, "null argument");
+  if (check_T(h, T)) return fail(RECNET_EINVAL, "T out of range");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
+  int r = fwd_decoder(h, enc, targets, T, step_weight, train, hiddens_out, st, output_indices); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
 int recnet_forward_reconstructor(recnet_handle* h, const float* enc, const float* hiddens, int32_t T,
                                  int32_t train, uint32_t seed, recnet_scalars* scalars, void* stream) {
   REQUIRE_WS(h);
@@ -1176,6 +1220,7 @@ int recnet_backward_decoder(recnet_handle* h, const float* enc, const int64_t* t
                             float grad_scale, void* stream) {
   REQUIRE_WS(h);
   if (!h->fwd_dec_done) return fail(RECNET_ESTATE, "backward_decoder before forward_decoder");
+  if (h->fwd_dec_done == 2) return fail(RECNET_ESTATE, "the free-running forward (recnet_forward_decoder_free) has no backward");
   if (!h->dGd.out_weight) return fail(RECNET_ESTATE, "decoder gradients not bound");
   if (!enc || !targets) return fail(RECNET_EINVAL, "null argument");
   int r = bwd_decoder(h, enc, targets, dhiddens, grad_scale, (hipStream_t)stream); if (r) return r;

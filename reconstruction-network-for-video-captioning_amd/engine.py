@@ -245,6 +245,21 @@ class Engine:
         self.T = T
         return hid
 
+    def forward_decoder_free(self, enc, targets, T, step_weight, train=False, seed=0):
+        """Free-running pass (train.py:46-51): returns (hiddens [T,1,B,H], output_indices [T,B] int64).  Forward only."""
+        d = self.dims
+        B = d["B"]
+        _chk_tensor(enc, (B, d["F"], d["D"]), torch.float32, "encoder_outputs")
+        _chk_tensor(targets, (self.hyper["caption_max_len"] + 1, B), torch.int64, "targets")
+        _chk_tensor(step_weight, (T,), torch.float32, "step_weight")
+        hid = torch.empty(T, 1, B, d["H"], dtype=torch.float32, device=self.device)
+        out = torch.empty(T, B, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.recnet_forward_decoder_free(self.handle, _ptr(enc), _ptr(targets), int(T), _ptr(step_weight),
+                                                        int(train), seed & 0xFFFFFFFF, _ptr(hid), _ptr(out),
+                                                        _ptr(self.scalars), _stream()), "recnet_forward_decoder_free")
+        self.T = T
+        return hid, out
+
     def forward_reconstructor(self, enc, hiddens, T, train=True, seed=0):
         d = self.dims
         _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")

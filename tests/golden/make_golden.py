@@ -244,6 +244,49 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
         os.path.getsize(path) / 1024))
 
 
+def run_free_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None, rec_cell="LSTM", RA=None, seed=0,
+                  out_scale=6.0):
+    """The validation pass of train.py:310-340: model.eval(), forward_decoder with the default teacher_forcing_ratio
+    (0 -> free running, arg-max fed back), then the reconstructor on the free-running hidden states."""
+    if ONLY is not None and name not in ONLY:
+        return
+    RA = RA or A
+    configure(B=B, F=F, D=D, V=V, E=E, H=H, A=A, dec_cell=dec_cell, rec_kind=rec_kind, rec_cell=rec_cell, RA=RA)
+    torch.manual_seed(seed)
+    dec = ref_train.build_decoder(V)
+    rec = ref_train.build_reconstructor() if rec_kind else None
+    dm = dec["model"]
+    with torch.no_grad():       # a decisive vocabulary projection, so the arg-max is not a coin flip at default init
+        dm.out.weight.mul_(out_scale)
+        dm.out.bias.mul_(out_scale)
+    enc, targets = make_batch(B, F, D, V, lens, seed + 100)
+    masks = targets > 0
+    out = {"meta_dims": np.array([B, F, D, V, E, H, A, RA], dtype=np.int64), "meta_lens": np.array(lens, dtype=np.int64),
+           "meta_cells": np.array([int(dec_cell == "GRU"), int(rec_cell == "GRU")], dtype=np.int64),
+           "meta_formula_seed": np.array(-1), "enc": enc.numpy(), "targets": targets.numpy()}
+    for k, v in dm.state_dict().items():
+        out["dec_init/" + k] = v.detach().numpy().copy()
+    if rec:
+        for k, v in rec["model"].state_dict().items():
+            out["rec_init/" + k] = v.detach().numpy().copy()
+    dm.eval()
+    with torch.no_grad():
+        dl, hiddens, idx = ref_train.forward_decoder(dec, enc, targets, masks)       # train.py:327
+        out["T"] = np.array(hiddens.shape[0])
+        out["dec_loss"] = np.array(dl.item(), dtype=np.float64)
+        out["hiddens"] = hiddens.numpy().copy()
+        out["output_indices"] = idx.numpy().astype(np.int64)
+        if rec:
+            rec["model"].eval()
+            fwd_rec = {"global": ref_train.forward_global_reconstructor, "local": ref_train.forward_local_reconstructor}[rec_kind]
+            out["rec_loss"] = np.array(fwd_rec(hiddens, enc, rec).item(), dtype=np.float64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-28s T=%2d dec_loss=%.6f distinct tokens %d, == targets %.2f  %6.1f KB" % (
+        name, int(out["T"]), float(out["dec_loss"]), len(set(out["output_indices"].ravel().tolist())),
+        float((out["output_indices"] == targets.numpy()[:int(out["T"])]).mean()), os.path.getsize(path) / 1024))
+
+
 SMALL = dict(B=5, F=6, D=72, V=97, E=20, H=40, A=24)
 
 if __name__ == "__main__":
@@ -267,6 +310,10 @@ if __name__ == "__main__":
     run_case("gru_dec_train", lens=[7, 3, 8, 1, 5], dec_cell="GRU", **SMALL)
     run_case("gru_global_train", lens=[7, 3, 8, 1, 5], dec_cell="GRU", rec_kind="global", rec_cell="GRU", **SMALL)
     run_case("gru_local_train3", lens=[6, 9, 2, 4, 4], dec_cell="LSTM", rec_kind="local", rec_cell="GRU", RA=16, **SMALL)
+    # validation pass (free-running decoder, eval mode): SURVEY.md §8f-4
+    run_free_case("free_dec", lens=[7, 3, 8, 1, 5], **SMALL)
+    run_free_case("free_global", lens=[6, 9, 2, 4, 4], rec_kind="global", **SMALL)
+    run_free_case("free_local_gru", lens=[30, 4, 11, 2, 9], dec_cell="GRU", rec_kind="local", rec_cell="GRU", RA=16, **SMALL)
     # full-shape cases (SURVEY.md §8a C1..C3 dims): parameters from formula_params(seed) so they can be
     # regenerated without the reference; only outputs / norms / slices are stored.
     FULL = dict(F=28, D=1536, V=4188, E=468, H=512, A=128)

@@ -180,3 +180,32 @@ def test_fused_step_vs_oracle_ragged_shapes(kind, prec, cells):
             if e > tol["grad"]:
                 bad.append((grp, k, e))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["free_dec", "free_global", "free_local_gru"])
+def test_free_running_validation_pass(name, prec):
+    """forward_decoder with the reference's default teacher_forcing_ratio (0: the validation call, train.py:327) in eval
+    mode: on-device arg-max feedback; tokens exact in the fp32 path, then the reconstructor on those hidden states."""
+    g, dims, kind, decP, recP, enc, targets = load_case(name)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP, cells=g["_cells"])
+    dec["model"].eval()
+    encd, tg = enc.cuda(), targets.cuda()
+    dl, hid, idx = R.forward_decoder(dec, encd, tg, tg > 0)
+    tol = TOL[prec]
+    T = int(g["T"])
+    assert tuple(idx.shape) == (T, dims[0]) and not dl.requires_grad
+    agree = float((idx.cpu().numpy() == g["output_indices"]).mean())
+    if prec == "f32":
+        assert agree == 1.0
+        assert np.abs(hid.cpu().numpy() - g["hiddens"]).max() <= tol["hid"]
+        assert abs(float(dl) - float(g["dec_loss"])) <= tol["loss"] * abs(float(g["dec_loss"]))
+    else:
+        assert agree >= 0.6          # one flipped near-tie changes every later token of that caption
+    if kind and prec == "f32":
+        rec["model"].eval()
+        fwd = R.forward_global_reconstructor if kind == "global" else R.forward_local_reconstructor
+        rl = fwd(hid, encd, rec)
+        assert abs(float(rl.detach()) - float(g["rec_loss"])) <= tol["loss"] * abs(float(g["rec_loss"]))
+    with pytest.raises(Exception):   # forward-only: no graph to differentiate
+        dl.backward()

@@ -114,3 +114,23 @@ def test_gradients_and_optimizer(name):
         for k in st.dec:
             np.testing.assert_allclose(st.dec[k].detach().numpy().reshape(-1)[:64],
                                        g["dec_pslice_after%d/%s" % (n_steps, k)], atol=1e-6, rtol=0)
+
+
+FREE_CASES = ["free_dec", "free_global", "free_local_gru"]
+
+
+@pytest.mark.parametrize("name", FREE_CASES)
+def test_free_running_validation_pass(name):
+    """train.py:310-340: eval mode, forward_decoder with teacher_forcing_ratio 0 (arg-max fed back), then the
+    reconstructor on those hidden states — tokens exact, losses / hidden states to fp32 rounding."""
+    g, decP, recP, kind, cells, enc, targets = _setup(name)
+    with torch.no_grad():
+        dl, hid, idx = O.forward_decoder(decP, enc, targets, targets > 0, cell=cells[0], drop=O.Dropper("eval"),
+                                         teacher_forcing=False)
+        assert np.array_equal(idx.numpy(), g["output_indices"])
+        np.testing.assert_allclose(hid.numpy(), g["hiddens"], atol=2e-6, rtol=0)
+        assert abs(float(dl) - float(g["dec_loss"])) <= 2e-6 * max(1.0, abs(float(g["dec_loss"])))
+        if kind:
+            fwd = O.forward_global_reconstructor if kind == "global" else O.forward_local_reconstructor
+            rl = fwd(recP, hid, enc, cell=cells[1], drop=O.Dropper("eval"))
+            assert abs(float(rl) - float(g["rec_loss"])) <= 2e-6 * max(1.0, abs(float(g["rec_loss"])))
