@@ -17,4 +17,5 @@ from .api import (build_decoder, build_reconstructor, forward_decoder, forward_g
                   step_weights)
 from .dp import DataParallelTrainStep, shard_bounds  # noqa: F401
 from .search import greedy_search, beam_search  # noqa: F401
+from .loop import Trainer, evaluate  # noqa: F401
 from .checkpoint import save_checkpoint, load_checkpoint, read_checkpoint  # noqa: F401
