@@ -15,6 +15,7 @@
 
 #include "../../include/recnet_hip.h"
 #include "kernels.hpp"
+#include "rec_step.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
@@ -61,6 +62,8 @@ struct recnet_handle {
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void *mpd_lp, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_a, *Wih_b, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
+  void* Whh_g = nullptr;   // gate-interleaved W_hh of the fused recurrent step (rec_step.hpp); global reconstructor, LSTM, bf16
+  int fused_rec = 0;
   // inference search scratch (beam width <= 8)
   float *sr_logits, *sr_scores, *sr_h[2], *sr_c[2], *sr_hn, *sr_cn, *sr_cum[2], *sr_vals;
   int64_t *sr_tok[2], *sr_hist[2]; int32_t *sr_eos[2], *sr_idx;
@@ -162,6 +165,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->mpd_lp = takev(Tm * B * ldH); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
     h->dout_lp = takev(B * ldR); h->dGr = takev(Tm * B * ld4R);
     h->Wih_a = takev(4 * R * ldH); h->Wih_b = takev(4 * R * ldH); h->Whh_w = takev(4 * R * ldR);
+    h->Whh_g = takev(4 * R * ldR);
   } else if (h->kind == RECNET_REC_LOCAL) {
     h->Ud = take(Tm * B * RA);
     h->Hr = take(F * B * R); h->Cr = take(F * B * R); h->acts_r = take(F * B * 4 * R);
@@ -231,6 +235,15 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
+  {
+    // fused recurrent step of the global reconstructor (rec_step.hpp): bf16 path, LSTM, B <= 112, R % 8 == 0, K <= 2048.
+    // Opt-in (RN_FUSED_REC=1): at B=100, R=1536 it runs 15-18 us per step against 17.4 us for the GEMM + pointwise pair
+    // (tools/micro/rec_probe.hip) — every workgroup re-reads the whole activation block from L2, which costs more than
+    // the split-K slab round trip it removes; see DESIGN.md section 5.
+    const char* e = getenv("RN_FUSED_REC");
+    const int want = e ? atoi(e) : 0;
+    h->fused_rec = want && h->lp && h->kind == RECNET_REC_GLOBAL && !h->rgru && h->B <= 112 && (h->R & 7) == 0 && h->R <= 2048;
+  }
   h->need = carve(h, nullptr);
   *out = h;
   return RECNET_OK;
@@ -260,7 +273,7 @@ static void build_pack_tables(recnet_handle* h, int g) {
   for (auto& pd : o.pack) { pd.ndst = 0; pd.cols = 1; }
   auto addr = [&](int t, int cols, void* dst, int ld, int c0, int nc, int r0, int nr) {
     PackDesc& pd = o.pack[t]; pd.cols = cols;
-    PackDst& d = pd.d[pd.ndst++]; d.dst = dst; d.ld = ld; d.c0 = c0; d.nc = nc; d.r0 = r0; d.nr = nr;
+    PackDst& d = pd.d[pd.ndst++]; d.dst = dst; d.ld = ld; d.c0 = c0; d.nc = nc; d.r0 = r0; d.nr = nr; d.mode = 0; d.pad = 0;
   };
   auto add = [&](int t, int cols, void* dst, int ld, int c0, int nc) { addr(t, cols, dst, ld, c0, nc, 0, 1 << 30); };
   // recurrent weights into the 4-block gate layout: W_ih rows as they are (GRU: 3 blocks, the 4th stays zero);
@@ -281,6 +294,7 @@ static void build_pack_tables(recnet_handle* h, int g) {
   } else if (h->kind == RECNET_REC_GLOBAL) {
     add_ih(0, 2 * H, h->Wih_a, h->ldH, 0, H); add_ih(0, 2 * H, h->Wih_b, h->ldH, H, H);
     add_hh(h->rgru, R, 1, R, h->Whh_w, h->ldR, 0, R);
+    if (h->fused_rec) { addr(1, R, h->Whh_g, h->ldR, 0, R, 0, R); o.pack[1].d[o.pack[1].ndst - 1].mode = 1; }
     add(4, R, h->Wor_w, h->ldR, 0, R);
   } else if (h->kind == RECNET_REC_LOCAL) {
     add(1, R, h->Wr_w, h->ldR, 0, R);
@@ -559,6 +573,8 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
       pack_gates(h, h->Wih_a, h->ldH, R, h->rP.rnn_weight_ih_l0, 2 * H, H, gmap_ih(h->rgru), nullptr, 0, 0, none, st);
       pack_gates(h, h->Wih_b, h->ldH, R, h->rP.rnn_weight_ih_l0 + H, 2 * H, H, gmap_ih(h->rgru), nullptr, 0, 0, none, st);
       pack_gates(h, h->Whh_w, h->ldR, R, h->rP.rnn_weight_hh_l0, R, R, gmap_hh(h->rgru), nullptr, 0, 0, none, st);
+      if (h->fused_rec)
+        hipLaunchKernelGGL(pack_interleave_kernel<bf16_t>, dim3(ew_blocks((size_t)4 * R * h->ldR)), dim3(256), 0, st, (bf16_t*)h->Whh_g, h->ldR, R, h->rP.rnn_weight_hh_l0, R, R);
     } else {
       pack_block(h, h->Ur_w, h->ldH, h->rP.attn_U_weight, H, RA, H, 1.f, st);
       pack_block(h, h->Wr_w, h->ldR, h->rP.attn_W_weight, R, RA, R, 1.f, st);
@@ -809,6 +825,26 @@ static int fwd_rec_global(recnet_handle* h, const float* enc, int T, int train, 
   gemm(h, h->mpd_lp, 0, h->ldH, h->Wih_b, 0, h->ldH, h->Xg, 4 * R, nullptr, T * B, 4 * R, H, 1.f, 1, st);
   for (int t = 0; t < T; ++t) {
     int S = 0;
+    if (t > 0 && h->fused_rec) {
+      RecStepArgs a;
+      a.B = B; a.R = R; a.K = R;
+      a.A = (const bf16_t*)at_off(h, h->Hr_lp, (size_t)(t - 1) * B * h->ldR); a.lda = h->ldR;
+      a.W = (const bf16_t*)h->Whh_g; a.ldw = h->ldR;
+      a.X = h->Xg + (size_t)t * B * 4 * R; a.ldx = 4 * R;
+      a.c_prev = h->Cr + (size_t)(t - 1) * B * R;
+      a.h_out = h->Hr + (size_t)t * B * R; a.c_out = h->Cr + (size_t)t * B * R;
+      a.acts = h->acts_r + (size_t)t * B * 4 * R;
+      a.h_lp = (bf16_t*)at_off(h, h->Hr_lp, (size_t)t * B * h->ldR); a.ld_hlp = h->ldR;
+      hipEvent_t e1 = nullptr;
+      if (h->prof_on == RN_TAG_REC_FWD) {
+        if (h->prof_used + 2 > h->prof_ev.size()) { hipEvent_t x, y; hipEventCreate(&x); hipEventCreate(&y); h->prof_ev.push_back(x); h->prof_ev.push_back(y); }
+        hipEventRecord(h->prof_ev[h->prof_used++], st); e1 = h->prof_ev[h->prof_used++];
+      }
+      if (R <= 1536) hipLaunchKernelGGL((rec_step_fused_kernel<12, 3>), dim3(R / 8), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((rec_step_fused_kernel<16, 3>), dim3(R / 8), dim3(256), 0, st, a);
+      if (e1) hipEventRecord(e1, st);
+      continue;
+    }
     if (t > 0) S = gemm_slabs(h, RN_TAG_REC_FWD, at_off(h, h->Hr_lp, (size_t)(t - 1) * B * h->ldR), h->ldR, h->Whh_w, 0, h->ldR, B, 4 * R, R, st);
     lstm_pw(h, R, S, 4 * R, h->Xg + (size_t)t * B * 4 * R, 4 * R, nullptr, nullptr,
             t > 0 ? (h->rgru ? h->Hr : h->Cr) + (size_t)(t - 1) * B * R : nullptr, h->Hr + (size_t)t * B * R,

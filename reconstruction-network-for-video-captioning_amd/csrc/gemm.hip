@@ -1,5 +1,5 @@
 // Host-side dispatch of the MFMA GEMM template (gemm.hpp).
-#include "gemm_lds.hpp"
+#include "gemm_chain.hpp"
 #include "launch.hpp"
 #include <stdlib.h>
 
@@ -44,6 +44,28 @@ void launch_lds(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream_t 
   else if (!a_col && b_col) launch_lds_one<false, true, NS, 0>(a, grid, st);
   else if (a_col && !b_col) launch_lds_one<true, false, NS, 0>(a, grid, st);
   else launch_lds_one<true, true, NS, 0>(a, grid, st);
+}
+template <int NG, int NKT, int TAG>
+void launch_chain_one(const GemmArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  auto fn = gemm_chain_kernel<NG, NKT, TAG>;
+  // LDS: NKT activation tiles; the epilogue reuses it for 4 x 32 x (16 NG + 4) floats of staging
+  const size_t lds = (size_t)(NKT < 2 ? 2 : NKT) * 16384;
+  if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  hipLaunchKernelGGL(fn, dim3((a.N + 64 * NG - 1) / (64 * NG), 1, a.splitk), dim3(256), lds, st, a);
+}
+template <int NG, int TAG>
+void launch_chain_nkt(const GemmArgs& a, int nkt, hipStream_t st) {
+  launch_chain_one<NG, 2, TAG>(a, st);
+}
+template <int NG>
+bool launch_chain(const GemmArgs& a, int nkt, hipStream_t st, int tag) {
+  switch (tag) {
+    case RN_TAG_DEC_FWD: launch_chain_nkt<NG, RN_TAG_DEC_FWD>(a, nkt, st); return true;
+    case RN_TAG_REC_FWD: launch_chain_nkt<NG, RN_TAG_REC_FWD>(a, nkt, st); return true;
+    case RN_TAG_REC_ATT: launch_chain_nkt<NG, RN_TAG_REC_ATT>(a, nkt, st); return true;
+    default: return false;
+  }
 }
 inline int vec_ok(const void* p, int ld, int elem) {
   return (((uintptr_t)p) % 16 == 0) && (((size_t)ld * elem) % 16 == 0);
@@ -94,6 +116,15 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
     if (!a_bf16 && !b_bf16) launch_layout<bf16_t, float, float>(a, a_col, b_col, grid, st, tag);
     else if (!a_bf16 && b_bf16) launch_layout<bf16_t, float, bf16_t>(a, a_col, b_col, grid, st, tag);
     else if (a.a_vec && a.b_vec) {
+      // forward-form chain launches (activations x weights^T, M <= 128, K slice <= 6 k-tiles): single round trip kernel
+      static int chain_on = getenv("RN_GEMM_CHAIN") ? atoi(getenv("RN_GEMM_CHAIN")) : 1;
+      static int chain_ng = getenv("RN_GEMM_CHAIN_NG") ? atoi(getenv("RN_GEMM_CHAIN_NG")) : 0;
+      if (chain_on && tag && !a_col && !b_col && M <= 128 && per <= GC_MAX_KT && !c_bf16 && !c2) {
+        // 128-column workgroups unless that leaves half the chip idle (e.g. the decoder's N = 4H + A = 2176)
+        const int ng = chain_ng ? chain_ng : ((((N + 127) / 128) * splitk >= 128) ? 2 : 1);
+        const bool done = ng == 1 ? launch_chain<1>(a, per, st, tag) : launch_chain<2>(a, per, st, tag);
+        if (done) goto after_launch;
+      }
       // both operands bf16 in memory: the DMA-staged ring kernel.  Chain launches (tag > 0) run ~1 block
       // per CU and want the deepest ring; batched GEMMs trade ring depth for 2 resident blocks per CU.
       static int ns_chain = getenv("RN_GEMM_NS_CHAIN") ? atoi(getenv("RN_GEMM_NS_CHAIN")) : 4;
@@ -106,6 +137,7 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
   } else {
     launch_layout<float, float, float>(a, a_col, b_col, grid, st, tag);
   }
+after_launch:
   if (splitk > 1 && reduce_after) {
     size_t total = (size_t)M * N;
     int blocks = (int)((total + 255) / 256);

@@ -24,6 +24,22 @@ __device__ __forceinline__ int gl_col_swz(int k) { return ((k & 3) << 1) | (k & 
 
 template <int N> __device__ __forceinline__ void gl_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Source address of this lane's 16 bytes of image piece `piece` (the image is lane-linear: piece * 1024 + lane * 16).
+template <bool COL>
+__device__ __forceinline__ const bf16_t* gl_piece_src(const bf16_t* base, int ld, int row0, int rext, int k0, int K, int piece, int lane) {
+  if (!COL) {
+    const int r = piece * 8 + (lane >> 3), cp = lane & 7;
+    int gr = row0 + r; gr = gr < rext ? gr : rext - 1;
+    int gk = k0 + ((cp ^ (r & 7)) << 3); gk = gk < K ? gk : 0;         // beyond K: any valid address, zero-fixed later
+    return base + (size_t)gr * ld + gk;
+  } else {
+    const int kk = piece * 4 + (lane >> 4), cp = lane & 15;
+    int gk = k0 + kk; gk = gk < K ? gk : K - 1;
+    const int r8 = (rext + 7) & ~7;
+    int gm = row0 + ((cp ^ gl_col_swz(kk)) << 3); gm = gm + 8 <= r8 ? gm : r8 - 8;
+    return base + (size_t)gk * ld + gm;
+  }
+}
 // One operand tile: 4 DMA instructions per wave, each 64 lanes x 16 B = 1 KiB of the image.
 template <bool COL>
 __device__ __forceinline__ void gl_stage(char* img, const bf16_t* base, int ld, int row0, int rext, int k0, int K,

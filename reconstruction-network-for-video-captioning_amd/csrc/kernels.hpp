@@ -194,6 +194,16 @@ __global__ void pack_gates_kernel(DT* __restrict__ dst, int ld_dst, int Hd, cons
     dst[i] = (DT)v;
   }
 }
+// gate-interleaved image of a [4 Hd][cols] recurrent weight (rec_step.hpp): destination row (u/8)*32 + gate*8 + u%8
+template <typename DT>
+__global__ void pack_interleave_kernel(DT* __restrict__ dst, int ld_dst, int Hd, const float* __restrict__ src, int ld_src, int cols) {
+  const size_t total = (size_t)4 * Hd * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    const int j = d >> 5, gate = (d >> 3) & 3, ul = d & 7;
+    dst[i] = (DT)(c < cols ? src[(size_t)(gate * Hd + j * 8 + ul) * ld_src + c] : 0.f);
+  }
+}
 // dst[r][c] = sum_j src[r*ld_src + j*cols + c]  (sum of NCH side-by-side partial blocks), zero padded to ld_dst
 template <typename AT>
 __global__ void sum_chunks_kernel(AT* __restrict__ dst, int ld_dst, const AT* __restrict__ src, int ld_src, int rows,
@@ -1288,7 +1298,8 @@ struct TensorDesc { float* p; float* g; float* m; float* v; float* vmax; int n; 
 // writes them directly, so the weights are re-packed (bf16) in the same pass that updates them.
 // Rows: only source rows [r0, r0 + nr) are written, to destination row (r - r0) (dst is pre-offset) — the GRU's
 // 3-block weights land in the 4-block packed layout this way.
-struct PackDst { void* dst; int ld; int c0; int nc; int r0; int nr; };
+// mode 1 (gate interleave, rec_step.hpp): r = gate * nr + u goes to destination row (u / 8) * 32 + gate * 8 + u % 8.
+struct PackDst { void* dst; int ld; int c0; int nc; int r0; int nr; int mode; int pad; };
 struct PackDesc { int ndst; int cols; PackDst d[6]; };
 #define RN_CHUNK 8192
 
@@ -1417,8 +1428,11 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
       const int r = i / pk.cols, c = i - r * pk.cols;
 #pragma unroll
       for (int d = 0; d < 6; ++d)
-        if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc && r >= pk.d[d].r0 && r < pk.d[d].r0 + pk.d[d].nr) {
-          const size_t o = (size_t)(r - pk.d[d].r0) * pk.d[d].ld + (c - pk.d[d].c0);
+        if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc &&
+            (pk.d[d].mode || (r >= pk.d[d].r0 && r < pk.d[d].r0 + pk.d[d].nr))) {
+          int dr = r - pk.d[d].r0;
+          if (pk.d[d].mode) { const int gate = r / pk.d[d].nr, u = r - gate * pk.d[d].nr; dr = (u >> 3) * 32 + gate * 8 + (u & 7); }
+          const size_t o = (size_t)dr * pk.d[d].ld + (c - pk.d[d].c0);
           if (lp) reinterpret_cast<bf16_t*>(pk.d[d].dst)[o] = (bf16_t)pn; else reinterpret_cast<float*>(pk.d[d].dst)[o] = pn;
         }
     }

@@ -114,6 +114,23 @@ def test_gemm_lds_exact_integers(tag_ns, a_col, b_col, M, N, K, monkeypatch):
         assert torch.equal(C.double(), ref), (a_col, b_col, splitk, (C.double() - ref).abs().max().item())
 
 
+@pytest.mark.parametrize("tag", [1, 3, 5])
+@pytest.mark.parametrize("M,N,K,splitk", [(100, 6144, 1536, 4), (100, 2176, 512, 4), (100, 128, 1536, 16), (37, 97, 41, 1),
+                                          (5, 288, 112, 1), (128, 130, 200, 1), (1, 64, 64, 1), (100, 200, 384, 2),
+                                          (128, 16384, 384, 1), (77, 2048, 768, 2), (13, 40, 8, 1)])
+def test_gemm_chain_exact_integers(tag, M, N, K, splitk):
+    """csrc/gemm_chain.hpp (forward-form recurrent-step GEMM: weights straight into MFMA registers, one round trip):
+    every K slice here is <= 6 k-tiles, so these shapes run that kernel — 64- and 128-column workgroups, partial tiles."""
+    g = torch.Generator().manual_seed(M + N + K)
+    eng = _engine("bf16")
+    Ab, Av = _bf16_operand(M, K, True, g)
+    Bb, Bv = _bf16_operand(N, K, True, g)
+    ref = _ref(Av.float(), Bv.float(), 0, 0)
+    C = eng.gemm_bf16(Ab, Bb, False, False, splitk=splitk, M=M, N=N, K=K, tag=tag)
+    torch.cuda.synchronize()
+    assert torch.equal(C.double(), ref), (C.double() - ref).abs().max().item()
+
+
 def test_gemm_lds_random_and_epilogue():
     torch.manual_seed(11)
     eng = _engine("bf16")

@@ -209,3 +209,11 @@ def test_free_running_validation_pass(name, prec):
         assert abs(float(rl.detach()) - float(g["rec_loss"])) <= tol["loss"] * abs(float(g["rec_loss"]))
     with pytest.raises(Exception):   # forward-only: no graph to differentiate
         dl.backward()
+
+
+@pytest.mark.parametrize("name", ["global_train", "global_eval", "full_global_B8"])
+def test_fused_reconstructor_step_opt_in(name, monkeypatch):
+    """RN_FUSED_REC=1 routes the global reconstructor's forward chain through csrc/rec_step.hpp (one kernel per step:
+    h . W_hh^T over the full K per workgroup + LSTM pointwise in the epilogue); same bars as the default path."""
+    monkeypatch.setenv("RN_FUSED_REC", "1")
+    test_autograd_api_losses_and_grads(name, "bf16")
