@@ -251,6 +251,14 @@ int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* s
 #define RECNET_SITE_REC_ATT 5   /* local reconstructor: hr . attn_W^T                           */
 int recnet_profile_begin(recnet_handle* h, int32_t site);
 int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms);
+/* Same read-out without leaving profiling mode: when the bracketed launches were captured into a hipGraph (the event
+ * records become graph nodes), call this after each replay — the durations are then those of the replayed graph. */
+int recnet_profile_read(recnet_handle* h, int32_t* n_launches, double* total_ms);
+/* Calibration of the bracket itself: `count` launches of an empty kernel bracketed by the same two event records (call
+ * between recnet_profile_begin and _read/_end, in the same eager / captured mode as the measurement).  bracket(count) =
+ * E + count * f: E is what the two event records add to every bracketed duration, f the dispatch-to-completion time of
+ * an empty kernel; a bracketed kernel's own dispatch-to-completion time is its bracket minus E. */
+int recnet_profile_null_launch(recnet_handle* h, int32_t count, void* stream);
 /* C[M,N] (+)= alpha * op(A) op(B)^T + bias.  a_col / b_col: operand stored with the contraction index
  * as the ROW index (see csrc/gemm.hpp).  All fp32 device pointers. */
 int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, const float* B, int32_t b_col,

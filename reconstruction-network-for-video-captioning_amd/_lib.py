@@ -122,6 +122,8 @@ EXPORTS["recnet_train_step_fwd_bwd_dev"] = (_i, [C.c_void_p, C.c_void_p, C.c_voi
 EXPORTS["recnet_optimizer_step_dev"] = (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p])
 EXPORTS["recnet_profile_begin"] = (_i, [C.c_void_p, _i])
 EXPORTS["recnet_profile_end"] = (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_d)])
+EXPORTS["recnet_profile_read"] = (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_d)])
+EXPORTS["recnet_profile_null_launch"] = (_i, [C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_gemm_bf16"] = (_i, [C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _f, _i, _i,
                                   C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_train_step_part_dev"] = (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_uint32,

@@ -1420,6 +1420,35 @@ int recnet_profile_begin(recnet_handle* h, int32_t site) {
   return RECNET_OK;
 }
 
+int recnet_profile_null_launch(recnet_handle* h, int32_t count, void* stream) {
+  if (!h || !h->ws) return fail(RECNET_ESTATE, "workspace not bound");
+  if (!h->prof_on) return fail(RECNET_ESTATE, "not profiling");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->prof_used + 2 > h->prof_ev.size()) {
+    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    h->prof_ev.push_back(a); h->prof_ev.push_back(b);
+  }
+  hipEvent_t e0 = h->prof_ev[h->prof_used++], e1 = h->prof_ev[h->prof_used++];
+  HIPCHK(hipEventRecord(e0, st));
+  for (int i = 0; i < count; ++i) hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl + 8, 0u);
+  HIPCHK(hipEventRecord(e1, st));
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_profile_read(recnet_handle* h, int32_t* n_launches, double* total_ms) {
+  if (!h || !n_launches || !total_ms) return fail(RECNET_EINVAL, "null argument");
+  double tot = 0; int n = 0;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    HIPCHK(hipEventSynchronize(h->prof_ev[i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+    tot += ms; ++n;
+  }
+  *n_launches = n; *total_ms = tot;
+  return RECNET_OK;
+}
+
 int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms) {
   if (!h || !n_launches || !total_ms) return fail(RECNET_EINVAL, "null argument");
   h->prof_on = 0;
