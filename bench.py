@@ -186,8 +186,7 @@ def main():
                     for _ in range(16):
                         eng.profile_null_launch(-site)
                     return
-                eng.train_step_fwd_bwd_dev(enc, targets, T, w, step.step_impl.seed_base)
-                eng.optimizer_step_dev(3)
+                eng.train_step_dev(enc, targets, T, w, step.step_impl.seed_base, 3)
             s_id = site if site > 0 else 5
             if args.graph and not step.reduce:
                 return eng.profile_site_graph(s_id, one)

@@ -226,6 +226,13 @@ int recnet_train_step(recnet_handle* h, const float* enc, const int64_t* targets
                       const float* step_weight, uint32_t seed, int32_t step, recnet_scalars* scalars,
                       void* stream);
 
+/* The fused step for graph replay (single rank): recnet_train_step with the step count and the dropout seed taken from
+ * device memory (advanced by the call itself, seed = seed_base + step) — forward, backward, then the optimiser with
+ * `flags`.  The reconstructor's optimiser step is issued as soon as its gradients are complete, under the decoder's
+ * backward chain; the decoder's follows the clip (train.py:265-273 as one capturable sequence). */
+int recnet_train_step_dev(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T, const float* step_weight,
+                          uint32_t seed_base, int32_t flags, recnet_scalars* scalars, void* stream);
+
 /* hipGraph-replay-friendly forms: the optimiser step count and the dropout seed live in device memory.
  * recnet_set_step initialises the counter; *_fwd_bwd_dev first does step += 1, seed = seed_base + step
  * on the device, so replaying a captured graph advances both; *_optimizer_step_dev reads the counter. */

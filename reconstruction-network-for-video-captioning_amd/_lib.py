@@ -119,6 +119,7 @@ EXPORTS["recnet_clip_grad_norm"] = (_i, [C.c_void_p, _i, _f, C.c_void_p, C.c_voi
 EXPORTS["recnet_set_step"] = (_i, [C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_train_step_fwd_bwd_dev"] = (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_uint32,
                                                  C.c_void_p, C.c_void_p])
+EXPORTS["recnet_train_step_dev"] = (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_uint32, _i, C.c_void_p, C.c_void_p])
 EXPORTS["recnet_optimizer_step_dev"] = (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p])
 EXPORTS["recnet_profile_begin"] = (_i, [C.c_void_p, _i])
 EXPORTS["recnet_profile_end"] = (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_d)])

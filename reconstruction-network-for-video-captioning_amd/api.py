@@ -475,8 +475,7 @@ class GraphedStep:
         if not self.split:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, **mode):
-                eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
-                eng.optimizer_step_dev(self.flags)
+                eng.train_step_dev(self.enc, self.targets, self.T, self.w, self.seed_base, self.flags)
             self.graphs = [g]
         else:
             for part in (1, 2):
@@ -495,7 +494,9 @@ class GraphedStep:
 
     def _eager(self):
         if not self.split:
-            self.eng.train_step_fwd_bwd_dev(self.enc, self.targets, self.T, self.w, self.seed_base)
+            self.eng.train_step_dev(self.enc, self.targets, self.T, self.w, self.seed_base, self.flags)
+            self._bump()
+            return
         else:
             self.eng.train_step_part_dev(1, self.enc, self.targets, self.T, self.w, self.seed_base)
             works = [self._reduce_async(self.rs.flat()["grad"].flat)] if self.rs else []

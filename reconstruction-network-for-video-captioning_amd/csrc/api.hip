@@ -69,14 +69,14 @@ struct recnet_handle {
   int64_t *sr_tok[2], *sr_hist[2]; int32_t *sr_eos[2], *sr_idx;
   size_t gws_floats, slab_floats;
   float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
-  hipStream_t s2 = nullptr; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int overlap = 1;
+  hipStream_t s2 = nullptr; hipEvent_t ev[16] = {}; int overlap = 1;
   // bindings
   recnet_decoder_tensors dP{}, dGd{}, dM{}, dV{}, dVm{};
   recnet_reconstructor_tensors rP{}, rG{}, rM{}, rV{}, rVm{};
   bool dec_bound = false, rec_bound = false;
   OptGroup og[2];
   // state between forward and backward
-  int T_last = 0, train_last = 0, fwd_dec_done = 0, fwd_rec_done = 0, rec_bwd_done = 0;
+  int T_last = 0, train_last = 0, fwd_dec_done = 0, fwd_rec_done = 0, rec_bwd_done = 0, early_opt_done = 0, norms_hoisted = 0;
   // optional per-launch timing of the recurrent-step GEMM (recnet_profile_*)
   int prof_on = 0; std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
 };
@@ -252,7 +252,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
 void recnet_destroy(recnet_handle* h) {
   if (!h) return;
   for (auto e : h->prof_ev) hipEventDestroy(e);
-  for (int i = 0; i < 6; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  for (int i = 0; i < 16; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
   if (h->s2) hipStreamDestroy(h->s2);
   delete h;
 }
@@ -327,7 +327,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
     const char* ov = getenv("RN_OVERLAP");
     h->overlap = ov ? atoi(ov) : 1;
     HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
-    for (int i = 0; i < 6; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
   }
   h->fwd_dec_done = h->fwd_rec_done = h->rec_bwd_done = 0;
   int r = upload_tables(h, 0); if (r) return r;
@@ -500,10 +500,10 @@ static void gate_bias_grad(recnet_handle* h, const void* dG, int rows, int Hd, i
 // dW_hh = dG^T . Hprev over `rows` rows.  LSTM: the 4 gate blocks as they are.  GRU: master blocks (r, z) come from
 // packed blocks (0, 1) and master block n from packed block 3 (the hidden-side n pre-activation, see gru_point).
 static void dW_hh(recnet_handle* h, int gru, int Hd, const void* dG, int ld_dg, const void* Hprev, int ld_h, float* dW, int rows,
-                  hipStream_t st) {
-  if (!gru) { gemm(h, dG, 1, ld_dg, Hprev, 1, ld_h, dW, Hd, nullptr, 4 * Hd, Hd, rows, 1.f, 0, st); return; }
-  gemm(h, dG, 1, ld_dg, Hprev, 1, ld_h, dW, Hd, nullptr, 2 * Hd, Hd, rows, 1.f, 0, st);
-  gemm(h, at_off(h, (void*)dG, (size_t)3 * Hd), 1, ld_dg, Hprev, 1, ld_h, dW + (size_t)2 * Hd * Hd, Hd, nullptr, Hd, Hd, rows, 1.f, 0, st);
+                  int acc, hipStream_t st) {
+  if (!gru) { gemm(h, dG, 1, ld_dg, Hprev, 1, ld_h, dW, Hd, nullptr, 4 * Hd, Hd, rows, 1.f, acc, st); return; }
+  gemm(h, dG, 1, ld_dg, Hprev, 1, ld_h, dW, Hd, nullptr, 2 * Hd, Hd, rows, 1.f, acc, st);
+  gemm(h, at_off(h, (void*)dG, (size_t)3 * Hd), 1, ld_dg, Hprev, 1, ld_h, dW + (size_t)2 * Hd * Hd, Hd, nullptr, Hd, Hd, rows, 1.f, acc, st);
 }
 static void fork_to(recnet_handle* h, int e, hipStream_t main, hipStream_t side) {
   hipEventRecord(h->ev[e], main); hipStreamWaitEvent(side, h->ev[e], 0);
@@ -626,7 +626,7 @@ static void embed_fwd(recnet_handle* h, const int64_t* targets, const int64_t* t
 static int dec_fwd_chain(recnet_handle* h, const float* enc, const int64_t* targets, int T, int train, hipStream_t st,
                          int64_t* free_tokens = nullptr) {
   const int B = h->B, F = h->F, E = h->E, H = h->H, A = h->A, V = h->V;
-  param_norms(h, 0, h->scal + 1, st);
+  if (!h->norms_hoisted) param_norms(h, 0, h->scal + 1, st);
   dec_invariants(h, enc, st);
   if (!free_tokens) {
     // all T teacher-forced input embeddings at once    (decoder.py:46-48, train.py:25,45)
@@ -743,47 +743,70 @@ static int dec_bwd_chain(recnet_handle* h, const float* dhid, hipStream_t st) {
   }
   return RECNET_OK;
 }
-static int dec_bwd_deferred(recnet_handle* h, const float* enc, const int64_t* targets, hipStream_t st) {
-  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V, T = h->T_last;
-  const int train = h->train_last, TB = T * B, ldWS = h->ldWS;
-  // deferred weight gradients (batched over all T steps); dgates live in columns [0,4H) of dGx, dWh chunks behind them
-  gemm(h, h->dGx, 0, ldWS, h->We_w, 1, h->ldE, h->demb, E, nullptr, TB, E, 4 * H, 1.f, 0, st);
-  hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(TB), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
-                     h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train));
+// Deferred weight gradients of the decoder for the time steps [t0, t1) (rows [t0 B, t1 B) of dGx): every product whose
+// contraction runs over (t, b).  acc = 0 for the first range processed (it also zeroes dEmb), 1 afterwards.  Ranges can be
+// issued as soon as the BPTT chain has produced their rows, on another stream, while the chain goes on.
+static int dec_bwd_deferred_rows(recnet_handle* h, const float* enc, const int64_t* targets, int t0, int t1, int acc, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, E = h->E, H = h->H, A = h->A, V = h->V;
+  const int train = h->train_last, ldWS = h->ldWS, nrow = (t1 - t0) * B;
+  const size_t r0 = (size_t)t0 * B;
   const int GH = (h->dgru ? 3 : 4) * H;   // rows of the master W_ih / W_hh: gate blocks (r, z, n) or (i, f, g, o)
-  gemm(h, h->dGx, 1, ldWS, h->emb_lp, 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, GH, E, TB, 1.f, 0, st);
-  // ctx_t = (1/F) sum_f a_t[f] enc[b,f] for every step (only needed here), then dW_ih[:, E:] = dgates^T . ctx
+  void* dG = at_off(h, h->dGx, r0 * ldWS);
+  // dgates live in columns [0,4H) of dGx, dWh chunks behind them
+  {
+    gemm(h, dG, 0, ldWS, h->We_w, 1, h->ldE, h->demb + r0 * E, E, nullptr, nrow, E, 4 * H, 1.f, 0, st);
+    if (!acc) hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(nrow), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
+                       h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0);
+    gemm(h, dG, 1, ldWS, at_off(h, h->emb_lp, r0 * h->ldE), 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, GH, E, nrow, 1.f, acc, st);
+  }
+  // ctx_t = (1/F) sum_f a_t[f] enc[b,f] for these steps (only needed here), then dW_ih[:, E:] (+)= dgates^T . ctx
   {
     dim3 grid(B, cdiv(h->ldD, 256));
+    const float* att = h->att + r0 * F;
+    void* ctx = at_off(h, h->ctx_lp, r0 * h->ldD);
+    const int Tn = t1 - t0;
     if (h->Tm <= 32) {
-      if (h->lp) hipLaunchKernelGGL(ctx_all_kernel<bf16_t>, grid, dim3(256), (size_t)32 * F * 4, st, h->att, enc, (bf16_t*)h->ctx_lp, h->ldD, T, B, F, D);
-      else hipLaunchKernelGGL(ctx_all_kernel<float>, grid, dim3(256), (size_t)32 * F * 4, st, h->att, enc, (float*)h->ctx_lp, h->ldD, T, B, F, D);
+      if (h->lp) hipLaunchKernelGGL(ctx_all_kernel<bf16_t>, grid, dim3(256), (size_t)32 * F * 4, st, att, enc, (bf16_t*)ctx, h->ldD, Tn, B, F, D);
+      else hipLaunchKernelGGL(ctx_all_kernel<float>, grid, dim3(256), (size_t)32 * F * 4, st, att, enc, (float*)ctx, h->ldD, Tn, B, F, D);
     } else {
-      if (h->lp) hipLaunchKernelGGL(ctx_all_slow_kernel<bf16_t>, grid, dim3(256), 0, st, h->att, enc, (bf16_t*)h->ctx_lp, h->ldD, T, B, F, D);
-      else hipLaunchKernelGGL(ctx_all_slow_kernel<float>, grid, dim3(256), 0, st, h->att, enc, (float*)h->ctx_lp, h->ldD, T, B, F, D);
+      if (h->lp) hipLaunchKernelGGL(ctx_all_slow_kernel<bf16_t>, grid, dim3(256), 0, st, att, enc, (bf16_t*)ctx, h->ldD, Tn, B, F, D);
+      else hipLaunchKernelGGL(ctx_all_slow_kernel<float>, grid, dim3(256), 0, st, att, enc, (float*)ctx, h->ldD, Tn, B, F, D);
     }
+    gemm(h, dG, 1, ldWS, ctx, 1, h->ldD, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, GH, D, nrow, 1.f, acc, st);
   }
-  gemm(h, h->dGx, 1, ldWS, h->ctx_lp, 1, h->ldD, h->dGd.rnn_weight_ih_l0 + E, E + D, nullptr, GH, D, TB, 1.f, 0, st);
   // dWh_t = sum of its RN_FCH frame-chunk partials (operand of dW_attn and source of d attn_b)
   {
-    const size_t n = (size_t)TB * h->ldA;
-    if (h->lp) hipLaunchKernelGGL(sum_chunks_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)h->dWhs, h->ldA, (const bf16_t*)h->dGx + 4 * H, ldWS, TB, A, RN_FCH);
-    else hipLaunchKernelGGL(sum_chunks_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)h->dWhs, h->ldA, (const float*)h->dGx + 4 * H, ldWS, TB, A, RN_FCH);
+    const size_t n = (size_t)nrow * h->ldA;
+    void* dst = at_off(h, h->dWhs, r0 * h->ldA);
+    if (h->lp) hipLaunchKernelGGL(sum_chunks_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (bf16_t*)dst, h->ldA, (const bf16_t*)dG + 4 * H, ldWS, nrow, A, RN_FCH);
+    else hipLaunchKernelGGL(sum_chunks_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (float*)dst, h->ldA, (const float*)dG + 4 * H, ldWS, nrow, A, RN_FCH);
   }
-  // dW_hh = sum_{t>=1} dgates_t^T h_{t-1} ; dW_attn = sum_{t>=1} dWh_t^T h_{t-1}   (h_{-1} = 0)
-  if (T > 1) {
-    dW_hh(h, h->dgru, H, at_off(h, h->dGx, (size_t)B * ldWS), ldWS, h->Hs_lp, h->ldH, h->dGd.rnn_weight_hh_l0, (T - 1) * B, st);
-    gemm(h, at_off(h, h->dWhs, (size_t)B * h->ldA), 1, h->ldA, h->Hs_lp, 1, h->ldH, h->dGd.attn_W_weight, H, nullptr, A, H, (T - 1) * B, 1.f, 0, st);
-  } else {
+  // dW_hh (+)= sum_{t>=1} dgates_t^T h_{t-1} ; dW_attn (+)= sum_{t>=1} dWh_t^T h_{t-1}   (h_{-1} = 0)
+  const int ta = t0 > 1 ? t0 : 1;
+  if (t1 > ta) {
+    const int nr = (t1 - ta) * B;
+    const void* hp = at_off(h, h->Hs_lp, (size_t)(ta - 1) * B * h->ldH);
+    dW_hh(h, h->dgru, H, at_off(h, h->dGx, (size_t)ta * B * ldWS), ldWS, hp, h->ldH, h->dGd.rnn_weight_hh_l0, nr, acc, st);
+    gemm(h, at_off(h, h->dWhs, (size_t)ta * B * h->ldA), 1, h->ldA, hp, 1, h->ldH, h->dGd.attn_W_weight, H, nullptr, A, H, nr, 1.f, acc, st);
+  } else if (!acc) {
     hipMemsetAsync(h->dGd.rnn_weight_hh_l0, 0, (size_t)GH * H * 4, st);
     hipMemsetAsync(h->dGd.attn_W_weight, 0, (size_t)A * H * 4, st);
   }
+  return RECNET_OK;
+}
+// what needs the whole chain: bias gradients (column sums over all rows), d attn_U (dUv is complete after step 0), d attn_w
+static int dec_bwd_deferred_tail(recnet_handle* h, hipStream_t st) {
+  const int B = h->B, F = h->F, D = h->D, H = h->H, A = h->A, T = h->T_last, TB = T * B, ldWS = h->ldWS;
   gate_bias_grad(h, h->dGx, TB, H, ldWS, h->dGd.rnn_bias_ih_l0, h->dGd.rnn_bias_hh_l0, h->dgru, st);
   gemm(h, h->dUv_lp, 1, h->ldA, h->enc_lp, 1, h->ldD, h->dGd.attn_U_weight, D, nullptr, A, D, B * F, 1.f, 0, st);
-  colsum_at(h, h->dWhs, TB, A, h->ldA, h->dGd.attn_b, st);
   colsum_t<float>(h->dwacc, RN_FCH * B, A, A, h->dGd.attn_w_weight, st);
+  colsum_at(h, h->dWhs, TB, A, h->ldA, h->dGd.attn_b, st);
   return RECNET_OK;
+}
+static int dec_bwd_deferred(recnet_handle* h, const float* enc, const int64_t* targets, hipStream_t st) {
+  int r = dec_bwd_deferred_rows(h, enc, targets, 0, h->T_last, 0, st); if (r) return r;
+  return dec_bwd_deferred_tail(h, st);
 }
 static int bwd_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhid, float gscale,
                        hipStream_t st) {
@@ -810,8 +833,10 @@ static void mean_over_t(recnet_handle* h, const float* X, int T, int Cn, float s
 
 static int fwd_rec_global(recnet_handle* h, const float* enc, int T, int train, hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R;
-  param_norms(h, 1, h->scal + 4, st);
-  gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, R, h->rgru, st);
+  if (!h->norms_hoisted) {
+    param_norms(h, 1, h->scal + 4, st);
+    gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, R, h->rgru, st);
+  }
   // mean-pooled decoder states, rescaled by caption_max_len / T (global_reconstructor.py:33-37): (cml / T^2) sum_t h_t
   mean_over_t(h, h->Hs, T, H, (float)h->cml / ((float)T * (float)T), h->mp, nullptr, 0, st);
   {
@@ -904,7 +929,7 @@ static int bwd_rec_global_deferred(recnet_handle* h, hipStream_t st) {
   gemm(h, h->dGr, 1, ld4R, h->Hs_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, GR, H, TB, 1.f, 0, st);
   gemm(h, h->dGr, 1, ld4R, h->mpd_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, GR, H, TB, 1.f, 0, st);
   if (T > 1)
-    dW_hh(h, h->rgru, R, at_off(h, h->dGr, (size_t)B * ld4R), ld4R, h->Hr_lp, h->ldR, h->rG.rnn_weight_hh_l0, (T - 1) * B, st);
+    dW_hh(h, h->rgru, R, at_off(h, h->dGr, (size_t)B * ld4R), ld4R, h->Hr_lp, h->ldR, h->rG.rnn_weight_hh_l0, (T - 1) * B, 0, st);
   else
     hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)GR * R * 4, st);
   gate_bias_grad(h, h->dGr, TB, R, ld4R, h->rG.rnn_bias_ih_l0, h->rG.rnn_bias_hh_l0, h->rgru, st);
@@ -915,8 +940,10 @@ static int bwd_rec_global_deferred(recnet_handle* h, hipStream_t st) {
 static int fwd_rec_local(recnet_handle* h, const float* enc, int T, int train, hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, H = h->H, R = h->R, RA = h->RA, ldHR = h->ldHR;
   const size_t esz = h->lp ? 2 : 4;
-  param_norms(h, 1, h->scal + 4, st);
-  gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, R, h->rgru, st);
+  if (!h->norms_hoisted) {
+    param_norms(h, 1, h->scal + 4, st);
+    gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, R, h->rgru, st);
+  }
   // Ud = hiddens . U_r^T   (local_reconstructor.py:42, hoisted)
   gemm(h, h->Hs_lp, 0, h->ldH, h->Ur_w, 0, h->ldH, h->Ud, RA, nullptr, T * B, RA, H, 1.f, 0, st);
   hipMemsetAsync(h->Xcat_r, 0, (size_t)F * B * ldHR * esz, st);   // hr_{-1} = 0 and the zero padding of every row
@@ -990,7 +1017,7 @@ static int bwd_rec_local_deferred(recnet_handle* h, hipStream_t st) {
   }
   if (F > 1) {
     gemm(h, at_off(h, h->dWhrs, (size_t)B * h->ldRA), 1, h->ldRA, h->Hr_lp, 1, h->ldR, h->rG.attn_W_weight, R, nullptr, RA, R, (F - 1) * B, 1.f, 0, st);
-    dW_hh(h, h->rgru, R, at_off(h, h->dGr, (size_t)B * ld4R), ld4R, h->Hr_lp, h->ldR, h->rG.rnn_weight_hh_l0, (F - 1) * B, st);
+    dW_hh(h, h->rgru, R, at_off(h, h->dGr, (size_t)B * ld4R), ld4R, h->Hr_lp, h->ldR, h->rG.rnn_weight_hh_l0, (F - 1) * B, 0, st);
   } else {
     hipMemsetAsync(h->rG.attn_W_weight, 0, (size_t)RA * R * 4, st);
     hipMemsetAsync(h->rG.rnn_weight_hh_l0, 0, (size_t)GR * R * 4, st);
@@ -1023,12 +1050,13 @@ static int bwd_rec(recnet_handle* h, float gscale, float* dhid_out, hipStream_t 
   return bwd_rec_deferred(h, st);
 }
 
-static int optimizer_step(recnet_handle* h, int flags, hipStream_t st) {
+static int optimizer_step(recnet_handle* h, int flags, hipStream_t st, int only_group = -1) {
   // decoder: total grad norm (incl. the regulariser gradient), clip coefficient, AMSGrad step
   const int include_reg = flags & RECNET_OPT_REG;
   for (int g = 0; g < 2; ++g) {
     OptGroup& o = h->og[g];
     if (!o.bound) continue;
+    if (only_group >= 0 && g != only_group) continue;
     if (g == 0 && (flags & RECNET_OPT_SKIP_DECODER)) continue;
     if (g == 1 && ((flags & RECNET_OPT_SKIP_RECONSTRUCTOR) || h->kind == RECNET_REC_NONE)) continue;
     if (!o.tab[0].m || !o.tab[0].g) return fail(RECNET_ESTATE, "gradients / Adam state not bound");
@@ -1307,38 +1335,68 @@ int recnet_optimizer_step(recnet_handle* h, int32_t step, int32_t flags, recnet_
 // GEMMs fill CUs that would otherwise idle.
 // phase 0: everything.  phase 1: up to and including every reconstructor gradient (so a data-parallel caller can
 // start all-reducing the reconstructor bucket).  phase 2: the decoder BPTT + its deferred gradients.
+// early_opt >= 0 (single-rank fused step): the reconstructor's optimiser step (flags = early_opt) is issued on the side
+// stream as soon as its gradients are complete, i.e. it runs under the decoder BPTT; the caller then steps the decoder only.
 static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st,
-                   int phase = 0) {
+                   int phase = 0, int early_opt = -1) {
   const bool rec = h->kind != RECNET_REC_NONE;
-  hipStream_t sd = (h->overlap && rec) ? h->s2 : st;
+  hipStream_t sd = h->overlap ? h->s2 : st;
   const bool par = sd != st;
   int r;
   const float* dh = rec ? h->dHsrec : nullptr;
+  h->early_opt_done = 0;
+  static const int f_hoist = getenv("RN_HOIST_NORMS") ? atoi(getenv("RN_HOIST_NORMS")) : 1;
+  static const int f_early = getenv("RN_EARLY_OPT") ? atoi(getenv("RN_EARLY_OPT")) : 1;
   if (phase != 2) {
-    r = dec_fwd_chain(h, enc, targets, T, 1, st); if (r) return r;
+    // parameter norms (regulariser values; the optimiser needs them again at the end) and the gate bias of the
+    // reconstructor do not depend on the batch: side stream, under the decoder chain
+    hipStream_t sn = (par && f_hoist) ? sd : st;
+    if (sn != st) fork_to(h, 4, st, sd);
+    param_norms(h, 0, h->scal + 1, sn);
+    if (rec) { param_norms(h, 1, h->scal + 4, sn); gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, h->R, h->rgru, sn); }
+    if (sn != st) hipEventRecord(h->ev[5], sd);       // done long before the decoder chain ends
+    h->norms_hoisted = 1;
+    r = dec_fwd_chain(h, enc, targets, T, 1, st);
+    if (r) { h->norms_hoisted = 0; return r; }
     if (par) { fork_to(h, 0, st, sd); h->gws_cur = h->gws2; }
-    r = dec_fwd_loss(h, targets, T, stepw, 1, sd); if (r) return r;
-    r = dec_bwd_out(h, 1.0f, sd); if (r) return r;
+    r = dec_fwd_loss(h, targets, T, stepw, 1, sd);
+    if (!r) r = dec_bwd_out(h, 1.0f, sd);
     h->gws_cur = h->gws;
+    if (r) { h->norms_hoisted = 0; return r; }
     if (rec) {
-      r = fwd_rec(h, enc, T, 1, st); if (r) return r;
+      if (par && f_hoist) hipStreamWaitEvent(st, h->ev[5], 0);   // bsum_r and the reconstructor's norm
+      r = fwd_rec(h, enc, T, 1, st);
+      h->norms_hoisted = 0;
+      if (r) return r;
       r = bwd_rec_chain(h, h->c.lambda_recon, h->dHsrec, st); if (r) return r;
       if (par) join_from(h, 1, st, sd);              // the decoder BPTT needs dHs_out; scal[2] is final
       hipLaunchKernelGGL(axpb_kernel, dim3(1), dim3(1), 0, st, h->scal + 2, h->scal + 5, h->c.lambda_recon, h->scal + 6);
       if (phase == 1) {                              // no decoder BPTT to hide behind: stay on the main stream
         r = bwd_rec_deferred(h, st); if (r) return r;
       }
+    } else if (par) {
+      join_from(h, 1, st, sd);                       // dHs_out of the vocabulary projection
     }
+    h->norms_hoisted = 0;
     if (phase == 1) return RECNET_OK;
   }
+  if (par) { fork_to(h, 2, st, sd); }
   if (phase == 0 && rec) {
-    if (par) { fork_to(h, 2, st, sd); h->gws_cur = h->gws2; }
+    if (par) h->gws_cur = h->gws2;
     r = bwd_rec_deferred(h, sd); if (r) return r;
     h->gws_cur = h->gws;
+    if (early_opt >= 0 && par && f_early) {
+      r = optimizer_step(h, early_opt, sd, 1); if (r) return r;
+      h->early_opt_done = 1;
+    }
   }
+  // Issuing the decoder's deferred GEMMs for finished parts of the chain while it is still running was measured and
+  // is a loss (+0.22 ms): the batched GEMMs occupy the CUs the latency-bound chain kernels need at every step.
+  // (So is splitting the deferred gradients over two streams after the chain, +0.11 ms: in a replayed graph every extra
+  // fork / join costs more than the concurrency returns.)
   r = dec_bwd_chain(h, dh, st); if (r) return r;
   r = dec_bwd_deferred(h, enc, targets, st); if (r) return r;
-  if (phase == 0 && rec && par) join_from(h, 3, st, sd);
+  if (par) join_from(h, 3, st, sd);
   h->fwd_dec_done = 0;
   return RECNET_OK;
 }
@@ -1359,10 +1417,44 @@ int recnet_train_step_fwd_bwd(recnet_handle* h, const float* enc, const int64_t*
   return RECNET_OK;
 }
 
+static int check_step_args(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* step_weight) {
+  if (!h->dec_bound || (h->kind != RECNET_REC_NONE && !h->rec_bound)) return fail(RECNET_ESTATE, "models not bound");
+  if (!h->dGd.out_weight || (h->kind != RECNET_REC_NONE && !h->rG.out_weight)) return fail(RECNET_ESTATE, "gradients not bound");
+  if (!enc || !targets || !step_weight) return fail(RECNET_EINVAL, "null argument");
+  if (check_T(h, T)) return fail(RECNET_EINVAL, "T out of range");
+  return RECNET_OK;
+}
+
 int recnet_train_step(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
                       const float* step_weight, uint32_t seed, int32_t step, recnet_scalars* scalars, void* stream) {
-  int r = recnet_train_step_fwd_bwd(h, enc, targets, T, step_weight, seed, nullptr, stream); if (r) return r;
-  return recnet_optimizer_step(h, step, RECNET_OPT_REG | RECNET_OPT_CLIP, scalars, stream);
+  REQUIRE_WS(h);
+  int r = check_step_args(h, enc, targets, T, step_weight); if (r) return r;
+  if (step < 1) return fail(RECNET_EINVAL, "step must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  const int flags = RECNET_OPT_REG | RECNET_OPT_CLIP;
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl, seed);
+  hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(1), 0, st, h->ctrl + 1, (uint32_t)step);
+  // the reconstructor's optimiser step is issued inside, under the decoder BPTT; the decoder's here
+  r = fwd_bwd(h, enc, targets, T, step_weight, st, 0, flags); if (r) return r;
+  r = optimizer_step(h, flags, st, h->early_opt_done ? 0 : -1); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  h->fwd_dec_done = 0;
+  LAUNCH_OK();
+  return RECNET_OK;
+}
+
+int recnet_train_step_dev(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T, const float* step_weight,
+                          uint32_t seed_base, int32_t flags, recnet_scalars* scalars, void* stream) {
+  REQUIRE_WS(h);
+  int r = check_step_args(h, enc, targets, T, step_weight); if (r) return r;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, st, (int32_t*)(h->ctrl + 1), h->ctrl, seed_base);
+  r = fwd_bwd(h, enc, targets, T, step_weight, st, 0, flags); if (r) return r;
+  r = optimizer_step(h, flags, st, h->early_opt_done ? 0 : -1); if (r) return r;
+  if (scalars) hipLaunchKernelGGL(export_scalars_kernel, dim3(1), dim3(1), 0, st, h->scal, scalars);
+  h->fwd_dec_done = 0;
+  LAUNCH_OK();
+  return RECNET_OK;
 }
 
 int recnet_set_step(recnet_handle* h, int32_t step, void* stream) {

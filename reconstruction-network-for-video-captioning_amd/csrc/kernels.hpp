@@ -317,8 +317,8 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict_
 // dEmb[token(row), :] += scale * dropmask * demb[row, :]   (dEmb pre-zeroed)
 __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
                                                         const float* __restrict__ demb, int B, int E, int V,
-                                                        float scale, DropDesc dd) {
-  const int row = blockIdx.x, t = row / B, b = row % B;
+                                                        float scale, DropDesc dd, int row0) {
+  const int row = row0 + blockIdx.x, t = row / B, b = row % B;
   long tok = (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
   tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
   const uint32_t key = drop_key(dd);

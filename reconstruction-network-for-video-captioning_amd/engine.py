@@ -321,6 +321,13 @@ class Engine:
                    "recnet_train_step_fwd_bwd_dev")
         self.T = T
 
+    def train_step_dev(self, enc, targets, T, step_weight, seed_base, flags):
+        """Fused forward + backward + optimiser, step count / seed on the device (graph replay, single rank)."""
+        _lib.check(self.lib.recnet_train_step_dev(self.handle, _ptr(enc), _ptr(targets), int(T), _ptr(step_weight),
+                                                  seed_base & 0xFFFFFFFF, int(flags), _ptr(self.scalars), _stream()),
+                   "recnet_train_step_dev")
+        self.T = T
+
     def train_step_part_dev(self, part, enc, targets, T, step_weight, seed_base):
         _lib.check(self.lib.recnet_train_step_part_dev(self.handle, int(part), _ptr(enc), _ptr(targets), int(T),
                                                        _ptr(step_weight), seed_base & 0xFFFFFFFF, _ptr(self.scalars),
