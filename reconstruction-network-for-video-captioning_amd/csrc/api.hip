@@ -43,14 +43,15 @@ struct recnet_handle {
   int dgru = 0, rgru = 0; // recurrent cell of the decoder / reconstructor: 0 LSTM, 1 GRU (4-block gate layout, kernels.hpp)
   int lp;                // 1: operand copies / packed weights are bf16 (DMA-staged GEMM); 0: fp32 (exact path)
   // leading dimensions (elements) of the operand buffers: multiples of 8
-  int ldD, ldE, ldH, ldV, ldA, ld4H, ldWS, ldR, ld4R, ldRA, ldHR, ldRA4;
+  int ldD, ldE, ldH, ldV, ldA, ld4H, ldWS, ldR, ld4R, ldRA, ldHR, ldRA4, ld2H;
   // workspace
   char* ws = nullptr; size_t ws_bytes = 0; size_t need = 0;
   uint32_t* ctrl;        // [0] seed slot, [1] step slot (int32)
   float* scal;           // [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
   // ---- decoder: fp32 state
   float *slab2 = nullptr;   // second slab buffer (local reconstructor backward: dWhr . W_r)
-  float *bsum4 = nullptr;   // [4 max(H,R)] column sums of the gate gradients (source of both bias gradients)
+  float *bsum4 = nullptr, *bsum4r = nullptr;   // [4H], [4R] column sums of the gate gradients (source of both bias gradients)
+  int prezeroed = 0;        // the step's atomic-sum targets were zeroed by one hoisted kernel (fwd_bwd)
   float *bsum_d, *Uv, *Xe, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws, *dHs, *dHsrec, *dc_carry, *dUv,
       *dwacc, *demb, *stepw, *msep;
   // ---- decoder: operand copies (AT = bf16 | float)
@@ -60,8 +61,8 @@ struct recnet_handle {
   // ---- reconstructor
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
-  void *mpd_lp, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
-  void *Wih_a, *Wih_b, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
+  void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
+  void *Wih_f, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   void* Whh_g = nullptr;   // gate-interleaved W_hh of the fused recurrent step (rec_step.hpp); global reconstructor, LSTM, bf16
   int fused_rec = 0;
   // inference search scratch (beam width <= 8)
@@ -95,7 +96,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->ldD = pad8(h->D); h->ldE = pad8(h->E); h->ldH = pad8(h->H); h->ldV = pad8(h->V); h->ldA = pad8(h->A);
   h->ld4H = pad8(4 * h->H); h->ldWS = pad8(4 * h->H + RN_FCH * h->A);
   h->ldR = pad8(h->R); h->ld4R = pad8(4 * h->R); h->ldRA = pad8(h->RA); h->ldHR = pad8(h->H + h->R);
-  h->ldRA4 = pad8(RN_TCH * h->RA);
+  h->ldRA4 = pad8(RN_TCH * h->RA); h->ld2H = pad8(2 * h->H);
   const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
                ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
@@ -103,7 +104,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->stepw = take(Tm);
   h->msep = take(1024);
   h->bsum_d = take(4 * H);
-  h->bsum4 = take(4 * (H > R ? H : R));
+  h->bsum4 = take(4 * H); h->bsum4r = take(4 * (R > 0 ? R : 1));
   h->Uv = take(B * F * A);
   h->Xe = take(Tm * B * 4 * H);
   h->Hs = take(Tm * B * H);
@@ -162,9 +163,9 @@ static size_t carve(recnet_handle* h, char* base) {
     h->Hr = take(Tm * B * R); h->Cr = take(Tm * B * R); h->acts_r = take(Tm * B * 4 * R);
     h->hrmean = take(B * R); h->outm = take(B * R); h->encmean = take(B * R); h->dhrmean = take(B * R);
     h->dmpd = take(Tm * B * H); h->dmp = take(B * H);
-    h->mpd_lp = takev(Tm * B * ldH); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
+    h->Xcat_g = takev(Tm * B * (size_t)h->ld2H); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
     h->dout_lp = takev(B * ldR); h->dGr = takev(Tm * B * ld4R);
-    h->Wih_a = takev(4 * R * ldH); h->Wih_b = takev(4 * R * ldH); h->Whh_w = takev(4 * R * ldR);
+    h->Wih_f = takev(4 * R * (size_t)h->ld2H); h->Whh_w = takev(4 * R * ldR);
     h->Whh_g = takev(4 * R * ldR);
   } else if (h->kind == RECNET_REC_LOCAL) {
     h->Ud = take(Tm * B * RA);
@@ -292,7 +293,7 @@ static void build_pack_tables(recnet_handle* h, int g) {
     add_hh(h->dgru, H, 6, H, h->Wcomb, h->ldH, 0, H);                       // rnn.weight_hh_l0
     add(9, H, h->Wo_w, h->ldH, 0, H);                                       // out.weight
   } else if (h->kind == RECNET_REC_GLOBAL) {
-    add_ih(0, 2 * H, h->Wih_a, h->ldH, 0, H); add_ih(0, 2 * H, h->Wih_b, h->ldH, H, H);
+    add_ih(0, 2 * H, h->Wih_f, h->ld2H, 0, 2 * H);
     add_hh(h->rgru, R, 1, R, h->Whh_w, h->ldR, 0, R);
     if (h->fused_rec) { addr(1, R, h->Whh_g, h->ldR, 0, R, 0, R); o.pack[1].d[o.pack[1].ndst - 1].mode = 1; }
     add(4, R, h->Wor_w, h->ldR, 0, R);
@@ -476,26 +477,28 @@ static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const v
   return s;
 }
 template <typename ST>
-static void colsum_t(const ST* X, int rows, int cols, int ld, float* out, hipStream_t st) {
+static void colsum_t(const ST* X, int rows, int cols, int ld, float* out, hipStream_t st, int zeroed = 0) {
   if (rows >= 64 && (ld & 7) == 0 && (((uintptr_t)X) & 15) == 0) {
     int rs = rows / 96; rs = rs < 1 ? 1 : (rs > 64 ? 64 : rs);
-    hipMemsetAsync(out, 0, (size_t)cols * 4, st);
+    if (!zeroed) hipMemsetAsync(out, 0, (size_t)cols * 4, st);
     hipLaunchKernelGGL(colsum_vec_kernel<ST>, dim3(cdiv(cols, 512), rs), dim3(256), 0, st, X, rows, cols, ld, out);
     return;
   }
   int rs = rows >= 512 ? 8 : 1;
-  if (rs > 1) hipMemsetAsync(out, 0, (size_t)cols * 4, st);
+  if (rs > 1 && !zeroed) hipMemsetAsync(out, 0, (size_t)cols * 4, st);
   hipLaunchKernelGGL(colsum_kernel<ST>, dim3(cdiv(cols, 64), rs), dim3(256), 0, st, X, rows, cols, ld, out, rs > 1 ? 1 : 0);
 }
-static void colsum_at(recnet_handle* h, const void* X, int rows, int cols, int ld, float* out, hipStream_t st) {
-  if (h->lp) colsum_t<bf16_t>((const bf16_t*)X, rows, cols, ld, out, st);
-  else colsum_t<float>((const float*)X, rows, cols, ld, out, st);
+// zeroed: `out` is one of the buffers the hoisted zero_list_kernel of this step cleared
+static void colsum_at(recnet_handle* h, const void* X, int rows, int cols, int ld, float* out, hipStream_t st, int zeroed = 0) {
+  if (h->lp) colsum_t<bf16_t>((const bf16_t*)X, rows, cols, ld, out, st, zeroed);
+  else colsum_t<float>((const float*)X, rows, cols, ld, out, st, zeroed);
 }
 // fork: `side` continues after everything enqueued on `main` so far; join: `main` waits for `side`.  Under
 // stream capture these become graph edges, so independent work runs in parallel branches of the hipGraph.
 static void gate_bias_grad(recnet_handle* h, const void* dG, int rows, int Hd, int ld, float* dbih, float* dbhh, int gru, hipStream_t st) {
-  colsum_at(h, dG, rows, 4 * Hd, ld, h->bsum4, st);
-  hipLaunchKernelGGL(gate_bias_grad_kernel, dim3(cdiv(4 * Hd, 256)), dim3(256), 0, st, h->bsum4, dbih, dbhh, Hd, gru);
+  float* tmp = (dbih == h->dGd.rnn_bias_ih_l0) ? h->bsum4 : h->bsum4r;      // decoder / reconstructor
+  colsum_at(h, dG, rows, 4 * Hd, ld, tmp, st, h->prezeroed);
+  hipLaunchKernelGGL(gate_bias_grad_kernel, dim3(cdiv(4 * Hd, 256)), dim3(256), 0, st, tmp, dbih, dbhh, Hd, gru);
 }
 // dW_hh = dG^T . Hprev over `rows` rows.  LSTM: the 4 gate blocks as they are.  GRU: master blocks (r, z) come from
 // packed blocks (0, 1) and master block n from packed block 3 (the hidden-side n pre-activation, see gru_point).
@@ -570,8 +573,7 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
     pack_block(h, h->Wor_w, h->ldR, h->rP.out_weight, R, R, R, 1.f, st);
     if (h->kind == RECNET_REC_GLOBAL) {
       const GateMap none = gmap_ih(0);
-      pack_gates(h, h->Wih_a, h->ldH, R, h->rP.rnn_weight_ih_l0, 2 * H, H, gmap_ih(h->rgru), nullptr, 0, 0, none, st);
-      pack_gates(h, h->Wih_b, h->ldH, R, h->rP.rnn_weight_ih_l0 + H, 2 * H, H, gmap_ih(h->rgru), nullptr, 0, 0, none, st);
+      pack_gates(h, h->Wih_f, h->ld2H, R, h->rP.rnn_weight_ih_l0, 2 * H, 2 * H, gmap_ih(h->rgru), nullptr, 0, 0, none, st);
       pack_gates(h, h->Whh_w, h->ldR, R, h->rP.rnn_weight_hh_l0, R, R, gmap_hh(h->rgru), nullptr, 0, 0, none, st);
       if (h->fused_rec)
         hipLaunchKernelGGL(pack_interleave_kernel<bf16_t>, dim3(ew_blocks((size_t)4 * R * h->ldR)), dim3(256), 0, st, (bf16_t*)h->Whh_g, h->ldR, R, h->rP.rnn_weight_hh_l0, R, R);
@@ -712,7 +714,7 @@ static int dec_bwd_out(recnet_handle* h, float gscale, hipStream_t st) {
   gemm(h, h->dlog_lp, 0, h->ldV, h->Wo_w, 1, h->ldH, h->dHs, H, nullptr, TB, H, V, 1.f, 0, st);
   // dW_o = dlogits^T . Hs ; db_o = colsum(dlogits)
   gemm(h, h->dlog_lp, 1, h->ldV, h->Hs_lp, 1, h->ldH, h->dGd.out_weight, H, nullptr, V, H, TB, 1.f, 0, st);
-  colsum_at(h, h->dlog_lp, TB, V, h->ldV, h->dGd.out_bias, st);
+  colsum_at(h, h->dlog_lp, TB, V, h->ldV, h->dGd.out_bias, st, h->prezeroed);
   return RECNET_OK;
 }
 // BPTT chain; dh_t (direct) = dHs_out[t] + dhid[t] (the reconstructor's gradient w.r.t. the hidden states)
@@ -755,7 +757,7 @@ static int dec_bwd_deferred_rows(recnet_handle* h, const float* enc, const int64
   // dgates live in columns [0,4H) of dGx, dWh chunks behind them
   {
     gemm(h, dG, 0, ldWS, h->We_w, 1, h->ldE, h->demb + r0 * E, E, nullptr, nrow, E, 4 * H, 1.f, 0, st);
-    if (!acc) hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
+    if (!acc && !h->prezeroed) hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(nrow), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
                        h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0);
     gemm(h, dG, 1, ldWS, at_off(h, h->emb_lp, r0 * h->ldE), 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, GH, E, nrow, 1.f, acc, st);
@@ -800,8 +802,8 @@ static int dec_bwd_deferred_tail(recnet_handle* h, hipStream_t st) {
   const int B = h->B, F = h->F, D = h->D, H = h->H, A = h->A, T = h->T_last, TB = T * B, ldWS = h->ldWS;
   gate_bias_grad(h, h->dGx, TB, H, ldWS, h->dGd.rnn_bias_ih_l0, h->dGd.rnn_bias_hh_l0, h->dgru, st);
   gemm(h, h->dUv_lp, 1, h->ldA, h->enc_lp, 1, h->ldD, h->dGd.attn_U_weight, D, nullptr, A, D, B * F, 1.f, 0, st);
-  colsum_t<float>(h->dwacc, RN_FCH * B, A, A, h->dGd.attn_w_weight, st);
-  colsum_at(h, h->dWhs, TB, A, h->ldA, h->dGd.attn_b, st);
+  colsum_t<float>(h->dwacc, RN_FCH * B, A, A, h->dGd.attn_w_weight, st, h->prezeroed);
+  colsum_at(h, h->dWhs, TB, A, h->ldA, h->dGd.attn_b, st, h->prezeroed);
   return RECNET_OK;
 }
 static int dec_bwd_deferred(recnet_handle* h, const float* enc, const int64_t* targets, hipStream_t st) {
@@ -840,14 +842,13 @@ static int fwd_rec_global(recnet_handle* h, const float* enc, int T, int train, 
   // mean-pooled decoder states, rescaled by caption_max_len / T (global_reconstructor.py:33-37): (cml / T^2) sum_t h_t
   mean_over_t(h, h->Hs, T, H, (float)h->cml / ((float)T * (float)T), h->mp, nullptr, 0, st);
   {
-    const size_t n = (size_t)T * B * h->ldH;
+    const size_t n = (size_t)T * B * h->ld2H;
     const DropDesc dd = mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train);
-    if (h->lp) hipLaunchKernelGGL(bcast_drop_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, h->mp, (bf16_t*)h->mpd_lp, h->ldH, T, B, H, dd);
-    else hipLaunchKernelGGL(bcast_drop_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, h->mp, (float*)h->mpd_lp, h->ldH, T, B, H, dd);
+    if (h->lp) hipLaunchKernelGGL(xcat_global_kernel<bf16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (const bf16_t*)h->Hs_lp, h->ldH, h->mp, (bf16_t*)h->Xcat_g, h->ld2H, T, B, H, dd);
+    else hipLaunchKernelGGL(xcat_global_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (const float*)h->Hs_lp, h->ldH, h->mp, (float*)h->Xcat_g, h->ld2H, T, B, H, dd);
   }
   // Xg = [h_t ; drop_t(mp)] . W_ih^T + b_ih + b_hh, batched over T (only h_r . W_hh^T is recurrent)
-  gemm(h, h->Hs_lp, 0, h->ldH, h->Wih_a, 0, h->ldH, h->Xg, 4 * R, h->bsum_r, T * B, 4 * R, H, 1.f, 0, st);
-  gemm(h, h->mpd_lp, 0, h->ldH, h->Wih_b, 0, h->ldH, h->Xg, 4 * R, nullptr, T * B, 4 * R, H, 1.f, 1, st);
+  gemm(h, h->Xcat_g, 0, h->ld2H, h->Wih_f, 0, h->ld2H, h->Xg, 4 * R, h->bsum_r, T * B, 4 * R, 2 * H, 1.f, 0, st);
   for (int t = 0; t < T; ++t) {
     int S = 0;
     if (t > 0 && h->fused_rec) {
@@ -905,7 +906,7 @@ static int bwd_rec_global(recnet_handle* h, float gscale, float* dhid_out, hipSt
   // dout (operand copy) = gscale * d loss / d out_mean
   pack_block(h, h->dout_lp, h->ldR, h->outm, R, B, R, gscale, st);
   gemm(h, h->dout_lp, 1, h->ldR, h->hrmean_lp, 1, h->ldR, h->rG.out_weight, R, nullptr, R, R, B, 1.f, 0, st);
-  colsum_at(h, h->dout_lp, B, R, h->ldR, h->rG.out_bias, st);
+  colsum_at(h, h->dout_lp, B, R, h->ldR, h->rG.out_bias, st, h->prezeroed);
   gemm(h, h->dout_lp, 0, h->ldR, h->Wor_w, 1, h->ldR, h->dhrmean, R, nullptr, B, R, R, 1.f, 0, st);
   int S = 0;
   for (int t = T - 1; t >= 0; --t) {
@@ -914,8 +915,8 @@ static int bwd_rec_global(recnet_handle* h, float gscale, float* dhid_out, hipSt
     if (t > 0) S = gemm_slabs(h, RN_TAG_REC_BWD, at_off(h, h->dGr, (size_t)t * B * ld4R), ld4R, h->Whh_w, 1, h->ldR, B, R, 4 * R, st);
   }
   // input-side gradients, batched
-  gemm(h, h->dGr, 0, ld4R, h->Wih_a, 1, h->ldH, dhid_out, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
-  gemm(h, h->dGr, 0, ld4R, h->Wih_b, 1, h->ldH, h->dmpd, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
+  gemm(h, h->dGr, 0, ld4R, h->Wih_f, 1, h->ld2H, dhid_out, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
+  gemm(h, h->dGr, 0, ld4R, at_off(h, h->Wih_f, (size_t)H), 1, h->ld2H, h->dmpd, H, nullptr, TB, H, 4 * R, 1.f, 0, st);
   const size_t nBH = (size_t)B * H;
   hipLaunchKernelGGL(bcast_drop_bwd_kernel, dim3(ew_blocks(nBH)), dim3(256), 0, st, h->dmpd, h->dmp, T, B, H,
                      mkdrop(h, RN_SITE_REC_INPUT, h->c.reconstructor_decoder_dropout, train));
@@ -926,8 +927,7 @@ static int bwd_rec_global(recnet_handle* h, float gscale, float* dhid_out, hipSt
 static int bwd_rec_global_deferred(recnet_handle* h, hipStream_t st) {
   const int B = h->B, H = h->H, R = h->R, T = h->T_last, TB = T * B, ld4R = h->ld4R;
   const int GR = (h->rgru ? 3 : 4) * R;
-  gemm(h, h->dGr, 1, ld4R, h->Hs_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, GR, H, TB, 1.f, 0, st);
-  gemm(h, h->dGr, 1, ld4R, h->mpd_lp, 1, h->ldH, h->rG.rnn_weight_ih_l0 + H, 2 * H, nullptr, GR, H, TB, 1.f, 0, st);
+  gemm(h, h->dGr, 1, ld4R, h->Xcat_g, 1, h->ld2H, h->rG.rnn_weight_ih_l0, 2 * H, nullptr, GR, 2 * H, TB, 1.f, 0, st);   // d W_ih = dG^T . [h_t ; drop(mp)]
   if (T > 1)
     dW_hh(h, h->rgru, R, at_off(h, h->dGr, (size_t)B * ld4R), ld4R, h->Hr_lp, h->ldR, h->rG.rnn_weight_hh_l0, (T - 1) * B, 0, st);
   else
@@ -979,7 +979,7 @@ static int bwd_rec_local(recnet_handle* h, float gscale, float* dhid_out, hipStr
   const int train = h->train_last, ld4R = h->ld4R, ldHR = h->ldHR;
   pack_block(h, h->dout_lp, h->ldR, h->outl, R, FB, R, gscale, st);
   gemm(h, h->dout_lp, 1, h->ldR, h->Hr_lp, 1, h->ldR, h->rG.out_weight, R, nullptr, R, R, FB, 1.f, 0, st);
-  colsum_at(h, h->dout_lp, FB, R, h->ldR, h->rG.out_bias, st);
+  colsum_at(h, h->dout_lp, FB, R, h->ldR, h->rG.out_bias, st, h->prezeroed);
   gemm(h, h->dout_lp, 0, h->ldR, h->Wor_w, 1, h->ldR, h->dHr, R, nullptr, FB, R, R, 1.f, 0, st);
   LocBwdArgs a;
   a.B = B; a.T = T; a.H = H; a.R = R; a.A = RA;
@@ -1267,6 +1267,7 @@ int recnet_forward_reconstructor(recnet_handle* h, const float* enc, const float
 
 int recnet_backward_reconstructor(recnet_handle* h, const float* enc, float grad_scale, float* dhiddens_out, void* stream) {
   REQUIRE_WS(h);
+  h->prezeroed = 0;
   if (!h->fwd_rec_done) return fail(RECNET_ESTATE, "backward_reconstructor before forward_reconstructor");
   if (!h->rG.out_weight) return fail(RECNET_ESTATE, "reconstructor gradients not bound");
   hipStream_t st = (hipStream_t)stream;
@@ -1283,6 +1284,7 @@ int recnet_backward_reconstructor(recnet_handle* h, const float* enc, float grad
 int recnet_backward_decoder(recnet_handle* h, const float* enc, const int64_t* targets, const float* dhiddens,
                             float grad_scale, void* stream) {
   REQUIRE_WS(h);
+  h->prezeroed = 0;
   if (!h->fwd_dec_done) return fail(RECNET_ESTATE, "backward_decoder before forward_decoder");
   if (h->fwd_dec_done == 2) return fail(RECNET_ESTATE, "the free-running forward (recnet_forward_decoder_free) has no backward");
   if (!h->dGd.out_weight) return fail(RECNET_ESTATE, "decoder gradients not bound");
@@ -1337,8 +1339,8 @@ int recnet_optimizer_step(recnet_handle* h, int32_t step, int32_t flags, recnet_
 // start all-reducing the reconstructor bucket).  phase 2: the decoder BPTT + its deferred gradients.
 // early_opt >= 0 (single-rank fused step): the reconstructor's optimiser step (flags = early_opt) is issued on the side
 // stream as soon as its gradients are complete, i.e. it runs under the decoder BPTT; the caller then steps the decoder only.
-static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st,
-                   int phase = 0, int early_opt = -1) {
+static int fwd_bwd_impl(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st,
+                        int phase, int early_opt) {
   const bool rec = h->kind != RECNET_REC_NONE;
   hipStream_t sd = h->overlap ? h->s2 : st;
   const bool par = sd != st;
@@ -1354,6 +1356,15 @@ static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, i
     if (sn != st) fork_to(h, 4, st, sd);
     param_norms(h, 0, h->scal + 1, sn);
     if (rec) { param_norms(h, 1, h->scal + 4, sn); gate_bias(h->rP.rnn_bias_ih_l0, h->rP.rnn_bias_hh_l0, h->bsum_r, h->R, h->rgru, sn); }
+    {   // the targets of this step's atomic column sums and of the embedding scatter-add, zeroed in one launch
+      ZeroList z; z.cnt = 0;
+      auto add = [&](float* p, size_t n) { if (p && n) { z.p[z.cnt] = p; z.n[z.cnt] = n; ++z.cnt; } };
+      add(h->dGd.embedding_weight, (size_t)h->V * h->E); add(h->dGd.out_bias, h->V); add(h->bsum4, (size_t)4 * h->H);
+      add(h->dGd.attn_b, h->A); add(h->dGd.attn_w_weight, h->A);
+      if (rec) { add(h->rG.out_bias, h->R); add(h->bsum4r, (size_t)4 * h->R); }
+      hipLaunchKernelGGL(zero_list_kernel, dim3(512), dim3(256), 0, sn, z);
+      h->prezeroed = 1;
+    }
     if (sn != st) hipEventRecord(h->ev[5], sd);       // done long before the decoder chain ends
     h->norms_hoisted = 1;
     r = dec_fwd_chain(h, enc, targets, T, 1, st);
@@ -1398,7 +1409,15 @@ static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, i
   r = dec_bwd_deferred(h, enc, targets, st); if (r) return r;
   if (par) join_from(h, 3, st, sd);
   h->fwd_dec_done = 0;
+  h->prezeroed = 0;
   return RECNET_OK;
+}
+
+static int fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int T, const float* stepw, hipStream_t st,
+                   int phase = 0, int early_opt = -1) {
+  const int r = fwd_bwd_impl(h, enc, targets, T, stepw, st, phase, early_opt);
+  if (r) { h->prezeroed = 0; h->norms_hoisted = 0; h->gws_cur = h->gws; }
+  return r;
 }
 
 int recnet_train_step_fwd_bwd(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,

@@ -286,6 +286,15 @@ __global__ void gate_bias_kernel(const float* __restrict__ bih, const float* __r
   const int blk = i / Hd;
   out[i] = blk < 2 ? bih[i] + bhh[i] : (blk == 2 ? bih[i] : bhh[i - Hd]);
 }
+// zeroes up to 8 buffers in one launch (the targets of the step's atomic column sums / scatter-add)
+struct ZeroList { float* p[8]; size_t n[8]; int cnt; };
+__global__ __launch_bounds__(256) void zero_list_kernel(const ZeroList z) {
+  for (int k = 0; k < z.cnt; ++k) {
+    float* p = z.p[k];
+    const size_t n = z.n[k];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+  }
+}
 // gradients of the two bias vectors from the column sums of the 4-block gate gradients
 __global__ void gate_bias_grad_kernel(const float* __restrict__ sum4, float* __restrict__ dbih, float* __restrict__ dbhh,
                                       int Hd, int gru) {
@@ -953,14 +962,19 @@ __global__ void mean_over_t_kernel(const float* __restrict__ X, int T, int Bn, i
     if (out_lp) out_lp[i] = (AT)s;
   }
 }
-// mpd[t,b,h] = mp[b,h] * dropmask(t,b,h)   (AT operand, zero padded)
+// The global reconstructor's LSTM input x_t = [h_t ; drop_t(mp)] (global_reconstructor.py:38-41) as one GEMM operand:
+//   xcat[t,b, 0:H) = h_t (copy of the decoder's operand copy),  xcat[t,b, H:2H) = mp[b] * dropmask(t,b,.),  zero padded
 template <typename AT>
-__global__ void bcast_drop_kernel(const float* __restrict__ mp, AT* __restrict__ mpd, int ld, int T, int B, int H, DropDesc dd) {
+__global__ void xcat_global_kernel(const AT* __restrict__ hs, int ld_hs, const float* __restrict__ mp, AT* __restrict__ xcat, int ld,
+                                   int T, int B, int H, DropDesc dd) {
   const uint32_t key = drop_key(dd);
   const size_t total = (size_t)T * B * ld;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int h = (int)(i % ld), b = (int)((i / ld) % B), t = (int)(i / ((size_t)ld * B));
-    mpd[i] = (AT)(h < H ? mp[(size_t)b * H + h] * drop_at(dd, key, t, b, H, h) : 0.f);
+    const int c = (int)(i % ld), b = (int)((i / ld) % B), t = (int)(i / ((size_t)ld * B));
+    AT v = (AT)0.f;
+    if (c < H) v = hs[((size_t)t * B + b) * ld_hs + c];
+    else if (c < 2 * H) v = (AT)(mp[(size_t)b * H + (c - H)] * drop_at(dd, key, t, b, H, c - H));
+    xcat[i] = v;
   }
 }
 // dmp[b,h] = sum_t dmpd[t,b,h] * dropmask(t,b,h)
