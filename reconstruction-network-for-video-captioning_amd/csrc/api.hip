@@ -760,6 +760,8 @@ static int dec_bwd_deferred_rows(recnet_handle* h, const float* enc, const int64
     if (!acc && !h->prezeroed) hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(nrow), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
                        h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0);
+    hipLaunchKernelGGL(embed_bwd_hot_kernel, dim3(cdiv(E, 128), cdiv(nrow, RN_HOT_ROWS)), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
+                       h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0, nrow);
     gemm(h, dG, 1, ldWS, at_off(h, h->emb_lp, r0 * h->ldE), 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, GH, E, nrow, 1.f, acc, st);
   }
   // ctx_t = (1/F) sum_f a_t[f] enc[b,f] for these steps (only needed here), then dW_ih[:, E:] (+)= dgates^T . ctx

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb
   const int row = row0 + blockIdx.x, t = row / B, b = row % B;
   long tok = (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
   tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+  if (tok < 3) return;        // <PAD> / <SOS> / <EOS> rows are summed by embed_bwd_hot_kernel (a third of all rows hit them)
   const uint32_t key = drop_key(dd);
   const float* src = demb + (size_t)row * E;
   float* dst = dEmb + (size_t)tok * E;
@@ -337,6 +338,53 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb
     const float m = drop_at(dd, key, t, b, E, j);
     if (m != 0.f) atomicAdd(dst + j, src[j] * scale * m);
   }
+}
+
+// The three special tokens feed ~40 % of all (t, b) positions (every position after a caption's <EOS> is <PAD>, step 0
+// is <SOS>): through the generic kernel that is >1000 atomics on each of the same E addresses.  Here a block (column
+// chunk, 32-row slice) sums the matching rows of its slice in registers and issues one atomic per token and column.
+#define RN_HOT_ROWS 32
+__global__ __launch_bounds__(128) void embed_bwd_hot_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
+                                                            const float* __restrict__ demb, int B, int E, int V,
+                                                            float scale, DropDesc dd, int row0, int nrow) {
+  __shared__ int stok[RN_HOT_ROWS];
+  const int j = blockIdx.x * 128 + threadIdx.x, i0 = blockIdx.y * RN_HOT_ROWS;
+  if (threadIdx.x < RN_HOT_ROWS) {   // tokens of this block's rows (so the row loop below has no dependent global load)
+    const int i = i0 + threadIdx.x;
+    int tk = -1;
+    if (i < nrow) {
+      const int row = row0 + i, t = row / B, b = row - t * B;
+      long v = (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
+      v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+      tk = (int)v;
+    }
+    stok[threadIdx.x] = tk;
+  }
+  __syncthreads();
+  if (j >= E) return;
+  const uint32_t key = drop_key(dd);
+  float acc[3] = {0.f, 0.f, 0.f};
+  // branch-free in groups of 8 rows: the 8 loads are in flight together (rows of other tokens are read and discarded)
+#pragma unroll
+  for (int g = 0; g < RN_HOT_ROWS; g += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + g + q;
+      v[q] = (i < nrow && stok[g + q] >= 0 && stok[g + q] <= 2) ? demb[(size_t)(row0 + i) * E + j] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int tk = stok[g + q];
+      if (tk < 0 || tk > 2) continue;
+      const int row = row0 + i0 + g + q, t = row / B, b = row - t * B;
+      const float x = v[q] * scale * drop_at(dd, key, t, b, E, j);
+      acc[0] += tk == 0 ? x : 0.f; acc[1] += tk == 1 ? x : 0.f; acc[2] += tk == 2 ? x : 0.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (acc[q] != 0.f) atomicAdd(dEmb + (size_t)q * E + j, acc[q]);
 }
 
 // =============================================================================================
