@@ -58,6 +58,8 @@ struct recnet_handle {
   void *enc_lp, *emb_lp, *Hs_lp, *P, *dlog_lp, *dGx, *ctx_lp, *dUv_lp, *dWhs;
   // ---- decoder: packed weights (AT)
   void *U_w, *Wc_w, *We_w, *Wcomb, *Wo_w;
+  void* WcombT = nullptr;   // [H][ldKW]: transpose of Wcomb, the decoder BPTT's GEMM operand with K contiguous (bf16 path)
+  int ldKW = 0, use_wcomb_t = 0;
   // ---- reconstructor
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
@@ -133,6 +135,8 @@ static size_t carve(recnet_handle* h, char* base) {
   h->Wc_w = takev(4 * H * ldD);
   h->We_w = takev(4 * H * ldE);
   h->Wcomb = takev((4 * H + RN_FCH * A) * ldH);
+  h->ldKW = pad8(4 * h->H + RN_FCH * h->A);
+  h->WcombT = takev(H * (size_t)h->ldKW);
   h->Wo_w = takev(V * ldH);
   size_t maxN = 4 * H + A;
   if (h->kind != RECNET_REC_NONE) {
@@ -244,6 +248,10 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const char* e = getenv("RN_FUSED_REC");
     const int want = e ? atoi(e) : 0;
     h->fused_rec = want && h->lp && h->kind == RECNET_REC_GLOBAL && !h->rgru && h->B <= 112 && (h->R & 7) == 0 && h->R <= 2048;
+  }
+  {
+    const char* e = getenv("RN_DEC_BWD_NT");
+    h->use_wcomb_t = (e ? atoi(e) : 1) && h->lp && h->B <= 128;
   }
   h->need = carve(h, nullptr);
   *out = h;
@@ -451,7 +459,8 @@ static int gemm_slabs(recnet_handle* h, int tag, const void* A, int lda, const v
   // split-K caps per site: more slices than this buy nothing for the GEMM (measured) and every slab is re-read by
   // the consumer kernel
   static const int cap_env = getenv("RN_SLAB_CAP") ? atoi(getenv("RN_SLAB_CAP")) : 0;
-  int cap = (tag == RN_TAG_DEC_FWD) ? 4 : (tag == RN_TAG_DEC_BWD ? 8 : 16);
+  static const int dbwd_cap = getenv("RN_DBWD_CAP") ? atoi(getenv("RN_DBWD_CAP")) : 16;
+  int cap = (tag == RN_TAG_DEC_FWD) ? 4 : (tag == RN_TAG_DEC_BWD ? (b_col ? 8 : dbwd_cap) : 16);
   if (dst) cap = 8;
   if (cap_env) cap = cap_env;
   int s = rn_pick_splitk(h->prec, M, N, K, cap, 1);
@@ -556,6 +565,14 @@ static void gate_bias(const float* bih, const float* bhh, float* out, int Hd, in
 // both bias gradients from the 4-block gate gradients dG [rows][4 Hd]
 static void gate_bias_grad(recnet_handle* h, const void* dG, int rows, int Hd, int ld, float* dbih, float* dbhh, int gru, hipStream_t st);
 
+// WcombT = Wcomb^T (after Wcomb changed: pack_weights, the decoder's Adam step)
+static void refresh_wcomb_t(recnet_handle* h, hipStream_t st) {
+  if (!h->use_wcomb_t) return;
+  const int KW = 4 * h->H + RN_FCH * h->A, H = h->H;
+  dim3 grid(cdiv(H, 32), cdiv(h->ldKW, 32));           // source = Wcomb [KW][ldH] (rows beyond KW read as zero -> pad)
+  hipLaunchKernelGGL(transpose_at_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)h->Wcomb, h->ldH, KW, H, (bf16_t*)h->WcombT, h->ldKW);
+}
+
 // Packed operand images of the weights (AT, zero padded leading dimensions), refreshed after every optimiser step.
 static int pack_weights(recnet_handle* h, hipStream_t st) {
   const int H = h->H, D = h->D, E = h->E, A = h->A, V = h->V, R = h->R, RA = h->RA;
@@ -568,6 +585,7 @@ static int pack_weights(recnet_handle* h, hipStream_t st) {
     for (int j = 0; j < RN_FCH; ++j)
       pack_block(h, at_off(h, h->Wcomb, (size_t)(4 * H + j * A) * h->ldH), h->ldH, h->dP.attn_W_weight, H, A, H, 1.f, st);
     pack_block(h, h->Wo_w, h->ldH, h->dP.out_weight, H, V, H, 1.f, st);
+    refresh_wcomb_t(h, st);
   }
   if (h->rec_bound) {
     pack_block(h, h->Wor_w, h->ldR, h->rP.out_weight, R, R, R, 1.f, st);
@@ -741,7 +759,8 @@ static int dec_bwd_chain(recnet_handle* h, const float* dhid, hipStream_t st) {
     a.Wh = h->Wh + (size_t)t * B * A;
     LAUNCH_AT(h, dec_cell_bwd_kernel, dim3(B, RN_FCH), dim3(256), sm, st, a);
     if (t > 0)
-      S = gemm_slabs(h, RN_TAG_DEC_BWD, at_off(h, h->dGx, (size_t)t * B * ldWS), ldWS, h->Wcomb, 1, h->ldH, B, H, KW, st);
+      S = h->use_wcomb_t ? gemm_slabs(h, RN_TAG_DEC_BWD, at_off(h, h->dGx, (size_t)t * B * ldWS), ldWS, h->WcombT, 0, h->ldKW, B, H, KW, st)
+                         : gemm_slabs(h, RN_TAG_DEC_BWD, at_off(h, h->dGx, (size_t)t * B * ldWS), ldWS, h->Wcomb, 1, h->ldH, B, H, KW, st);
   }
   return RECNET_OK;
 }
@@ -1081,6 +1100,7 @@ static int optimizer_step(recnet_handle* h, int flags, hipStream_t st, int only_
     // the kernel also writes the packed operand images of the tensors it updates (no separate re-pack pass)
     hipLaunchKernelGGL(adam_chunk_kernel, dim3(o.nchunks), dim3(256), 0, st, o.d_tab, o.d_chunks, hp, o.d_pnorm, clip,
                        (const int32_t*)(h->ctrl + 1), (const PackDesc*)o.d_pack, h->lp);
+    if (g == 0) refresh_wcomb_t(h, st);
   }
   return RECNET_OK;
 }

@@ -56,12 +56,14 @@ void launch_chain_one(const GemmArgs& a, hipStream_t st) {
 }
 template <int NG, int TAG>
 void launch_chain_nkt(const GemmArgs& a, int nkt, hipStream_t st) {
-  launch_chain_one<NG, 2, TAG>(a, st);
+  if (nkt <= 2) launch_chain_one<NG, 2, TAG>(a, st);
+  else launch_chain_one<NG, 4, TAG>(a, st);
 }
 template <int NG>
 bool launch_chain(const GemmArgs& a, int nkt, hipStream_t st, int tag) {
   switch (tag) {
     case RN_TAG_DEC_FWD: launch_chain_nkt<NG, RN_TAG_DEC_FWD>(a, nkt, st); return true;
+    case RN_TAG_DEC_BWD: launch_chain_nkt<NG, RN_TAG_DEC_BWD>(a, nkt, st); return true;   // with the K-contiguous weight image
     case RN_TAG_REC_FWD: launch_chain_nkt<NG, RN_TAG_REC_FWD>(a, nkt, st); return true;
     case RN_TAG_REC_ATT: launch_chain_nkt<NG, RN_TAG_REC_ATT>(a, nkt, st); return true;
     default: return false;
@@ -112,6 +114,11 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
   a.a_vec = vec_ok(A, lda, a_bf16 ? 2 : 4);
   a.b_vec = vec_ok(B, ldb, b_bf16 ? 2 : 4);
   dim3 grid((N + GEMM_TILE - 1) / GEMM_TILE, (M + GEMM_TILE - 1) / GEMM_TILE, splitk);
+  // the site-tagged symbols of the ring / register-staged kernels are instantiated for one operand layout per site
+  // (forward sites: B row operand, backward sites: B col operand); any other layout runs the untagged form
+  const int tag_bcol = (tag == RN_TAG_DEC_BWD || tag == RN_TAG_REC_BWD || tag == RN_TAG_REC_ATT_BWD) ? 1 : 0;
+  const int tag_chain = tag;
+  if (tag && (a_col || (b_col != 0) != (tag_bcol != 0))) tag = 0;
   if (prec == RN_PREC_BF16) {
     if (!a_bf16 && !b_bf16) launch_layout<bf16_t, float, float>(a, a_col, b_col, grid, st, tag);
     else if (!a_bf16 && b_bf16) launch_layout<bf16_t, float, bf16_t>(a, a_col, b_col, grid, st, tag);
@@ -119,10 +126,10 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
       // forward-form chain launches (activations x weights^T, M <= 128, K slice <= 6 k-tiles): single round trip kernel
       static int chain_on = getenv("RN_GEMM_CHAIN") ? atoi(getenv("RN_GEMM_CHAIN")) : 1;
       static int chain_ng = getenv("RN_GEMM_CHAIN_NG") ? atoi(getenv("RN_GEMM_CHAIN_NG")) : 0;
-      if (chain_on && tag && !a_col && !b_col && M <= 128 && per <= GC_MAX_KT && !c_bf16 && !c2) {
+      if (chain_on && tag_chain && !a_col && !b_col && M <= 128 && per <= GC_MAX_KT && !c_bf16 && !c2) {
         // 128-column workgroups unless that leaves half the chip idle (e.g. the decoder's N = 4H + A = 2176)
         const int ng = chain_ng ? chain_ng : ((((N + 127) / 128) * splitk >= 128) ? 2 : 1);
-        const bool done = ng == 1 ? launch_chain<1>(a, per, st, tag) : launch_chain<2>(a, per, st, tag);
+        const bool done = ng == 1 ? launch_chain<1>(a, per, st, tag_chain) : launch_chain<2>(a, per, st, tag_chain);
         if (done) goto after_launch;
       }
       // both operands bf16 in memory: the DMA-staged ring kernel.  Chain launches (tag > 0) run ~1 block

@@ -13,7 +13,7 @@
 #pragma once
 #include "gemm_lds.hpp"
 
-#define GC_MAX_KT 2          // k-tiles (64 deep) per K slice
+#define GC_MAX_KT 4          // k-tiles (64 deep) per K slice
 
 // NG = 16-column groups per wave (BN = 64 NG columns per workgroup); NKT = k-tiles the kernel is compiled for: the
 // loads of all NKT tiles are issued unconditionally, straight-line (slices with fewer tiles re-read a valid address and

@@ -194,6 +194,23 @@ __global__ void pack_gates_kernel(DT* __restrict__ dst, int ld_dst, int Hd, cons
     dst[i] = (DT)v;
   }
 }
+// dst[c][r] = src[r][c]  (32 x 32 tiles through LDS): the K-contiguous image of a weight that a backward chain GEMM
+// uses as its "col" operand, so that it can load fragments straight into MFMA registers (gemm_chain.hpp)
+template <typename AT>
+__global__ __launch_bounds__(256) void transpose_at_kernel(const AT* __restrict__ src, int ld_src, int rows, int cols,
+                                                           AT* __restrict__ dst, int ld_dst) {
+  __shared__ AT tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : (AT)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;                 // dst row = source column; pad columns [rows, ld_dst) get zeros
+    if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+  }
+}
 // gate-interleaved image of a [4 Hd][cols] recurrent weight (rec_step.hpp): destination row (u/8)*32 + gate*8 + u%8
 template <typename DT>
 __global__ void pack_interleave_kernel(DT* __restrict__ dst, int ld_dst, int Hd, const float* __restrict__ src, int ld_src, int cols) {
