@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void consumer(const float* __restrict__ slab, 
 }
 
 int main(int argc, char** argv) {
-  const int M = 100, N = 6144, K = 1536, S = 4, chain = 30;
+  const int M = 100, N = 6144, K = 1536, S = 6, chain = 30;   // 6 slices of 4 k-tiles (the chain kernel holds <= 4)
   const int which = argc > 1 ? atoi(argv[1]) : 0;     // 0 chain kernel, 1 ring kernel
   bf16_t *A, *B; float *ws, *out;
   hipMalloc(&A, (size_t)M * K * 2 * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&ws, (size_t)S * M * N * 4); hipMalloc(&out, (size_t)M * N * 4);
@@ -24,15 +24,15 @@ int main(int argc, char** argv) {
   a.A = A; a.B = B; a.C = nullptr; a.bias = nullptr; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N;
   a.alpha = 1.f; a.accumulate = 0; a.splitk = S; a.kchunk = K / S; a.ws = ws; a.a_vec = a.b_vec = 1; a.c_bf16 = 0; a.C2 = nullptr; a.ldc2 = 0;
   hipStream_t st; hipStreamCreate(&st);
-  auto fc = gemm_chain_kernel<2, 6, 3>;
+  auto fc = gemm_chain_kernel<2, 4, 3>;
   auto fr = gemm_lds_kernel<false, false, 4, 3>;
-  hipFuncSetAttribute((const void*)fc, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 16384);
+  hipFuncSetAttribute((const void*)fc, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
   hipFuncSetAttribute((const void*)fr, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GL_STAGE_BYTES);
   for (int mode = 0; mode < 2; ++mode) {             // 0: GEMM launches only, 1: GEMM + consumer pairs
     hipGraph_t g; hipGraphExec_t ge;
     hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
     for (int i = 0; i < chain; ++i) {
-      if (which == 0) hipLaunchKernelGGL(fc, dim3(N / 128, 1, S), dim3(256), 6 * 16384, st, a);
+      if (which == 0) hipLaunchKernelGGL(fc, dim3(N / 128, 1, S), dim3(256), 4 * 16384, st, a);
       else hipLaunchKernelGGL(fr, dim3(N / 128, 1, S), dim3(256), 4 * GL_STAGE_BYTES, st, a);
       if (mode) hipLaunchKernelGGL(consumer, dim3((M * N + 255) / 256), dim3(256), 0, st, ws, S, M * N, out, A);
     }
