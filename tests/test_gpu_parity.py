@@ -217,3 +217,51 @@ def test_fused_reconstructor_step_opt_in(name, monkeypatch):
     h . W_hh^T over the full K per workgroup + LSTM pointwise in the epilogue); same bars as the default path."""
     monkeypatch.setenv("RN_FUSED_REC", "1")
     test_autograd_api_losses_and_grads(name, "bf16")
+
+
+# shapes that leave the fast paths of the kernels (F > 32 as in BASELINE config C4, attention sizes > 128 / > 256,
+# H > 512 so a caption spans several cell workgroups) and the degenerate ends (one caption, one frame, one step)
+EDGE = {
+    "F40_C4_frames": ([6, 40, 64, 53, 12, 64, 128, 128], [9, 2, 5, 12, 1, 7]),
+    "A136": ([5, 6, 48, 41, 12, 40, 136, 136], [4, 2, 6, 1, 3]),
+    "A264": ([4, 5, 40, 37, 10, 24, 264, 264], [3, 5, 1, 2]),
+    "H1032": ([3, 4, 32, 29, 8, 1032, 16, 16], [2, 4, 1]),
+    "B1": ([1, 5, 40, 37, 10, 24, 16, 16], [6]),
+    "F1": ([4, 1, 40, 37, 10, 24, 16, 16], [3, 5, 1, 2]),
+    "T1_empty_captions": ([4, 5, 40, 37, 10, 24, 16, 16], [0, 0, 0, 0]),
+    "T31_all_full": ([3, 5, 40, 37, 10, 24, 16, 16], [30, 30, 30]),
+}
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("kind", ["global", "local"])
+@pytest.mark.parametrize("case", sorted(EDGE))
+def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
+    dims, lens = EDGE[case]
+    B, F, D, V, E, H, A, RA = dims
+    if H > 512 and kind == "local":
+        pytest.skip("the H > 512 case exercises the decoder cell kernels; one reconstructor is enough")
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 31)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 32)
+    enc, targets = GU.make_batch(B, F, D, V, lens, 78)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP)
+    step = R.TrainStep(dec, rec)
+    T, w = step.prepare(targets.numpy())
+    assert T == max(lens) + 1
+    step.fwd_bwd(enc.cuda(), targets.cuda(), T, w, seed=6)
+    step.engine.add_reg_grad(0, 1.0)
+    step.engine.add_reg_grad(1, 1.0)
+    torch.cuda.synchronize()
+    ref = oracle_grads(decP, recP, kind, enc, targets, True, 6)
+    sc = step.engine.scalar_dict()
+    tol = TOL[prec]
+    assert abs(sc["dec_loss"] - ref["dec_loss"]) <= tol["loss"] * abs(ref["dec_loss"])
+    assert abs(sc["rec_loss"] - ref["rec_loss"]) <= tol["loss"] * abs(ref["rec_loss"])
+    bad = []
+    for grp, md in (("dec", dec), ("rec", rec)):
+        gv = md["_state"].flat()["grad"].views
+        for k in gv:
+            e = rel_err(gv[k].cpu().numpy(), ref[grp + "_grad"][k])
+            if e > tol["grad"]:
+                bad.append((grp, k, e))
+    assert not bad, bad
