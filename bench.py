@@ -81,7 +81,7 @@ def roofline(eng, run_step, kind, precision, iters=5):
         traffic = int(json.load(open(tf))["traffic_bytes_per_launch"])
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
-            "kernel": "%s (recurrent-step GEMM, %s)" % ("gemm_lds_kernel<false, false, 4, 3>" if kind else "gemm_chain_kernel<1, 2, 1>", "reconstructor fwd" if kind else "decoder fwd"),
+            "kernel": "%s (recurrent-step GEMM, %s)" % ("gemm_lds_kernel<false, false, 4, 3, 96>" if kind else "gemm_chain_kernel<1, 2, 1>", "reconstructor fwd" if kind else "decoder fwd"),
             "launches_timed": n, "avg_launch_us": round(ms * 1e3, 3), "bracket_us": round(ms_raw * 1e3, 3),
             "event_pair_overhead_us": round(ms_null * 1e3, 3), "empty_kernel_us": round(f_empty * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch)}
 

@@ -29,6 +29,15 @@ void launch_lds_one(const GemmArgs& a, dim3 grid, hipStream_t st) {
   if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, NS * GL_STAGE_BYTES); attr_done = true; }
   hipLaunchKernelGGL(fn, grid, dim3(256), NS * GL_STAGE_BYTES, st, a);
 }
+// 96-column workgroups of the row/row form (see gemm_lds.hpp): reconstructor forward chain site
+template <int NS, int TAG>
+void launch_lds_96(const GemmArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  auto fn = gemm_lds_kernel<false, false, NS, TAG, 96>;
+  constexpr int lds = NS * (16384 + 96 * 128);
+  if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+  hipLaunchKernelGGL(fn, dim3((a.N + 95) / 96, (a.M + GEMM_TILE - 1) / GEMM_TILE, a.splitk), dim3(256), lds, st, a);
+}
 template <int NS>
 void launch_lds(const GemmArgs& a, int a_col, int b_col, dim3 grid, hipStream_t st, int tag) {
   switch (tag) {
@@ -137,6 +146,15 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
       static int ns_chain = getenv("RN_GEMM_NS_CHAIN") ? atoi(getenv("RN_GEMM_NS_CHAIN")) : 4;
       static int ns_batch = getenv("RN_GEMM_NS_BATCH") ? atoi(getenv("RN_GEMM_NS_BATCH")) : 2;
       const int ns = tag ? ns_chain : ns_batch;
+      {
+        // chain launch, row/row: 96-column workgroups when that turns a partial wave of workgroups into one per CU
+        static int bn96 = getenv("RN_GEMM_BN96") ? atoi(getenv("RN_GEMM_BN96")) : 1;
+        const int t128 = ((N + 127) / 128) * ((M + 127) / 128) * splitk, t96 = ((N + 95) / 96) * ((M + 127) / 128) * splitk;
+        if (bn96 && tag == RN_TAG_REC_FWD && !a_col && !b_col && ns >= 4 && N % 96 == 0 && t128 < 224 && t96 <= 256) {
+          launch_lds_96<4, RN_TAG_REC_FWD>(a, st);
+          goto after_launch;
+        }
+      }
       if (ns >= 4) launch_lds<4>(a, a_col, b_col, grid, st, tag);
       else if (ns == 3) launch_lds<3>(a, a_col, b_col, grid, st, tag);
       else launch_lds<2>(a, a_col, b_col, grid, st, tag);

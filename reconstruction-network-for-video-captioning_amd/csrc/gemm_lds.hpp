@@ -40,13 +40,14 @@ __device__ __forceinline__ const bf16_t* gl_piece_src(const bf16_t* base, int ld
     return base + (size_t)gk * ld + gm;
   }
 }
-// One operand tile: 4 DMA instructions per wave, each 64 lanes x 16 B = 1 KiB of the image.
-template <bool COL>
+// One operand tile: NP DMA instructions per wave (4 for a 128-row tile, 3 for the 96-row weight tile of the row/row
+// form), each 64 lanes x 16 B = 1 KiB of the image.
+template <bool COL, int NP = 4>
 __device__ __forceinline__ void gl_stage(char* img, const bf16_t* base, int ld, int row0, int rext, int k0, int K,
                                          int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;
+  for (int i = 0; i < NP; ++i) {
+    const int piece = wave * NP + i;
     const bf16_t* src;
     if (!COL) {
       const int r = piece * 8 + (lane >> 3), cp = lane & 7;
@@ -65,11 +66,11 @@ __device__ __forceinline__ void gl_stage(char* img, const bf16_t* base, int ld, 
   }
 }
 // zero the chunks of the (last, partial) k-tile that lie beyond K
-template <bool COL>
+template <bool COL, int NP = 4>
 __device__ __forceinline__ void gl_zero_tail(char* img, int k0, int K, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;
+  for (int i = 0; i < NP; ++i) {
+    const int piece = wave * NP + i;
     bool bad;
     if (!COL) {
       const int r = piece * 8 + (lane >> 3), cp = lane & 7;
@@ -101,12 +102,17 @@ __device__ __forceinline__ bf16x8 gl_frag(const char* img, int row /*first of th
   }
 }
 
-template <bool ACOL, bool BCOL, int NS, int TAG>
+// BN = columns per workgroup: 128, or 96 (row/row form only) — N = 6144 with 4 K slices is 192 workgroups of 128
+// columns but 256 of 96, one per CU, each with a quarter less weight data and MFMA work on the chain's critical path.
+template <bool ACOL, bool BCOL, int NS, int TAG, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
+  static_assert(BN == 128 || (BN == 96 && !BCOL), "96-column tiles: row-layout weights only");
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+  constexpr int NPB = BN / 32;                 // DMA pieces per wave of the B tile = 16-column groups per wave
+  constexpr int STAGE = 16384 + BN * 128;      // A image 16 KiB + B image
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int m0 = blockIdx.y * GEMM_TILE, n0 = blockIdx.x * GEMM_TILE;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
+  const int m0 = blockIdx.y * GEMM_TILE, n0 = blockIdx.x * BN;
   const int z = blockIdx.z;
   const int kbeg = z * p.kchunk;
   int kend = kbeg + p.kchunk;
@@ -115,54 +121,54 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
   constexpr int D = NS - 1;     // prefetch distance in k-tiles
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NPB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NPB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (kend > kbeg) ? (kend - kbeg + 63) / 64 : 0;
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < nkt) {
-      char* st = gl_smem + d * GL_STAGE_BYTES;
+      char* st = gl_smem + d * STAGE;
       gl_stage<ACOL>(st, A, p.lda, m0, p.M, kbeg + d * 64, kend, wave, lane);
-      gl_stage<BCOL>(st + 16384, B, p.ldb, n0, p.N, kbeg + d * 64, kend, wave, lane);
+      gl_stage<BCOL, NPB>(st + 16384, B, p.ldb, n0, p.N, kbeg + d * 64, kend, wave, lane);
     }
   for (int kt = 0; kt < nkt; ++kt) {
     // this wave's DMA of tile kt has landed once at most `ahead` later tiles (8 DMAs each) are outstanding
     const int issued = (kt + D < nkt) ? kt + D : nkt;
     const int ahead = issued - (kt + 1);
-    if (NS >= 4 && ahead >= 2) gl_wait_vmcnt<16>();
-    else if (NS >= 3 && ahead >= 1) gl_wait_vmcnt<8>();
+    if (NS >= 4 && ahead >= 2) gl_wait_vmcnt<2 * (4 + NPB)>();
+    else if (NS >= 3 && ahead >= 1) gl_wait_vmcnt<4 + NPB>();
     else gl_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();           // every wave's part of tile kt landed; everyone is done with tile kt-1
     asm volatile("" ::: "memory");
     if (kt + D < nkt) {
-      char* st = gl_smem + ((kt + D) % NS) * GL_STAGE_BYTES;
+      char* st = gl_smem + ((kt + D) % NS) * STAGE;
       gl_stage<ACOL>(st, A, p.lda, m0, p.M, kbeg + (kt + D) * 64, kend, wave, lane);
-      gl_stage<BCOL>(st + 16384, B, p.ldb, n0, p.N, kbeg + (kt + D) * 64, kend, wave, lane);
+      gl_stage<BCOL, NPB>(st + 16384, B, p.ldb, n0, p.N, kbeg + (kt + D) * 64, kend, wave, lane);
     }
-    char* cur = gl_smem + (kt % NS) * GL_STAGE_BYTES;
+    char* cur = gl_smem + (kt % NS) * STAGE;
     const int k0 = kbeg + kt * 64;
     if (k0 + 64 > kend) {                    // partial last tile: zero what lies beyond K (block-uniform branch)
       gl_zero_tail<ACOL>(cur, k0, kend, wave, lane);
-      gl_zero_tail<BCOL>(cur + 16384, k0, kend, wave, lane);
+      gl_zero_tail<BCOL, NPB>(cur + 16384, k0, kend, wave, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int ks = 0; ks < 64; ks += 32) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[4], fb[NPB];
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = gl_frag<ACOL>(cur, wm + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = gl_frag<BCOL>(cur + 16384, wn + j * 16, ks, lane);
+      for (int j = 0; j < NPB; ++j) fb[j] = gl_frag<BCOL>(cur + 16384, wn + j * 16, ks, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = gemm_mma(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NPB; ++j) acc[i][j] = gemm_mma(fa[i], fb[j], acc[i][j]);
     }
   }
 
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NPB; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(ii * 16 + cr + r) * 68 + j * 16 + cc] = acc[half * 2 + ii][j][r];
 #pragma unroll
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
       const int rl = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
       const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 68 + c4);
       const int row = m0 + wm + half * 32 + rl, col = n0 + wn + c4;
-      if (row >= p.M || col >= p.N) continue;
+      if (row >= p.M || col >= p.N || c4 >= BN / 2) continue;
       if (to_slab) {
         float* dst = Cb + (size_t)row * ldc + col;
         if (vec4 && col + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;

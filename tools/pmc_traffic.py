@@ -9,7 +9,7 @@ def per_launch(d, counter, pat):
         if r["Counter_Name"] == counter and pat in r["Kernel_Name"]:
             tot += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"])
     return tot, len(ids)
-pat = sys.argv[3] if len(sys.argv) > 3 else "gemm_lds_kernel<false, false, 4, 3>"
+pat = sys.argv[3] if len(sys.argv) > 3 else "gemm_lds_kernel<false, false, 4, 3, 96>"
 fs, n1 = per_launch(sys.argv[1], "FETCH_SIZE", pat)
 ws, n2 = per_launch(sys.argv[2], "WRITE_SIZE", pat)
 out = {"kernel": pat, "launches": n1, "fetch_size_kib_per_launch_raw": fs / max(n1, 1), "write_size_kib_per_launch": ws / max(n2, 1),
