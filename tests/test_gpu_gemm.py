@@ -131,6 +131,20 @@ def test_gemm_chain_exact_integers(tag, M, N, K, splitk):
     assert torch.equal(C.double(), ref), (C.double() - ref).abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(100, 1536, 6144, 16), (100, 1536, 6144, 3), (37, 96, 200, 1), (100, 192, 1000, 4),
+                                          (128, 288, 64, 1), (100, 512, 2560, 8)])
+def test_gemm_lds_backward_site_exact_integers(M, N, K, splitk):
+    """Backward chain site (tag 4: activations x weights stored [K][N], read through the transposing LDS load)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    eng = _engine("bf16")
+    Ab, Av = _bf16_operand(M, K, True, g)
+    Bb, Bv = _bf16_operand(K, N, True, g)
+    ref = _ref(Av.float(), Bv.float(), 0, 1)
+    C = eng.gemm_bf16(Ab, Bb, False, True, splitk=splitk, M=M, N=N, K=K, tag=4)
+    torch.cuda.synchronize()
+    assert torch.equal(C.double(), ref), (C.double() - ref).abs().max().item()
+
+
 def test_gemm_lds_random_and_epilogue():
     torch.manual_seed(11)
     eng = _engine("bf16")
