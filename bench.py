@@ -103,6 +103,8 @@ def main():
                     "(the north-star workload is LSTM; GRU is config.py:31's literal default)")
     ap.add_argument("--lengths", default="uniform", choices=["uniform", "msvd"], help="caption lengths: the benchmark's "
                     "U{4..30} with one full-length caption (T = 31), or MSVD-like 3 + Poisson(5) (the loop exits early)")
+    ap.add_argument("--force-allreduce", action="store_true", help="keep the gradient all-reduce (and the three-graph step "
+                    "built around it) with a single rank too: exercises the RCCL path on one GPU")
     ap.add_argument("--feed", type=int, default=0, help="1: every step takes a fresh HOST batch through feed.DeviceFeeder "
                     "(pinned staging + H2D on a side stream); reports the PCIe-inclusive rate, not the headline value")
     args = ap.parse_args()
@@ -136,7 +138,7 @@ def main():
     lo, hi = R.shard_bounds(Bg, world, rank)
     enc = synthetic_features(hi - lo, F, D, seed=1234 + rank).to(dev)
     targets = targets_g[:, lo:hi].contiguous().to(dev)
-    step = R.DataParallelTrainStep(dec, rec, Bg, rank, world, n_frames=F, always_reduce=under_launcher)
+    step = R.DataParallelTrainStep(dec, rec, Bg, rank, world, n_frames=F, always_reduce=args.force_allreduce and under_launcher)
     T, w = step.prepare(targets_g.numpy())
 
     def sync_all():
