@@ -179,8 +179,9 @@ int recnet_forward_decoder(recnet_handle* h, const float* enc, const int64_t* ta
 /* ---- forward_decoder without teacher forcing, train.py:46-51 — the validation pass (train.py:327 calls
  * forward_decoder with the default teacher_forcing_ratio = 0): the input of step t+1 is the arg-max of the logits
  * Decoder.forward returned at step t.  Same arguments and loss as recnet_forward_decoder (targets / masks only enter the
- * loss and T); output_indices [T,B] int64 receives the fed-back tokens (train.py:50, `output_indices`).  Forward only:
- * recnet_backward_decoder after it returns RECNET_ESTATE; the hidden states do feed recnet_forward_reconstructor. */
+ * loss and T); output_indices [T,B] int64 receives the fed-back tokens (train.py:50, `output_indices`).  A following
+ * recnet_backward_decoder differentiates this pass (the arg-max passes no gradient; the embedding gradient is scattered to
+ * the rows of the tokens that were fed); the hidden states feed recnet_forward_reconstructor as usual. */
 int recnet_forward_decoder_free(recnet_handle* h, const float* enc, const int64_t* targets, int32_t T,
                                 const float* step_weight, int32_t train, uint32_t seed, float* hiddens_out,
                                 int64_t* output_indices, recnet_scalars* scalars, void* stream);

@@ -288,6 +288,27 @@ class _DecoderSeq(torch.autograd.Function):
         return (None,) * 8 + (None,) * len(ctx.ms.params())
 
 
+class _DecoderSeqFree(torch.autograd.Function):
+    """forward_decoder without teacher forcing (train.py:46-51): arg-max fed back on the device.  Differentiable like
+    the reference's (the arg-max passes no gradient; the embedding gradient goes to the rows of the tokens fed)."""
+
+    @staticmethod
+    def forward(ctx, eng, ms, enc, targets, T, stepw, train, seed, *params):
+        hid, out = eng.forward_decoder_free(enc, targets, T, stepw, train=train, seed=seed)
+        ctx.eng, ctx.ms, ctx.enc, ctx.targets = eng, ms, enc, targets
+        ctx.mark_non_differentiable(out)
+        return eng.scalars[2].clone(), hid, out
+
+    @staticmethod
+    def backward(ctx, dloss, dhid, _dout):
+        eng = ctx.eng
+        gs = float(dloss) if dloss is not None else 0.0
+        eng.backward_decoder(ctx.enc, ctx.targets, None if dhid is None else dhid.contiguous(), gs)
+        eng.add_reg_grad(0, gs)
+        ctx.ms.publish_grads()
+        return (None,) * 8 + (None,) * len(ctx.ms.params())
+
+
 class _ReconstructorSeq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, ms, hiddens, enc, T, train, seed, *params):
@@ -320,8 +341,9 @@ def forward_decoder(decoder, encoder_outputs, targets, target_masks, teacher_for
 
     Teacher forcing is drawn like the reference does (`random.random() <= teacher_forcing_ratio`, train.py:38).  The
     teacher-forced pass (training: config.py:71 ratio 1.0) is differentiable; output_indices is empty.  The free-running
-    pass (validation, train.py:327 — the default ratio 0) feeds the arg-max back on the device, returns
-    output_indices [T,B] and is forward-only: loss and hiddens carry no autograd graph."""
+    pass (validation, train.py:327 — the default ratio 0; training when the draw says so) feeds the arg-max back on
+    the device and returns output_indices [T,B]; it is differentiable too (the embedding gradient goes to the tokens
+    that were fed)."""
     use_teacher_forcing = random.random() <= teacher_forcing_ratio
     model = decoder["model"]
     B, F = encoder_outputs.shape[0], encoder_outputs.shape[1]
@@ -335,10 +357,8 @@ def forward_decoder(decoder, encoder_outputs, targets, target_masks, teacher_for
     seed = decoder["_C"].dropout_seed + decoder["_state"].step if seed is None else seed
     decoder["_last_seed"] = seed
     if not use_teacher_forcing:
-        with torch.no_grad():
-            hid, out = eng.forward_decoder_free(encoder_outputs.contiguous(), targets.contiguous(), T, stepw,
-                                                train=model.training, seed=seed)
-            return eng.scalars[2].clone(), hid, out
+        return _DecoderSeqFree.apply(eng, decoder["_state"], encoder_outputs.contiguous(), targets.contiguous(), T, stepw,
+                                     model.training, seed, *decoder["_state"].params().values())
     loss, hid = _DecoderSeq.apply(eng, decoder["_state"], encoder_outputs.contiguous(), targets.contiguous(), T,
                                   stepw, model.training, seed, *decoder["_state"].params().values())
     return loss, hid, torch.zeros(0, dtype=torch.long)

@@ -70,6 +70,8 @@ struct recnet_handle {
   // inference search scratch (beam width <= 8)
   float *sr_logits, *sr_scores, *sr_h[2], *sr_c[2], *sr_hn, *sr_cn, *sr_cum[2], *sr_vals;
   int64_t *sr_tok[2], *sr_hist[2]; int32_t *sr_eos[2], *sr_idx;
+  int64_t* in_tok = nullptr;   // [Tm][B] tokens fed by the last free-running forward (its backward scatters the embedding gradient by them)
+  int free_fwd = 0;
   size_t gws_floats, slab_floats;
   float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
   hipStream_t s2 = nullptr; hipEvent_t ev[16] = {}; int overlap = 1;
@@ -155,6 +157,7 @@ static size_t carve(recnet_handle* h, char* base) {
       h->sr_h[i] = take(W * B * H); h->sr_c[i] = take(W * B * H); h->sr_cum[i] = take(W * B);
       h->sr_tok[i] = (int64_t*)take(2 * W * B); h->sr_hist[i] = (int64_t*)take(2 * W * B * Tm); h->sr_eos[i] = (int32_t*)take(W * B);
     }
+    h->in_tok = (int64_t*)take(2 * Tm * B);
     h->sr_hn = take(W * B * H); h->sr_cn = take(W * B * H); h->sr_vals = take(W * B); h->sr_idx = (int32_t*)take(W * B);
   }
   if (h->kind != RECNET_REC_NONE) {
@@ -663,7 +666,9 @@ static int dec_fwd_chain(recnet_handle* h, const float* enc, const int64_t* targ
   const float* prev_state = h->dgru ? h->Hs : h->Cs;   // what the pointwise part carries: h_{t-1} (GRU) / c_{t-1}
   for (int t = 0; t < T; ++t) {
     if (free_tokens) {
-      embed_fwd(h, nullptr, t == 0 ? h->sr_tok[0] : free_tokens + (size_t)(t - 1) * B, B, train, t, st, (size_t)t * B);
+      const int64_t* fed = t == 0 ? h->sr_tok[0] : free_tokens + (size_t)(t - 1) * B;
+      hipMemcpyAsync(h->in_tok + (size_t)t * B, fed, (size_t)B * 8, hipMemcpyDeviceToDevice, st);
+      embed_fwd(h, nullptr, fed, B, train, t, st, (size_t)t * B);
       gemm(h, at_off(h, h->emb_lp, (size_t)t * B * h->ldE), 0, h->ldE, h->We_w, 0, h->ldE, h->Xe + (size_t)t * B * 4 * H, 4 * H,
            h->bsum_d, B, 4 * H, E, 1.f, 0, st);
     }
@@ -715,8 +720,8 @@ static int fwd_decoder(recnet_handle* h, const float* enc, const int64_t* target
   int r = dec_fwd_chain(h, enc, targets, T, train, st, free_tokens); if (r) return r;
   r = dec_fwd_loss(h, targets, T, stepw, train, st, free_tokens != nullptr); if (r) return r;
   if (hiddens_out) copyf(h->Hs, hiddens_out, (size_t)T * h->B * h->H, st);
-  // 2: hidden states are valid for the reconstructor's forward, but there is no backward through a free-running pass
-  h->fwd_dec_done = free_tokens ? 2 : 1; h->fwd_rec_done = 0; h->rec_bwd_done = 0;
+  // free_fwd: the backward scatters the embedding gradient by the tokens that were fed (in_tok), not by the targets
+  h->fwd_dec_done = 1; h->free_fwd = free_tokens ? 1 : 0; h->fwd_rec_done = 0; h->rec_bwd_done = 0;
   return RECNET_OK;
 }
 
@@ -778,9 +783,11 @@ static int dec_bwd_deferred_rows(recnet_handle* h, const float* enc, const int64
     gemm(h, dG, 0, ldWS, h->We_w, 1, h->ldE, h->demb + r0 * E, E, nullptr, nrow, E, 4 * H, 1.f, 0, st);
     if (!acc && !h->prezeroed) hipMemsetAsync(h->dGd.embedding_weight, 0, (size_t)V * E * 4, st);
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(nrow), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
-                       h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0);
+                       h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0,
+                       (const int64_t*)(h->free_fwd ? h->in_tok : nullptr));
     hipLaunchKernelGGL(embed_bwd_hot_kernel, dim3(cdiv(E, 128), cdiv(nrow, RN_HOT_ROWS)), dim3(128), 0, st, h->dGd.embedding_weight, targets, h->demb, B, E, V,
-                       h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0, nrow);
+                       h->c.embedding_scale, mkdrop(h, RN_SITE_DEC_EMBED, h->c.embedding_dropout, train), (int)r0, nrow,
+                       (const int64_t*)(h->free_fwd ? h->in_tok : nullptr));
     gemm(h, dG, 1, ldWS, at_off(h, h->emb_lp, r0 * h->ldE), 1, h->ldE, h->dGd.rnn_weight_ih_l0, E + D, nullptr, GH, E, nrow, 1.f, acc, st);
   }
   // ctx_t = (1/F) sum_f a_t[f] enc[b,f] for these steps (only needed here), then dW_ih[:, E:] (+)= dgates^T . ctx
@@ -1308,7 +1315,6 @@ int recnet_backward_decoder(recnet_handle* h, const float* enc, const int64_t* t
   REQUIRE_WS(h);
   h->prezeroed = 0;
   if (!h->fwd_dec_done) return fail(RECNET_ESTATE, "backward_decoder before forward_decoder");
-  if (h->fwd_dec_done == 2) return fail(RECNET_ESTATE, "the free-running forward (recnet_forward_decoder_free) has no backward");
   if (!h->dGd.out_weight) return fail(RECNET_ESTATE, "decoder gradients not bound");
   if (!enc || !targets) return fail(RECNET_EINVAL, "null argument");
   int r = bwd_decoder(h, enc, targets, dhiddens, grad_scale, (hipStream_t)stream); if (r) return r;
@@ -1369,6 +1375,7 @@ static int fwd_bwd_impl(recnet_handle* h, const float* enc, const int64_t* targe
   int r;
   const float* dh = rec ? h->dHsrec : nullptr;
   h->early_opt_done = 0;
+  if (phase != 2) h->free_fwd = 0;                 // the fused step is teacher-forced
   static const int f_hoist = getenv("RN_HOIST_NORMS") ? atoi(getenv("RN_HOIST_NORMS")) : 1;
   static const int f_early = getenv("RN_EARLY_OPT") ? atoi(getenv("RN_EARLY_OPT")) : 1;
   if (phase != 2) {

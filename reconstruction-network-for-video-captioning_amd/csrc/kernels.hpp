@@ -340,13 +340,19 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict_
   AT* dst = emb + (size_t)row * ld;
   for (int j = threadIdx.x; j < ld; j += 128) dst[j] = (AT)(j < E ? src[j] * scale * drop_at(dd, key, t, b, E, j) : 0.f);
 }
+// input token of decoder step t for caption b: the tokens that were actually fed when a free-running forward recorded
+// them (in_tok [T][B], train.py:47-51), else teacher forcing: <SOS> at t = 0, targets[t-1] after (train.py:25,45)
+__device__ __forceinline__ long rn_input_token(const int64_t* __restrict__ in_tok, const int64_t* __restrict__ targets, int t, int b,
+                                               int B, int V) {
+  long tok = in_tok ? in_tok[(size_t)t * B + b] : (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
+  return tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+}
 // dEmb[token(row), :] += scale * dropmask * demb[row, :]   (dEmb pre-zeroed)
 __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
                                                         const float* __restrict__ demb, int B, int E, int V,
-                                                        float scale, DropDesc dd, int row0) {
+                                                        float scale, DropDesc dd, int row0, const int64_t* __restrict__ in_tok) {
   const int row = row0 + blockIdx.x, t = row / B, b = row % B;
-  long tok = (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
-  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+  const long tok = rn_input_token(in_tok, targets, t, b, B, V);
   if (tok < 3) return;        // <PAD> / <SOS> / <EOS> rows are summed by embed_bwd_hot_kernel (a third of all rows hit them)
   const uint32_t key = drop_key(dd);
   const float* src = demb + (size_t)row * E;
@@ -363,7 +369,8 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb
 #define RN_HOT_ROWS 32
 __global__ __launch_bounds__(128) void embed_bwd_hot_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
                                                             const float* __restrict__ demb, int B, int E, int V,
-                                                            float scale, DropDesc dd, int row0, int nrow) {
+                                                            float scale, DropDesc dd, int row0, int nrow,
+                                                            const int64_t* __restrict__ in_tok) {
   __shared__ int stok[RN_HOT_ROWS];
   const int j = blockIdx.x * 128 + threadIdx.x, i0 = blockIdx.y * RN_HOT_ROWS;
   if (threadIdx.x < RN_HOT_ROWS) {   // tokens of this block's rows (so the row loop below has no dependent global load)
@@ -371,9 +378,7 @@ __global__ __launch_bounds__(128) void embed_bwd_hot_kernel(float* __restrict__ 
     int tk = -1;
     if (i < nrow) {
       const int row = row0 + i, t = row / B, b = row - t * B;
-      long v = (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
-      v = v < 0 ? 0 : (v >= V ? V - 1 : v);
-      tk = (int)v;
+      tk = (int)rn_input_token(in_tok, targets, t, b, B, V);
     }
     stok[threadIdx.x] = tk;
   }

@@ -194,12 +194,12 @@ def test_free_running_validation_pass(name, prec):
     dl, hid, idx = R.forward_decoder(dec, encd, tg, tg > 0)
     tol = TOL[prec]
     T = int(g["T"])
-    assert tuple(idx.shape) == (T, dims[0]) and not dl.requires_grad
+    assert tuple(idx.shape) == (T, dims[0]) and not idx.requires_grad
     agree = float((idx.cpu().numpy() == g["output_indices"]).mean())
     if prec == "f32":
         assert agree == 1.0
-        assert np.abs(hid.cpu().numpy() - g["hiddens"]).max() <= tol["hid"]
-        assert abs(float(dl) - float(g["dec_loss"])) <= tol["loss"] * abs(float(g["dec_loss"]))
+        assert np.abs(hid.detach().cpu().numpy() - g["hiddens"]).max() <= tol["hid"]
+        assert abs(float(dl.detach()) - float(g["dec_loss"])) <= tol["loss"] * abs(float(g["dec_loss"]))
     else:
         assert agree >= 0.6          # one flipped near-tie changes every later token of that caption
     if kind and prec == "f32":
@@ -207,8 +207,45 @@ def test_free_running_validation_pass(name, prec):
         fwd = R.forward_global_reconstructor if kind == "global" else R.forward_local_reconstructor
         rl = fwd(hid, encd, rec)
         assert abs(float(rl.detach()) - float(g["rec_loss"])) <= tol["loss"] * abs(float(g["rec_loss"]))
-    with pytest.raises(Exception):   # forward-only: no graph to differentiate
-        dl.backward()
+
+
+@pytest.mark.parametrize("cells", [("LSTM", "LSTM"), ("GRU", "GRU")])
+@pytest.mark.parametrize("kind", [None, "local"])
+def test_free_running_pass_is_differentiable(kind, cells):
+    """teacher_forcing_ratio = 0 in TRAIN mode (dropout on) with loss.backward(), against the oracle's autograd of the
+    same free-running unroll: same tokens, losses and gradients (the embedding gradient follows the fed tokens)."""
+    dims = [6, 5, 48, 41, 12, 24, 16, 16]
+    B, F, D, V, E, H, A, RA = dims
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, cells[0]), 41)
+    decP["out.weight"] = decP["out.weight"] * 6.0          # decisive arg-max
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA, cells[1]), 42) if kind else None
+    enc, targets = GU.make_batch(B, F, D, V, [5, 2, 7, 3, 1, 4], 79)
+    C, dec, rec = make_models(dims, kind, "f32", decP, recP, cells=cells)
+    encd, tg = enc.cuda(), targets.cuda()
+    dl, hid, idx = R.forward_decoder(dec, encd, tg, tg > 0, 0.0, seed=8)
+    loss = dl
+    if kind:
+        rl = R.forward_local_reconstructor(hid, encd, rec, seed=8)
+        loss = dl + rl
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle
+    st = O.TrainState(decP, recP, kind, cell=cells[0], rec_cell=cells[1])
+    drop = O.Dropper("hash", seed=8)
+    odl, ohid, oidx, oce, _ = O.forward_decoder(st.dec, enc, targets, targets > 0, cell=cells[0], drop=drop,
+                                                teacher_forcing=False, return_parts=True)
+    oloss = odl
+    if kind:
+        oloss = odl + O.forward_local_reconstructor(st.rec, ohid, enc, cell=cells[1], drop=drop)
+    oloss.backward()
+    assert np.array_equal(idx.cpu().numpy(), oidx.numpy())
+    tol = TOL["f32"]
+    assert abs(float(loss.detach()) - float(oloss)) <= tol["loss"] * abs(float(oloss))
+    for k, p in dec["model"].named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), st.dec[k].grad.numpy()) <= tol["grad"], k
+    if kind:
+        for k, p in rec["model"].named_parameters():
+            assert rel_err(p.grad.cpu().numpy(), st.rec[k].grad.numpy()) <= tol["grad"], k
 
 
 @pytest.mark.parametrize("name", ["global_train", "global_eval", "full_global_B8"])
