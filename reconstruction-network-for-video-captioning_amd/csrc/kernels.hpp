@@ -1125,18 +1125,52 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
 #pragma unroll
     for (int t = 0; t < 32; ++t) hv[t] = (t < p.T && h < p.H) ? p.Hs[((size_t)t * p.B + b) * p.H + h] : 0.f;
   }
+  // Ud[t, b, k] of this wave's time steps (t = wave, wave + 4, ...; lane -> k = lane, lane + 64), also issued up front:
+  // the score loop below then has no load in it (A <= 128, T <= 32 fast path)
+  const bool fastA = fastT && p.A <= 128;
+  float udr[8][2];
+  if (fastA) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = wave + 4 * i;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = lane + 64 * j;
+        udr[i][j] = (t < p.T && k < p.A) ? p.Ud[((size_t)t * p.B + b) * p.A + k] : 0.f;
+      }
+    }
+  }
   for (int k = tid; k < p.A; k += 256) {
     const float v = p.slab ? sum_strided(p.slab + (size_t)b * p.A + k, zs, p.S) : 0.f;
     swh[k] = v;
     if (blockIdx.y == 0) p.Whr_out[(size_t)b * p.A + k] = v;
   }
   __syncthreads();
-  for (int t = wave; t < p.T; t += 4) {
-    const float* ud = p.Ud + ((size_t)t * p.B + b) * p.A;
-    float s = 0.f;
-    for (int k = lane; k < p.A; k += 64) s += p.w[k] * rn_tanh(swh[k] + ud[k] + p.ab[k]);
-    s = wave_sum(s);
-    if (lane == 0) { sbeta[t] = s; if (blockIdx.y == 0) p.beta_out[(size_t)b * p.T + t] = s; }
+  if (fastA) {
+    float wk[2], bk[2], hk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = lane + 64 * j;
+      wk[j] = k < p.A ? p.w[k] : 0.f; bk[j] = k < p.A ? p.ab[k] : 0.f; hk[j] = k < p.A ? swh[k] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = wave + 4 * i;
+      if (t < p.T) {
+        float s = wk[0] * rn_tanh(hk[0] + udr[i][0] + bk[0]);
+        if (p.A > 64) s += wk[1] * rn_tanh(hk[1] + udr[i][1] + bk[1]);
+        s = wave_sum(s);
+        if (lane == 0) { sbeta[t] = s; if (blockIdx.y == 0) p.beta_out[(size_t)b * p.T + t] = s; }
+      }
+    }
+  } else {
+    for (int t = wave; t < p.T; t += 4) {
+      const float* ud = p.Ud + ((size_t)t * p.B + b) * p.A;
+      float s = 0.f;
+      for (int k = lane; k < p.A; k += 64) s += p.w[k] * rn_tanh(swh[k] + ud[k] + p.ab[k]);
+      s = wave_sum(s);
+      if (lane == 0) { sbeta[t] = s; if (blockIdx.y == 0) p.beta_out[(size_t)b * p.T + t] = s; }
+    }
   }
   __syncthreads();
   if (h >= p.H) return;
@@ -1190,10 +1224,93 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   const uint32_t key = drop_key(p.dd);
   const float invT = 1.0f / (float)T;
   const int nt = (T - ch + RN_TCH - 1) / RN_TCH;        // decoder steps of this chunk
+  const size_t st = (size_t)p.B * H * RN_TCH;
+  const int G = (A <= 256) ? 256 / A : 1;
+  // ---- fast path (T <= 32, H <= 512, A <= 128): every global load of the kernel that does not depend on its own
+  // results is issued here, before the first barrier — the kernel is one link of a dependent chain and otherwise pays
+  // one memory latency per phase (hidden-state rows of the wave's dot products, the chunk's old dHs values, Ud / dUd of
+  // the thread's (t', k) cells)
+  const bool fast = T <= 32 && H <= 512 && A <= 128;
+  float hsr[2][8], dhv[2][8], udv[4], dudv[4];
+  const int kk = tid % A, gi = tid / A;
+  if (fast) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = wave + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = lane + 64 * j;
+        hsr[q][j] = (i < nt && h < H) ? p.Hs[((size_t)(ch + i * RN_TCH) * p.B + b) * H + h] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int h = tid + 256 * q;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        dhv[q][i] = (!p.first && h < H && i < nt) ? p.dHs[((size_t)ch * p.B + b) * H + h + (size_t)i * st] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = gi + q * G;
+      udv[q] = 0.f; dudv[q] = 0.f;
+      if (gi < G && i < nt) {
+        const size_t o = ((size_t)(ch + i * RN_TCH) * p.B + b) * A + kk;
+        udv[q] = p.Ud[o];
+        if (!p.first) dudv[q] = p.dUd[o];
+      }
+    }
+  }
   for (int j = tid; j < H; j += 256)
     sdx[j] = sum_strided(p.slab + (size_t)b * W2 + j, zs, p.S) * drop_at(p.dd, key, p.s, b, H, j);
   for (int t = tid; t < T; t += 256) sbt[t] = p.beta[(size_t)b * T + t] * invT;
   __syncthreads();
+  if (fast) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = wave + 4 * q;
+      if (i < nt) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int h = lane + 64 * j; if (h < H) s += sdx[h] * hsr[q][j]; }
+        s = wave_sum(s);
+        if (lane == 0) sdb[ch + i * RN_TCH] = s * invT;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int h = tid + 256 * q;
+      if (h < H) {
+        const float dx = sdx[h];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < nt) p.dHs[((size_t)ch * p.B + b) * H + h + (size_t)i * st] = dhv[q][i] + sbt[ch + i * RN_TCH] * dx;
+      }
+    }
+    __syncthreads();
+    if (gi < G) {
+      const float whk = p.Whr[(size_t)b * A + kk] + p.ab[kk];
+      const float wk = p.w[kk];
+      float dwh = 0.f, dw = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = gi + q * G;
+        if (i < nt) {
+          const int t = ch + i * RN_TCH;
+          const size_t o = ((size_t)t * p.B + b) * A + kk;
+          const float tz = rn_tanh(whk + udv[q]);
+          const float dz = sdb[t] * wk * (1.f - tz * tz);
+          dw += sdb[t] * tz;
+          dwh += dz;
+          const float nv = dudv[q] + dz;
+          p.dUd[o] = nv;
+          if (p.last) reinterpret_cast<AT*>(p.dUd_lp)[((size_t)t * p.B + b) * p.ld_dUd + kk] = (AT)nv;
+        }
+      }
+      spart[gi * A + kk] = dwh;
+      spart[(G + gi) * A + kk] = dw;
+    }
+  } else {
   for (int i = wave; i < nt; i += 4) {
     const int t = ch + i * RN_TCH;
     const float* hs = p.Hs + ((size_t)t * p.B + b) * H;
@@ -1203,7 +1320,6 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
     if (lane == 0) sdb[t] = s * invT;
   }
   // dHs[t',b,:] += (1/T) beta[t'] dx for the chunk's t' (independent read-modify-writes, four in flight)
-  const size_t st = (size_t)p.B * H * RN_TCH;
   for (int h = tid; h < H; h += 256) {
     const float dx = sdx[h];
     float* d0 = p.dHs + ((size_t)ch * p.B + b) * H + h;
@@ -1223,7 +1339,6 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   }
   __syncthreads();
   // (t', k) plane: thread -> k = tid % A, group gi = tid / A
-  const int G = (A <= 256) ? 256 / A : 1;
   auto tk = [&](int k2, int g2) {
     const float whk = p.Whr[(size_t)b * A + k2] + p.ab[k2];
     const float wk = p.w[k2];
@@ -1244,6 +1359,7 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   };
   if (A <= 256) { if (tid < G * A) tk(tid % A, tid / A); }
   else for (int k2 = tid; k2 < A; k2 += 256) tk(k2, 0);
+  }   // !fast
   __syncthreads();
   AT* dwr = reinterpret_cast<AT*>(p.dWhr) + (size_t)b * p.ld_dwhr;
   for (int k2 = tid; k2 < A; k2 += 256) {
