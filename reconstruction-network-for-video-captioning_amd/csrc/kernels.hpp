@@ -598,6 +598,16 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
       uvr[i][j] = (f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
     }
   }
+  // the rest of what the later phases read from memory (attention vectors, c_{t-1} of the pointwise phase): requested
+  // now, so that no phase after a barrier starts with a memory round trip
+  float wk[2], bk[2], cpre[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = lane + 64 * j;
+    wk[j] = k < A ? p.w[k] : 0.f; bk[j] = k < A ? p.ab[k] : 0.f;
+    const int uu = u0 + tid + 256 * j;
+    cpre[j] = (p.c_prev && uu < H) ? p.c_prev[(size_t)b * H + uu] : 0.f;
+  }
   for (int k = tid; k < A; k += 256) {
     const float v = p.slab ? sum_strided(p.slab + (size_t)b * WS + W4 + k, zs, p.S) : 0.f;
     swh[k] = v;
@@ -605,11 +615,11 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
   }
   __syncthreads();
   {
-    float wk[2], bk[2], hk[2];
+    float hk[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k = lane + 64 * j;
-      wk[j] = k < A ? p.w[k] : 0.f; bk[j] = k < A ? p.ab[k] : 0.f; hk[j] = k < A ? swh[k] : 0.f;
+      hk[j] = k < A ? swh[k] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -640,11 +650,13 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
     *reinterpret_cast<f32x4*>(dst + 4) = f32x4{pre[4] + c[4] * invF, pre[5] + c[5] * invF, pre[6] + c[6] * invF, pre[7] + c[7] * invF};
   }
   __syncthreads();
-  for (int ul = tid; ul < 512; ul += 256) {
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int ul = tid + 256 * jj;
     const int uu = u0 + ul;
     if (uu >= H) break;
     const size_t o = (size_t)b * H + uu;
-    const float cprev = p.c_prev ? p.c_prev[o] : 0.f;
+    const float cprev = cpre[jj];
     float hv, a0, a1, a2, a3;
     if (p.gru) {
       const GruOut r = gru_point(spre[ul], spre[512 + ul], spre[1024 + ul], spre[1536 + ul], cprev);
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   // Uv / dUv of the thread's (f, k) cells); fast path: 4H <= 2048 (multiple of 8), <= 8 frames per chunk, A <= 256
   const bool fast = ((W4 & 7) == 0) && W4 <= 2048 && nf <= 8 && A <= 256 && nf <= 4 * G;
   Raw8<AT> pr[2][4];
-  float uvr[4], duvr[4];
+  float uvr[4], duvr[4], whk_pre = 0.f, wk_pre = 0.f;
   const int kk = (A <= 256) ? tid % A : 0, gi = (A <= 256) ? tid / A : 0;
   if (fast) {
 #pragma unroll
@@ -731,6 +743,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
         if (!p.first) duvr[q] = p.dUv[o];
       }
     }
+    if (gi < G) { whk_pre = p.Wh[(size_t)b * A + kk] + p.ab[kk]; wk_pre = p.w[kk]; }
   }
   for (int u = tid; u < H; u += 256) {
     const size_t o = (size_t)b * H + u;
@@ -783,8 +796,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   // (f, k) plane: thread -> k = tid % A, frame group gi = tid / A (A <= 256), else one thread per k
   if (fast) {
     if (gi < G) {
-      const float whk = p.Wh[(size_t)b * A + kk] + p.ab[kk];
-      const float wk = p.w[kk];
+      const float whk = whk_pre, wk = wk_pre;
       float dwh = 0.f, dw = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1128,8 +1140,13 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   // Ud[t, b, k] of this wave's time steps (t = wave, wave + 4, ...; lane -> k = lane, lane + 64), also issued up front:
   // the score loop below then has no load in it (A <= 128, T <= 32 fast path)
   const bool fastA = fastT && p.A <= 128;
-  float udr[8][2];
+  float udr[8][2], wk[2] = {0.f, 0.f}, bk[2] = {0.f, 0.f};
   if (fastA) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = lane + 64 * j;
+      wk[j] = k < p.A ? p.w[k] : 0.f; bk[j] = k < p.A ? p.ab[k] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int t = wave + 4 * i;
@@ -1147,11 +1164,11 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   }
   __syncthreads();
   if (fastA) {
-    float wk[2], bk[2], hk[2];
+    float hk[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int k = lane + 64 * j;
-      wk[j] = k < p.A ? p.w[k] : 0.f; bk[j] = k < p.A ? p.ab[k] : 0.f; hk[j] = k < p.A ? swh[k] : 0.f;
+      hk[j] = k < p.A ? swh[k] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1231,7 +1248,7 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   // one memory latency per phase (hidden-state rows of the wave's dot products, the chunk's old dHs values, Ud / dUd of
   // the thread's (t', k) cells)
   const bool fast = T <= 32 && H <= 512 && A <= 128;
-  float hsr[2][8], dhv[2][8], udv[4], dudv[4];
+  float hsr[2][8], dhv[2][8], udv[4], dudv[4], whk_pre = 0.f, wk_pre = 0.f;
   const int kk = tid % A, gi = tid / A;
   if (fast) {
 #pragma unroll
@@ -1260,6 +1277,7 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
         if (!p.first) dudv[q] = p.dUd[o];
       }
     }
+    if (gi < G) { whk_pre = p.Whr[(size_t)b * A + kk] + p.ab[kk]; wk_pre = p.w[kk]; }
   }
   for (int j = tid; j < H; j += 256)
     sdx[j] = sum_strided(p.slab + (size_t)b * W2 + j, zs, p.S) * drop_at(p.dd, key, p.s, b, H, j);
@@ -1289,8 +1307,7 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
     }
     __syncthreads();
     if (gi < G) {
-      const float whk = p.Whr[(size_t)b * A + kk] + p.ab[kk];
-      const float wk = p.w[kk];
+      const float whk = whk_pre, wk = wk_pre;
       float dwh = 0.f, dw = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
