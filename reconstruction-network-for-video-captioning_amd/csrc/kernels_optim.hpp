@@ -1,0 +1,153 @@
+// RecNet gfx950 kernels: norms, clipping, multi-tensor Adam with fused weight re-pack.
+// Included through kernels.hpp.
+#pragma once
+// =============================================================================================
+// norms, clipping and multi-tensor Adam (train.py:69,103,129,149,186,270-273)
+// =============================================================================================
+struct TensorDesc { float* p; float* g; float* m; float* v; float* vmax; int n; int chunk0; int nchunks; int pad; };
+// Where the packed operand image(s) of a parameter tensor live: element (r, c) of a [rows][cols] tensor goes to
+// dst[r * ld + (c - c0)] for every destination whose column window [c0, c0 + nc) contains c.  The Adam kernel
+// writes them directly, so the weights are re-packed (bf16) in the same pass that updates them.
+// Rows: only source rows [r0, r0 + nr) are written, to destination row (r - r0) (dst is pre-offset) — the GRU's
+// 3-block weights land in the 4-block packed layout this way.
+// mode 1 (gate interleave, rec_step.hpp): r = gate * nr + u goes to destination row (u / 8) * 32 + gate * 8 + u % 8.
+struct PackDst { void* dst; int ld; int c0; int nc; int r0; int nr; int mode; int pad; };
+struct PackDesc { int ndst; int cols; PackDst d[6]; };
+#define RN_CHUNK 8192
+
+// partial[chunk] = sum over the chunk of p^2 (mode 0) or (g + coef * p / ||p||)^2 (mode 1)
+__global__ __launch_bounds__(256) void sumsq_chunk_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                          int mode, const float* __restrict__ pnorm, float coef,
+                                                          float* __restrict__ partial) {
+  __shared__ float sm[4];
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  float k = 0.f;
+  if (mode == 1) { const float nrm = pnorm[ch.x]; k = nrm > 0.f ? coef / nrm : 0.f; }
+  float s = 0.f;
+  // chunks start at multiples of RN_CHUNK elements of a 16-byte aligned tensor: float4 loads for the whole quads
+  const bool al = ((((uintptr_t)td.p) | ((uintptr_t)(mode ? td.g : td.p))) & 15) == 0;
+  int i0 = ch.y;
+  if (al) {
+    const int nq = (end - ch.y) >> 2;
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(td.p + ch.y);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>((mode ? td.g : td.p) + ch.y);
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      const f32x4 pv = p4[q];
+      f32x4 x = pv;
+      if (mode) { const f32x4 gv = g4[q]; x = gv + k * pv; }
+      s += x[0] * x[0]; s1 += x[1] * x[1]; s2 += x[2] * x[2]; s3 += x[3] * x[3];
+    }
+    s = (s + s1) + (s2 + s3);
+    i0 = ch.y + (nq << 2);
+  }
+  for (int i = i0 + threadIdx.x; i < end; i += 256) {
+    const float x = mode == 0 ? td.p[i] : td.g[i] + k * td.p[i];
+    s += x * x;
+  }
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// one block per tensor: out[tensor] = sqrt(sum of its chunk partials)   (deterministic order)
+__global__ __launch_bounds__(256) void tensor_norm_kernel(const TensorDesc* __restrict__ tab, const float* __restrict__ partial,
+                                                          float* __restrict__ out_norm) {
+  __shared__ float sm[4];
+  const TensorDesc td = tab[blockIdx.x];
+  float s = 0.f;
+  for (int c = threadIdx.x; c < td.nchunks; c += 256) s += partial[td.chunk0 + c];
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) out_norm[blockIdx.x] = sqrtf(s);
+}
+// total = sqrt(sum_i norms[i]^2), clip coefficient of torch.nn.utils.clip_grad_norm_; also sum of norms.
+__global__ void norm_finalize_kernel(const float* __restrict__ norms, int n, float max_norm, float* total_out,
+                                     float* clip_out, float* sum_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float ss = 0.f, sn = 0.f;
+  for (int i = 0; i < n; ++i) { ss += norms[i] * norms[i]; sn += norms[i]; }
+  const float tot = sqrtf(ss);
+  if (total_out) *total_out = tot;
+  if (sum_out) *sum_out = sn;
+  if (clip_out) {
+    float c = 1.f;
+    if (max_norm > 0.f) { c = max_norm / (tot + 1e-6f); if (c > 1.f) c = 1.f; }
+    *clip_out = c;
+  }
+}
+// g += coef * p / ||p||   (autograd-compatible path: the regulariser's gradient, train.py:69-70)
+__global__ __launch_bounds__(256) void add_reg_grad_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                           const float* __restrict__ pnorm, float coef) {
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  const float nrm = pnorm[ch.x];
+  const float k = nrm > 0.f ? coef / nrm : 0.f;
+  for (int i = ch.y + threadIdx.x; i < end; i += 256) td.g[i] += k * td.p[i];
+}
+
+// g *= *clip   (clip_grad_norm_ in place)
+__global__ __launch_bounds__(256) void scale_grads_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                          const float* __restrict__ clip) {
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  const float c = *clip;
+  if (c == 1.f) return;
+  for (int i = ch.y + threadIdx.x; i < end; i += 256) td.g[i] *= c;
+}
+
+struct AdamHyper { double lr, beta1, beta2; float eps, wd, one_m_b1, beta2f, one_m_b2; int amsgrad; float reg_coef; };
+// torch.optim.Adam (single-tensor form of torch 2.10): g' = clip * (g + reg) + wd * p ;
+// m <- lerp(m, g', 1-b1) ; v <- b2 v + (1-b2) g'^2 ; [vmax <- max(vmax, v)] ;
+// p <- p - (lr / bc1) * m / (sqrt(v̂) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
+                                                         AdamHyper hp, const float* __restrict__ pnorm,
+                                                         const float* __restrict__ clip, const int32_t* __restrict__ step_ptr,
+                                                         const PackDesc* __restrict__ pack, int lp) {
+  __shared__ float sc[2];
+  if (threadIdx.x == 0) {
+    const double st = (double)(*step_ptr);
+    const double bc1 = 1.0 - pow(hp.beta1, st);
+    const double bc2 = 1.0 - pow(hp.beta2, st);
+    sc[0] = (float)(hp.lr / bc1);
+    sc[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = sc[0], bc2s = sc[1];
+  const int2 ch = chunks[blockIdx.x];
+  const TensorDesc td = tab[ch.x];
+  const int end = min(td.n, ch.y + RN_CHUNK);
+  const float nrm = pnorm ? pnorm[ch.x] : 0.f;
+  const float k = (nrm > 0.f) ? hp.reg_coef / nrm : 0.f;
+  const float cl = clip ? *clip : 1.f;
+  PackDesc pk; pk.ndst = 0; pk.cols = 1;
+  if (pack) pk = pack[ch.x];
+  for (int i = ch.y + threadIdx.x; i < end; i += 256) {
+    const float p = td.p[i];
+    float g = (td.g[i] + k * p) * cl;
+    g = g + hp.wd * p;
+    float m = td.m[i];
+    m = m + hp.one_m_b1 * (g - m);
+    float v = td.v[i] * hp.beta2f + hp.one_m_b2 * g * g;
+    td.m[i] = m; td.v[i] = v;
+    float vh = v;
+    if (hp.amsgrad) { vh = fmaxf(td.vmax[i], v); td.vmax[i] = vh; }
+    const float denom = sqrtf(vh) / bc2s + hp.eps;
+    const float pn = p - step_size * (m / denom);
+    td.p[i] = pn;
+    if (pk.ndst) {
+      const int r = i / pk.cols, c = i - r * pk.cols;
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+        if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc &&
+            (pk.d[d].mode || (r >= pk.d[d].r0 && r < pk.d[d].r0 + pk.d[d].nr))) {
+          int dr = r - pk.d[d].r0;
+          if (pk.d[d].mode) { const int gate = r / pk.d[d].nr, u = r - gate * pk.d[d].nr; dr = (u >> 3) * 32 + gate * 8 + (u & 7); }
+          const size_t o = (size_t)dr * pk.d[d].ld + (c - pk.d[d].c0);
+          if (lp) reinterpret_cast<bf16_t*>(pk.d[d].dst)[o] = (bf16_t)pn; else reinterpret_cast<float*>(pk.d[d].dst)[o] = pn;
+        }
+    }
+  }
+}
+

@@ -1,0 +1,405 @@
+// RecNet gfx950 kernels: small utilities, reductions, packing, column sums, gate math (LSTM / GRU), embedding.
+// Included through kernels.hpp.
+#pragma once
+// =============================================================================================
+// small utilities
+// =============================================================================================
+__global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+__global__ void set_f32_kernel(float* p, float v) { *p = v; }
+// step counter += 1; seed slot = seed_base + step (graph-replay friendly train step)
+__global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t seed_base) {
+  int s = *step + 1; *step = s; *seed_slot = seed_base + (uint32_t)s;
+}
+
+// sum_{z<n} p[z*stride] over the split-K slabs.  All (<= 16) loads are issued back to back and reduced as a
+// tree: a dependent round trip to L2 / memory costs ~1-3 us in these low-occupancy chain kernels, so the
+// number of serialized load rounds, not bytes, sets their run time (PMC: SQ_WAIT_ANY ~75 % of wave cycles).
+__device__ __forceinline__ float sum_strided(const float* __restrict__ p, size_t stride, int n) {
+  if (n <= 16) {
+    float v[16];
+#pragma unroll
+    for (int z = 0; z < 16; ++z) {
+      const int zz = z < n ? z : n - 1;                 // clamped: branch-free, the duplicates hit L1
+      v[z] = p[(size_t)zz * stride];
+    }
+#pragma unroll
+    for (int z = 0; z < 16; ++z) v[z] = z < n ? v[z] : 0.f;
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+      for (int z = 0; z < w; ++z) v[z] += v[z + w];
+    return v[0];
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int z = 0;
+  for (; z + 4 <= n; z += 4) {
+    const float a = p[(size_t)z * stride], b = p[(size_t)(z + 1) * stride], c = p[(size_t)(z + 2) * stride], d = p[(size_t)(z + 3) * stride];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; z < n; ++z) s0 += p[(size_t)z * stride];
+  return (s0 + s1) + (s2 + s3);
+}
+// 8 consecutive operand elements as floats (16-byte aligned for bf16, 32-byte for float)
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+template <typename AT> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void zero() { for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f; }
+  __device__ __forceinline__ float at(int j) const { return (float)v[j]; }
+};
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+  __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+  __device__ __forceinline__ float at(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
+
+// out[c] += sum_r X[r*ld + c], 16-byte loads: a wave covers 512 columns of one row per instruction, the four waves of a
+// workgroup take rows r0 + w, r0 + w + 4, ...; grid (ceil(cols / 512), row splits); `out` pre-zeroed (float atomics,
+// one per column per workgroup).  Needs ld % 8 == 0 and a 16-byte aligned base (true for every operand buffer).
+template <typename ST>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const ST* __restrict__ X, int rows, int cols, int ld,
+                                                         float* __restrict__ out) {
+  __shared__ float sm[4][64][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 512 + lane * 8;
+  const int rs = gridDim.y, per = (rows + rs - 1) / rs;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c0 < cols) {
+    int r = r0 + wave;
+    for (; r + 4 < r1; r += 8) {          // two rows in flight
+      Raw8<ST> a, b;
+      a.load(X + (size_t)r * ld + c0); b.load(X + (size_t)(r + 4) * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += a.at(j) + b.at(j);
+    }
+    for (; r < r1; r += 4) {
+      Raw8<ST> a; a.load(X + (size_t)r * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += a.at(j);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sm[wave][lane][j] = acc[j];
+  __syncthreads();
+  if (wave == 0 && c0 < cols) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = sm[0][lane][j] + sm[1][lane][j] + sm[2][lane][j] + sm[3][lane][j];
+      if (c0 + j < cols) atomicAdd(out + c0 + j, v);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t drop_key(const DropDesc& dd) { return rn_site_key(*dd.seed, dd.site); }
+__device__ __forceinline__ float drop_at(const DropDesc& dd, uint32_t key, int t, int b, int N, int j) {
+  const uint32_t idx = ((uint32_t)t * (uint32_t)dd.Bg + (uint32_t)(dd.boff + b)) * (uint32_t)N + (uint32_t)j;
+  return rn_drop_scale(key, dd.thr, dd.inv_keep, idx);
+}
+
+// out[i] = scale * sum_j x[j]   (single block; deterministic order)
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float* out, float scale) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) *out = s * scale;
+}
+
+// out[c] (+)= sum_r X[r*ld + c].  grid (ceil(cols/64), RS); with RS > 1 `out` must be pre-zeroed (atomics).
+template <typename ST>
+__global__ __launch_bounds__(256) void colsum_kernel(const ST* __restrict__ X, int rows, int cols, int ld,
+                                                     float* __restrict__ out, int use_atomic) {
+  __shared__ float sm[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int rs = gridDim.y, per = (rows + rs - 1) / rs;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + rg; r < r1; r += 4) s += (float)X[(size_t)r * ld + c];
+  sm[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (use_atomic) atomicAdd(out + c, s); else out[c] = s;
+  }
+}
+
+// out[i] = a[i] + b[i]  (biases b_ih + b_hh)
+__global__ void add2_kernel(const float* a, const float* b, float* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+template <typename T>
+__global__ void scale_kernel(T* x, size_t n, float s) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] = (T)((float)x[i] * s);
+}
+// operand copy: dst[r][c] = (AT)(scale * src[r*ld_src + c]) for c < cols, 0 for cols <= c < ld_dst (the zero
+// padding the DMA-staged GEMM relies on).  Used for enc, the packed weight images and dout.
+template <typename AT>
+__global__ void pack_block_kernel(AT* __restrict__ dst, int ld_dst, const float* __restrict__ src, int ld_src, int rows,
+                                  int cols, float scale) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    dst[i] = (AT)(c < cols ? scale * src[(size_t)r * ld_src + c] : 0.f);
+  }
+}
+// dst[r] = [src1[r, 0:c1) | src2[r, 0:c2) | 0 ...] with leading dimension ld_dst  (concatenated weight image)
+template <typename DT>
+__global__ void pack2_kernel(DT* __restrict__ dst, int ld_dst, const float* __restrict__ src1, int ld1, int c1,
+                             const float* __restrict__ src2, int ld2, int c2, int rows) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    float v = 0.f;
+    if (c < c1) v = src1[(size_t)r * ld1 + c];
+    else if (c < c1 + c2) v = src2[(size_t)r * ld2 + (c - c1)];
+    dst[i] = (DT)v;
+  }
+}
+// Recurrent weights into the 4-block gate layout: packed row (q * Hd + u) takes master row (map[q] * Hd + u) of
+// src1 (columns [0,c1)) and of src2 (columns [c1, c1+c2)), zeros where map[q] < 0 and in the padding.
+// LSTM: map = {0,1,2,3}.  GRU: W_ih map {0,1,2,-1}, W_hh map {0,1,-1,2}  (see gru_point).
+struct GateMap { int m[4]; };
+template <typename DT>
+__global__ void pack_gates_kernel(DT* __restrict__ dst, int ld_dst, int Hd, const float* __restrict__ src1, int ld1, int c1,
+                                  GateMap map1, const float* __restrict__ src2, int ld2, int c2, GateMap map2) {
+  const size_t total = (size_t)4 * Hd * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst), q = r / Hd, u = r - q * Hd;
+    float v = 0.f;
+    if (c < c1) { if (map1.m[q] >= 0) v = src1[(size_t)(map1.m[q] * Hd + u) * ld1 + c]; }
+    else if (c < c1 + c2) { if (map2.m[q] >= 0) v = src2[(size_t)(map2.m[q] * Hd + u) * ld2 + (c - c1)]; }
+    dst[i] = (DT)v;
+  }
+}
+// dst[c][r] = src[r][c]  (32 x 32 tiles through LDS): the K-contiguous image of a weight that a backward chain GEMM
+// uses as its "col" operand, so that it can load fragments straight into MFMA registers (gemm_chain.hpp)
+template <typename AT>
+__global__ __launch_bounds__(256) void transpose_at_kernel(const AT* __restrict__ src, int ld_src, int rows, int cols,
+                                                           AT* __restrict__ dst, int ld_dst) {
+  __shared__ AT tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : (AT)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;                 // dst row = source column; pad columns [rows, ld_dst) get zeros
+    if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+  }
+}
+// gate-interleaved image of a [4 Hd][cols] recurrent weight (rec_step.hpp): destination row (u/8)*32 + gate*8 + u%8
+template <typename DT>
+__global__ void pack_interleave_kernel(DT* __restrict__ dst, int ld_dst, int Hd, const float* __restrict__ src, int ld_src, int cols) {
+  const size_t total = (size_t)4 * Hd * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    const int j = d >> 5, gate = (d >> 3) & 3, ul = d & 7;
+    dst[i] = (DT)(c < cols ? src[(size_t)(gate * Hd + j * 8 + ul) * ld_src + c] : 0.f);
+  }
+}
+// dst[r][c] = sum_j src[r*ld_src + j*cols + c]  (sum of NCH side-by-side partial blocks), zero padded to ld_dst
+template <typename AT>
+__global__ void sum_chunks_kernel(AT* __restrict__ dst, int ld_dst, const AT* __restrict__ src, int ld_src, int rows,
+                                  int cols, int nch) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i % ld_dst);
+    float v = 0.f;
+    if (c < cols) for (int j = 0; j < nch; ++j) v += (float)src[(size_t)r * ld_src + j * cols + c];
+    dst[i] = (AT)v;
+  }
+}
+__global__ void copy_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = x[i];
+}
+
+// =============================================================================================
+// LSTM gate math (torch.nn.LSTM order i, f, g, o)
+// =============================================================================================
+struct LstmOut { float i, f, g, o, c, h; };
+__device__ __forceinline__ LstmOut lstm_point(float gi, float gf, float gg, float go, float c_prev) {
+  LstmOut r;
+  r.i = rn_sigmoid(gi);
+  r.f = rn_sigmoid(gf);
+  r.g = rn_tanh(gg);
+  r.o = rn_sigmoid(go);
+  r.c = r.f * c_prev + r.i * r.g;
+  r.h = r.o * rn_tanh(r.c);
+  return r;
+}
+struct LstmGrad { float di, df, dg, d_o, dc_prev; };
+__device__ __forceinline__ LstmGrad lstm_point_bwd(float dh, float dc_in, float i, float f, float g, float o,
+                                                   float c, float c_prev) {
+  const float tc = rn_tanh(c);
+  const float dc = dc_in + dh * o * (1.f - tc * tc);
+  LstmGrad r;
+  r.d_o = dh * tc * o * (1.f - o);
+  r.di = dc * g * i * (1.f - i);
+  r.df = dc * c_prev * f * (1.f - f);
+  r.dg = dc * i * (1.f - g * g);
+  r.dc_prev = dc * f;
+  return r;
+}
+
+// =============================================================================================
+// GRU gate math (torch.nn.GRU order r, z, n) in the library's 4-block gate layout
+//   block 0 = r, block 1 = z (input + hidden parts summed), block 2 = W_in x + b_in, block 3 = W_hn h + b_hn :
+// the packed weights hold W_ih as blocks (r, z, n, 0) and W_hh as blocks (r, z, 0, n), so every GEMM, slab and
+// gate-gradient row of the LSTM path is reused as is and only this pointwise part differs.
+//   n = tanh(g2 + r * g3) ; h = (1 - z) n + z h_prev.  Saved activations: (r, z, n, g3).
+// =============================================================================================
+struct GruOut { float r, z, n, hn, h; };
+__device__ __forceinline__ GruOut gru_point(float g0, float g1, float g2, float g3, float h_prev) {
+  GruOut o;
+  o.r = rn_sigmoid(g0);
+  o.z = rn_sigmoid(g1);
+  o.hn = g3;
+  o.n = rn_tanh(g2 + o.r * g3);
+  o.h = (1.f - o.z) * o.n + o.z * h_prev;
+  return o;
+}
+// returns the gate-block gradients in (di, df, dg, d_o) = (d g0, d g1, d g2, d g3) and dc_prev = the direct part
+// of d h_prev (dh * z); the part through W_hh comes from the next GEMM like the LSTM's.
+__device__ __forceinline__ LstmGrad gru_point_bwd(float dh, float r, float z, float n, float hn, float h_prev) {
+  LstmGrad g;
+  const float dn = dh * (1.f - z) * (1.f - n * n);
+  g.dg = dn;
+  g.d_o = dn * r;
+  g.di = dn * hn * r * (1.f - r);
+  g.df = dh * (h_prev - n) * z * (1.f - z);
+  g.dc_prev = dh * z;
+  return g;
+}
+// bias of the 4-block gate layout: LSTM b_ih + b_hh ; GRU (b_ir + b_hr, b_iz + b_hz, b_in, b_hn)
+__global__ void gate_bias_kernel(const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ out,
+                                 int Hd, int gru) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * Hd) return;
+  if (!gru) { out[i] = bih[i] + bhh[i]; return; }
+  const int blk = i / Hd;
+  out[i] = blk < 2 ? bih[i] + bhh[i] : (blk == 2 ? bih[i] : bhh[i - Hd]);
+}
+// zeroes up to 8 buffers in one launch (the targets of the step's atomic column sums / scatter-add)
+struct ZeroList { float* p[8]; size_t n[8]; int cnt; };
+__global__ __launch_bounds__(256) void zero_list_kernel(const ZeroList z) {
+  for (int k = 0; k < z.cnt; ++k) {
+    float* p = z.p[k];
+    const size_t n = z.n[k];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+  }
+}
+// gradients of the two bias vectors from the column sums of the 4-block gate gradients
+__global__ void gate_bias_grad_kernel(const float* __restrict__ sum4, float* __restrict__ dbih, float* __restrict__ dbhh,
+                                      int Hd, int gru) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * Hd) return;
+  if (!gru) { dbih[i] = sum4[i]; dbhh[i] = sum4[i]; return; }
+  const int blk = i / Hd;
+  if (blk < 2) { dbih[i] = sum4[i]; dbhh[i] = sum4[i]; }
+  else if (blk == 2) dbih[i] = sum4[i];
+  else dbhh[i - Hd] = sum4[i];
+}
+
+// =============================================================================================
+// embedding  (decoder.py:46-48)
+// =============================================================================================
+// emb[row, :] = scale * Emb[token(row), :] * dropmask ; row = (t - t0) * B + b
+template <typename AT>
+__global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict__ Emb, const int64_t* __restrict__ targets,
+                                                        const int64_t* __restrict__ tokens, AT* __restrict__ emb, int ld,
+                                                        int B, int E, int V, float scale, DropDesc dd, int t0) {
+  const int row = blockIdx.x, t = t0 + row / B, b = row % B;
+  long tok = tokens ? tokens[b] : (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
+  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+  const uint32_t key = drop_key(dd);
+  const float* src = Emb + (size_t)tok * E;
+  AT* dst = emb + (size_t)row * ld;
+  for (int j = threadIdx.x; j < ld; j += 128) dst[j] = (AT)(j < E ? src[j] * scale * drop_at(dd, key, t, b, E, j) : 0.f);
+}
+// input token of decoder step t for caption b: the tokens that were actually fed when a free-running forward recorded
+// them (in_tok [T][B], train.py:47-51), else teacher forcing: <SOS> at t = 0, targets[t-1] after (train.py:25,45)
+__device__ __forceinline__ long rn_input_token(const int64_t* __restrict__ in_tok, const int64_t* __restrict__ targets, int t, int b,
+                                               int B, int V) {
+  long tok = in_tok ? in_tok[(size_t)t * B + b] : (t == 0 ? 1 : targets[(size_t)(t - 1) * B + b]);
+  return tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+}
+// dEmb[token(row), :] += scale * dropmask * demb[row, :]   (dEmb pre-zeroed)
+__global__ __launch_bounds__(128) void embed_bwd_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
+                                                        const float* __restrict__ demb, int B, int E, int V,
+                                                        float scale, DropDesc dd, int row0, const int64_t* __restrict__ in_tok) {
+  const int row = row0 + blockIdx.x, t = row / B, b = row % B;
+  const long tok = rn_input_token(in_tok, targets, t, b, B, V);
+  if (tok < 3) return;        // <PAD> / <SOS> / <EOS> rows are summed by embed_bwd_hot_kernel (a third of all rows hit them)
+  const uint32_t key = drop_key(dd);
+  const float* src = demb + (size_t)row * E;
+  float* dst = dEmb + (size_t)tok * E;
+  for (int j = threadIdx.x; j < E; j += 128) {
+    const float m = drop_at(dd, key, t, b, E, j);
+    if (m != 0.f) atomicAdd(dst + j, src[j] * scale * m);
+  }
+}
+
+// The three special tokens feed ~40 % of all (t, b) positions (every position after a caption's <EOS> is <PAD>, step 0
+// is <SOS>): through the generic kernel that is >1000 atomics on each of the same E addresses.  Here a block (column
+// chunk, 32-row slice) sums the matching rows of its slice in registers and issues one atomic per token and column.
+#define RN_HOT_ROWS 32
+__global__ __launch_bounds__(128) void embed_bwd_hot_kernel(float* __restrict__ dEmb, const int64_t* __restrict__ targets,
+                                                            const float* __restrict__ demb, int B, int E, int V,
+                                                            float scale, DropDesc dd, int row0, int nrow,
+                                                            const int64_t* __restrict__ in_tok) {
+  __shared__ int stok[RN_HOT_ROWS];
+  const int j = blockIdx.x * 128 + threadIdx.x, i0 = blockIdx.y * RN_HOT_ROWS;
+  if (threadIdx.x < RN_HOT_ROWS) {   // tokens of this block's rows (so the row loop below has no dependent global load)
+    const int i = i0 + threadIdx.x;
+    int tk = -1;
+    if (i < nrow) {
+      const int row = row0 + i, t = row / B, b = row - t * B;
+      tk = (int)rn_input_token(in_tok, targets, t, b, B, V);
+    }
+    stok[threadIdx.x] = tk;
+  }
+  __syncthreads();
+  if (j >= E) return;
+  const uint32_t key = drop_key(dd);
+  float acc[3] = {0.f, 0.f, 0.f};
+  // branch-free in groups of 8 rows: the 8 loads are in flight together (rows of other tokens are read and discarded)
+#pragma unroll
+  for (int g = 0; g < RN_HOT_ROWS; g += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = i0 + g + q;
+      v[q] = (i < nrow && stok[g + q] >= 0 && stok[g + q] <= 2) ? demb[(size_t)(row0 + i) * E + j] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int tk = stok[g + q];
+      if (tk < 0 || tk > 2) continue;
+      const int row = row0 + i0 + g + q, t = row / B, b = row - t * B;
+      const float x = v[q] * scale * drop_at(dd, key, t, b, E, j);
+      acc[0] += tk == 0 ? x : 0.f; acc[1] += tk == 1 ? x : 0.f; acc[2] += tk == 2 ? x : 0.f;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (acc[q] != 0.f) atomicAdd(dEmb + (size_t)q * E + j, acc[q]);
+}
+
