@@ -83,7 +83,11 @@ _lib = None
 
 
 class RecNetLibraryError(RuntimeError):
-    pass
+    """librecnet_hip.so is missing, stale or does not match include/recnet_hip.h."""
+
+
+class RecNetError(RuntimeError):
+    """A library call returned a non-zero code; the message is recnet_last_error()'s."""
 
 
 def load():
@@ -112,7 +116,7 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().recnet_last_error()
-        raise RuntimeError("%s failed (code %d): %s" % (what or "recnet call", rc, (msg or b"").decode()))
+        raise RecNetError("%s failed (code %d): %s" % (what or "recnet call", rc, (msg or b"").decode()))
 
 OPT_REG, OPT_CLIP, OPT_SKIP_DECODER, OPT_SKIP_RECONSTRUCTOR = 1, 2, 4, 8
 EXPORTS["recnet_clip_grad_norm"] = (_i, [C.c_void_p, _i, _f, C.c_void_p, C.c_void_p])

@@ -222,6 +222,9 @@ class Engine:
         d = self.dims
         B = d["B"]
         _chk_tensor(tokens, (B,), torch.int64, "tokens")
+        for nm, st in (("h", h_in), ("c", c_in)):
+            if st is not None:
+                _chk_tensor(st, (B, d["H"]), torch.float32, "hidden state " + nm)
         if enc is not None:
             _chk_tensor(enc, (B, d["F"], d["D"]), torch.float32, "encoder_outputs")
         logits = torch.empty(B, d["V"], dtype=torch.float32, device=self.device)
@@ -272,14 +275,17 @@ class Engine:
 
     def backward_reconstructor(self, enc, grad_scale=1.0, want_dhiddens=True):
         d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
         dh = torch.empty(self.T, 1, d["B"], d["H"], dtype=torch.float32, device=self.device) if want_dhiddens else None
         _lib.check(self.lib.recnet_backward_reconstructor(self.handle, _ptr(enc), float(grad_scale), _ptr(dh),
                                                           _stream()), "recnet_backward_reconstructor")
         return dh
 
     def backward_decoder(self, enc, targets, dhiddens=None, grad_scale=1.0):
+        d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
+        _chk_tensor(targets, (self.hyper["caption_max_len"] + 1, d["B"]), torch.int64, "targets")
         if dhiddens is not None:
-            d = self.dims
             _chk_tensor(dhiddens, (self.T, 1, d["B"], d["H"]), torch.float32, "dhiddens")
         _lib.check(self.lib.recnet_backward_decoder(self.handle, _ptr(enc), _ptr(targets), _ptr(dhiddens),
                                                     float(grad_scale), _stream()), "recnet_backward_decoder")
@@ -298,13 +304,22 @@ class Engine:
         _lib.check(self.lib.recnet_optimizer_step(self.handle, int(step), int(flags), _ptr(self.scalars), _stream()),
                    "recnet_optimizer_step")
 
+    def _chk_step(self, enc, targets, T, step_weight):
+        """The raw pointers go straight to the device: shapes, dtypes and residency are checked here."""
+        d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
+        _chk_tensor(targets, (self.hyper["caption_max_len"] + 1, d["B"]), torch.int64, "targets")
+        _chk_tensor(step_weight, (int(T),), torch.float32, "step_weight")
+
     def train_step_fwd_bwd(self, enc, targets, T, step_weight, seed):
+        self._chk_step(enc, targets, T, step_weight)
         _lib.check(self.lib.recnet_train_step_fwd_bwd(self.handle, _ptr(enc), _ptr(targets), int(T),
                                                       _ptr(step_weight), seed & 0xFFFFFFFF, _ptr(self.scalars),
                                                       _stream()), "recnet_train_step_fwd_bwd")
         self.T = T
 
     def train_step(self, enc, targets, T, step_weight, seed, step):
+        self._chk_step(enc, targets, T, step_weight)
         _lib.check(self.lib.recnet_train_step(self.handle, _ptr(enc), _ptr(targets), int(T), _ptr(step_weight),
                                               seed & 0xFFFFFFFF, int(step), _ptr(self.scalars), _stream()),
                    "recnet_train_step")
@@ -315,6 +330,7 @@ class Engine:
         _lib.check(self.lib.recnet_set_step(self.handle, int(step), _stream()), "recnet_set_step")
 
     def train_step_fwd_bwd_dev(self, enc, targets, T, step_weight, seed_base):
+        self._chk_step(enc, targets, T, step_weight)
         _lib.check(self.lib.recnet_train_step_fwd_bwd_dev(self.handle, _ptr(enc), _ptr(targets), int(T),
                                                           _ptr(step_weight), seed_base & 0xFFFFFFFF,
                                                           _ptr(self.scalars), _stream()),
@@ -323,12 +339,14 @@ class Engine:
 
     def train_step_dev(self, enc, targets, T, step_weight, seed_base, flags):
         """Fused forward + backward + optimiser, step count / seed on the device (graph replay, single rank)."""
+        self._chk_step(enc, targets, T, step_weight)
         _lib.check(self.lib.recnet_train_step_dev(self.handle, _ptr(enc), _ptr(targets), int(T), _ptr(step_weight),
                                                   seed_base & 0xFFFFFFFF, int(flags), _ptr(self.scalars), _stream()),
                    "recnet_train_step_dev")
         self.T = T
 
     def train_step_part_dev(self, part, enc, targets, T, step_weight, seed_base):
+        self._chk_step(enc, targets, T, step_weight)
         _lib.check(self.lib.recnet_train_step_part_dev(self.handle, int(part), _ptr(enc), _ptr(targets), int(T),
                                                        _ptr(step_weight), seed_base & 0xFFFFFFFF, _ptr(self.scalars),
                                                        _stream()), "recnet_train_step_part_dev")
