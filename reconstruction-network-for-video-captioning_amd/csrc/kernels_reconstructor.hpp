@@ -52,6 +52,65 @@ __global__ __launch_bounds__(256) void lstm_pw_kernel(const LstmPwArgs p) {
   a[0] = a0; a[Hd] = a1; a[2 * Hd] = a2; a[3 * Hd] = a3;
 }
 
+// 4-wide form: a thread owns 4 consecutive hidden units, every slab / input / state access is a 16-byte load or store
+// and exactly S slab loads per gate are issued (the scalar form reads one float at a time and pads its slab loop to 16
+// loads).  Requires Hd, the leading dimensions and the column offsets to be multiples of 4 and 16-byte aligned bases.
+template <typename AT> struct AT4;
+template <> struct AT4<float> { typedef f32x4 type; static __device__ __forceinline__ type cvt(f32x4 v) { return v; } };
+template <> struct AT4<bf16_t> {
+  typedef bf16x4 type;
+  static __device__ __forceinline__ type cvt(f32x4 v) { type r; r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3]; return r; }
+};
+template <typename AT>
+__global__ __launch_bounds__(256) void lstm_pw_vec_kernel(const LstmPwArgs p) {
+  const int Hq = p.Hd >> 2, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * Hq) return;
+  const int b = i / Hq, u = (i - b * Hq) << 2, Hd = p.Hd;
+  f32x4 g[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = q * Hd + u;
+    f32x4 v = p.X ? *reinterpret_cast<const f32x4*>(p.X + (size_t)b * p.x_ld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.b1) v += *reinterpret_cast<const f32x4*>(p.b1 + col);
+    if (p.b2) v += *reinterpret_cast<const f32x4*>(p.b2 + col);
+    g[q] = v;
+  }
+  const f32x4 cp = p.c_prev ? *reinterpret_cast<const f32x4*>(p.c_prev + (size_t)b * Hd + u) : f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* sp = p.slab + (size_t)b * p.slab_ld + u;
+#pragma unroll 4
+    for (int z = 0; z < p.S; ++z) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q] += *reinterpret_cast<const f32x4*>(sp + (size_t)z * p.slab_stride + q * Hd);
+    }
+  }
+  f32x4 hv, a0, a1, a2, a3, cv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (p.gru) {
+      const GruOut r = gru_point(g[0][j], g[1][j], g[2][j], g[3][j], cp[j]);
+      hv[j] = r.h; a0[j] = r.r; a1[j] = r.z; a2[j] = r.n; a3[j] = r.hn; cv[j] = 0.f;
+    } else {
+      const LstmOut r = lstm_point(g[0][j], g[1][j], g[2][j], g[3][j], cp[j]);
+      hv[j] = r.h; a0[j] = r.i; a1[j] = r.f; a2[j] = r.g; a3[j] = r.o; cv[j] = r.c;
+    }
+  }
+  if (!p.gru) *reinterpret_cast<f32x4*>(p.c_out + (size_t)b * Hd + u) = cv;
+  *reinterpret_cast<f32x4*>(p.h_out + (size_t)b * p.h_ld + u) = hv;
+  typedef typename AT4<AT>::type at4;
+  if (p.h_lp) {
+    AT* d = reinterpret_cast<AT*>(p.h_lp) + (size_t)b * p.hlp_ld;
+    *reinterpret_cast<at4*>(d + u) = AT4<AT>::cvt(hv);
+    if (u < p.hlp_ld - p.hlp_pad_from) {          // pad columns [Hd, hlp_ld): fewer than 8, zeroed by the first threads
+      for (int j = 0; j < 4; ++j) if (p.hlp_pad_from + u + j < p.hlp_ld) d[p.hlp_pad_from + u + j] = (AT)0.f;
+    }
+  }
+  if (p.h_lp2) *reinterpret_cast<at4*>(reinterpret_cast<AT*>(p.h_lp2) + (size_t)b * p.hlp2_ld + u) = AT4<AT>::cvt(hv);
+  float* a = p.acts + (size_t)b * 4 * Hd + u;
+  *reinterpret_cast<f32x4*>(a) = a0; *reinterpret_cast<f32x4*>(a + Hd) = a1;
+  *reinterpret_cast<f32x4*>(a + 2 * Hd) = a2; *reinterpret_cast<f32x4*>(a + 3 * Hd) = a3;
+}
+
 struct LstmBwdArgs {
   int B, Hd, S;
   int gru;
@@ -79,6 +138,43 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs p) {
   dg[u] = (AT)g.di; dg[Hd + u] = (AT)g.df; dg[2 * Hd + u] = (AT)g.dg; dg[3 * Hd + u] = (AT)g.d_o;
   if (u < p.ld_dg - 4 * Hd) dg[4 * Hd + u] = (AT)0.f;
   p.dc_carry[o] = g.dc_prev;
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void lstm_bwd_vec_kernel(const LstmBwdArgs p) {
+  const int Hq = p.Hd >> 2, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * Hq) return;
+  const int b = i / Hq, u = (i - b * Hq) << 2, Hd = p.Hd;
+  const size_t o = (size_t)b * Hd + u;
+  f32x4 dh = p.dh_direct ? p.dh_scale * *reinterpret_cast<const f32x4*>(p.dh_direct + (size_t)b * p.dhd_ld + u) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* a = p.acts + (size_t)b * 4 * Hd + u;
+  const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + Hd),
+              a2 = *reinterpret_cast<const f32x4*>(a + 2 * Hd), a3 = *reinterpret_cast<const f32x4*>(a + 3 * Hd);
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 carry = p.first ? zero : *reinterpret_cast<const f32x4*>(p.dc_carry + o);
+  const f32x4 cpv = p.c_prev ? *reinterpret_cast<const f32x4*>(p.c_prev + o) : zero;
+  const f32x4 cc = p.gru ? zero : *reinterpret_cast<const f32x4*>(p.c + o);
+  {
+    const float* sp = p.slab + (size_t)b * p.slab_ld + p.slab_col0 + u;
+#pragma unroll 8
+    for (int z = 0; z < p.S; ++z) dh += *reinterpret_cast<const f32x4*>(sp + (size_t)z * p.slab_stride);
+    const float* s2 = p.slab2 + (size_t)b * Hd + u;
+#pragma unroll 8
+    for (int z = 0; z < p.S2; ++z) dh += *reinterpret_cast<const f32x4*>(s2 + (size_t)z * p.slab2_stride);
+  }
+  f32x4 di, df, dg, d_o, dcp;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const LstmGrad g = p.gru ? gru_point_bwd(dh[j] + carry[j], a0[j], a1[j], a2[j], a3[j], cpv[j])
+                             : lstm_point_bwd(dh[j], carry[j], a0[j], a1[j], a2[j], a3[j], cc[j], cpv[j]);
+    di[j] = g.di; df[j] = g.df; dg[j] = g.dg; d_o[j] = g.d_o; dcp[j] = g.dc_prev;
+  }
+  typedef typename AT4<AT>::type at4;
+  AT* d = reinterpret_cast<AT*>(p.dG) + (size_t)b * p.ld_dg;
+  *reinterpret_cast<at4*>(d + u) = AT4<AT>::cvt(di); *reinterpret_cast<at4*>(d + Hd + u) = AT4<AT>::cvt(df);
+  *reinterpret_cast<at4*>(d + 2 * Hd + u) = AT4<AT>::cvt(dg); *reinterpret_cast<at4*>(d + 3 * Hd + u) = AT4<AT>::cvt(d_o);
+  if (u < p.ld_dg - 4 * Hd) for (int j = 0; j < 4; ++j) if (4 * Hd + u + j < p.ld_dg) d[4 * Hd + u + j] = (AT)0.f;
+  *reinterpret_cast<f32x4*>(p.dc_carry + o) = dcp;
 }
 
 // =============================================================================================
