@@ -159,23 +159,27 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
   const int u = u0 + lane * 8;
   const bool live = u < H;                    // H % 8 == 0: a lane's 8 units are all inside or all outside
   const int col = g * H + u;
+  // ---- every global load of the kernel is ISSUED here, before the first use of any loaded value: the kernel is one
+  // link of a dependent chain at ~1 workgroup per CU, so each "load, wait, use, load" costs a full memory round trip
+  // (the compiler keeps program order between a use and the loads that follow it; sched_barrier pins the block)
   Raw8<AT> pv[32];
-  float pre[8];
+  f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0, sl[4][2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) pre[j] = 0.f;
+  for (int z = 0; z < 4; ++z) { sl[z][0] = x0; sl[z][1] = x0; }
+  const int S4 = p.slab ? (p.S < 4 ? p.S : 4) : 0;
   if (live) {
     const AT* pp = reinterpret_cast<const AT*>(p.P) + (size_t)b * F * p.ldp + col;
 #pragma unroll
     for (int f = 0; f < 32; ++f) { if (f < F) pv[f].load(pp + (size_t)f * p.ldp); else pv[f].zero(); }
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(p.Xe + (size_t)b * W4 + col);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(p.Xe + (size_t)b * W4 + col + 4);
-    pre[0] = x0[0]; pre[1] = x0[1]; pre[2] = x0[2]; pre[3] = x0[3]; pre[4] = x1[0]; pre[5] = x1[1]; pre[6] = x1[2]; pre[7] = x1[3];
-    if (p.slab) {
-      for (int z = 0; z < p.S; ++z) {
-        const float* sp = p.slab + z * zs + (size_t)b * WS + col;
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-        pre[0] += s0[0]; pre[1] += s0[1]; pre[2] += s0[2]; pre[3] += s0[3];
-        pre[4] += s1[0]; pre[5] += s1[1]; pre[6] += s1[2]; pre[7] += s1[3];
+    x0 = *reinterpret_cast<const f32x4*>(p.Xe + (size_t)b * W4 + col);
+    x1 = *reinterpret_cast<const f32x4*>(p.Xe + (size_t)b * W4 + col + 4);
+    if (S4) {
+      const float* sp0 = p.slab + (size_t)b * WS + col;
+#pragma unroll
+      for (int z = 0; z < 4; ++z) {
+        const int zz = z < S4 ? z : S4 - 1;          // clamped duplicates instead of a branch
+        sl[z][0] = *reinterpret_cast<const f32x4*>(sp0 + (size_t)zz * zs);
+        sl[z][1] = *reinterpret_cast<const f32x4*>(sp0 + (size_t)zz * zs + 4);
       }
     }
   }
@@ -190,9 +194,8 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
       uvr[i][j] = (f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
     }
   }
-  // the rest of what the later phases read from memory (attention vectors, c_{t-1} of the pointwise phase): requested
-  // now, so that no phase after a barrier starts with a memory round trip
-  float wk[2], bk[2], cpre[2];
+  // attention vectors, c_{t-1} of the pointwise phase, and this thread's column of the attention pre-activation W h
+  float wk[2], bk[2], cpre[2], whv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int k = lane + 64 * j;
@@ -200,8 +203,38 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
     const int uu = u0 + tid + 256 * j;
     cpre[j] = (p.c_prev && uu < H) ? p.c_prev[(size_t)b * H + uu] : 0.f;
   }
+  if (S4 && tid < A) {
+#pragma unroll
+    for (int z = 0; z < 4; ++z) whv[z] = p.slab[(size_t)(z < S4 ? z : S4 - 1) * zs + (size_t)b * WS + W4 + tid];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- uses
+  float pre[8];
+  pre[0] = x0[0]; pre[1] = x0[1]; pre[2] = x0[2]; pre[3] = x0[3]; pre[4] = x1[0]; pre[5] = x1[1]; pre[6] = x1[2]; pre[7] = x1[3];
+#pragma unroll
+  for (int z = 0; z < 4; ++z)
+    if (z < S4) {
+      pre[0] += sl[z][0][0]; pre[1] += sl[z][0][1]; pre[2] += sl[z][0][2]; pre[3] += sl[z][0][3];
+      pre[4] += sl[z][1][0]; pre[5] += sl[z][1][1]; pre[6] += sl[z][1][2]; pre[7] += sl[z][1][3];
+    }
+  if (live && p.slab)
+    for (int z = 4; z < p.S; ++z) {               // split-K beyond 4 (not used by the chain's caps): plain loop
+      const float* sp = p.slab + (size_t)b * WS + col + (size_t)z * zs;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+      pre[0] += s0[0]; pre[1] += s0[1]; pre[2] += s0[2]; pre[3] += s0[3];
+      pre[4] += s1[0]; pre[5] += s1[1]; pre[6] += s1[2]; pre[7] += s1[3];
+    }
   for (int k = tid; k < A; k += 256) {
-    const float v = p.slab ? sum_strided(p.slab + (size_t)b * WS + W4 + k, zs, p.S) : 0.f;
+    float v = 0.f;
+    if (p.slab) {
+      if (k == tid) {
+#pragma unroll
+        for (int z = 0; z < 4; ++z) v += z < S4 ? whv[z] : 0.f;
+        for (int z = 4; z < p.S; ++z) v += p.slab[(size_t)z * zs + (size_t)b * WS + W4 + k];
+      } else {
+        v = sum_strided(p.slab + (size_t)b * WS + W4 + k, zs, p.S);
+      }
+    }
     swh[k] = v;
     if (p.Wh_out && blockIdx.y == 0) p.Wh_out[(size_t)b * A + k] = v;
   }
