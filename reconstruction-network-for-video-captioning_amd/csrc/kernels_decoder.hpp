@@ -370,6 +370,47 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
     }
     if (gi < G) { whk_pre = p.Wh[(size_t)b * A + kk] + p.ab[kk]; wk_pre = p.w[kk]; }
   }
+  // pointwise backward of the whole row.  H <= 512, S <= 16: the loads of both units a thread owns (u = tid, tid + 256)
+  // are all issued before the first use — with the loads above that is the kernel's single memory round trip
+  if (H <= 512 && p.S <= 16) {
+    float d1[2], d2[2], sl[2][16], av[2][4], cr[2], cpv[2], cv[2];
+    const int Sn = p.slab ? p.S : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u = tid + 256 * q;
+      const bool ok = u < H;
+      const size_t o = (size_t)b * H + (ok ? u : 0);
+      d1[q] = ok ? p.dHs[o] : 0.f;
+      d2[q] = (ok && p.dHs2) ? p.dHs2[o] : 0.f;
+#pragma unroll
+      for (int z = 0; z < 16; ++z) sl[q][z] = (ok && Sn) ? p.slab[o + (size_t)(z < Sn ? z : Sn - 1) * zs] : 0.f;
+      const float* a = p.acts + (size_t)b * W4 + (ok ? u : 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[q][j] = ok ? a[(size_t)j * H] : 0.f;
+      cr[q] = (ok && !p.first) ? p.dc_in[o] : 0.f;
+      cpv[q] = (ok && p.c_prev) ? p.c_prev[o] : 0.f;
+      cv[q] = (ok && !p.gru) ? p.c[o] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u = tid + 256 * q;
+      if (u < H) {
+        float dh = d1[q] + d2[q];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int z = 0; z < 16; z += 2) { s0 += z < Sn ? sl[q][z] : 0.f; s1 += z + 1 < Sn ? sl[q][z + 1] : 0.f; }
+        dh += s0 + s1;
+        const LstmGrad g = p.gru ? gru_point_bwd(dh + cr[q], av[q][0], av[q][1], av[q][2], av[q][3], cpv[q])
+                                 : lstm_point_bwd(dh, cr[q], av[q][0], av[q][1], av[q][2], av[q][3], cv[q], cpv[q]);
+        sdg[u] = g.di; sdg[H + u] = g.df; sdg[2 * H + u] = g.dg; sdg[3 * H + u] = g.d_o;
+        if (ch == 0) {
+          dgx[u] = (AT)g.di; dgx[H + u] = (AT)g.df; dgx[2 * H + u] = (AT)g.dg; dgx[3 * H + u] = (AT)g.d_o;
+          p.dc_out[(size_t)b * H + u] = g.dc_prev;
+        }
+      }
+    }
+  } else
   for (int u = tid; u < H; u += 256) {
     const size_t o = (size_t)b * H + u;
     float dh = p.dHs[o];
