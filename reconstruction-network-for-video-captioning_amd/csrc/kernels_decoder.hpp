@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   // Uv / dUv of the thread's (f, k) cells); fast path: 4H <= 2048 (multiple of 8), <= 8 frames per chunk, A <= 256
   const bool fast = ((W4 & 7) == 0) && W4 <= 2048 && nf <= 8 && A <= 256 && nf <= 4 * G;
   Raw8<AT> pr[2][4];
-  float uvr[4], duvr[4], whk_pre = 0.f, wk_pre = 0.f;
+  float uvr[4], duvr[4], whk_pre = 0.f, abk_pre = 0.f, wk_pre = 0.f;
   const int kk = (A <= 256) ? tid % A : 0, gi = (A <= 256) ? tid / A : 0;
   if (fast) {
 #pragma unroll
@@ -368,34 +368,42 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
         if (!p.first) duvr[q] = p.dUv[o];
       }
     }
-    if (gi < G) { whk_pre = p.Wh[(size_t)b * A + kk] + p.ab[kk]; wk_pre = p.w[kk]; }
+    // (kept as separate registers: adding them here would be a use, i.e. a wait for everything issued so far)
+    if (gi < G) { whk_pre = p.Wh[(size_t)b * A + kk]; abk_pre = p.ab[kk]; wk_pre = p.w[kk]; }
   }
   // pointwise backward of the whole row.  H <= 512, S <= 16: the loads of both units a thread owns (u = tid, tid + 256)
   // are all issued before the first use — with the loads above that is the kernel's single memory round trip
   if (H <= 512 && p.S <= 16) {
+    // Unconditional loads from always-valid addresses (absent inputs alias a present one and are masked in the
+    // arithmetic): a select on a loaded value, like an add, is a use and would split the loads into several round trips.
     float d1[2], d2[2], sl[2][16], av[2][4], cr[2], cpv[2], cv[2];
     const int Sn = p.slab ? p.S : 0;
+    const float* q2 = p.dHs2 ? p.dHs2 : p.dHs;
+    const float* qs = p.slab ? p.slab : p.dHs;
+    const float* qc = p.c_prev ? p.c_prev : p.c;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int u = tid + 256 * q;
-      const bool ok = u < H;
-      const size_t o = (size_t)b * H + (ok ? u : 0);
-      d1[q] = ok ? p.dHs[o] : 0.f;
-      d2[q] = (ok && p.dHs2) ? p.dHs2[o] : 0.f;
+      const size_t o = (size_t)b * H + (u < H ? u : 0);
+      d1[q] = p.dHs[o];
+      d2[q] = q2[o];
 #pragma unroll
-      for (int z = 0; z < 16; ++z) sl[q][z] = (ok && Sn) ? p.slab[o + (size_t)(z < Sn ? z : Sn - 1) * zs] : 0.f;
-      const float* a = p.acts + (size_t)b * W4 + (ok ? u : 0);
+      for (int z = 0; z < 16; ++z) sl[q][z] = qs[o + (size_t)(z < Sn ? z : (Sn ? Sn - 1 : 0)) * (Sn ? zs : 0)];
+      const float* a = p.acts + (size_t)b * W4 + (u < H ? u : 0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) av[q][j] = ok ? a[(size_t)j * H] : 0.f;
-      cr[q] = (ok && !p.first) ? p.dc_in[o] : 0.f;
-      cpv[q] = (ok && p.c_prev) ? p.c_prev[o] : 0.f;
-      cv[q] = (ok && !p.gru) ? p.c[o] : 0.f;
+      for (int j = 0; j < 4; ++j) av[q][j] = a[(size_t)j * H];
+      cr[q] = p.dc_in[o];
+      cpv[q] = qc[o];
+      cv[q] = p.c[o];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int u = tid + 256 * q;
       if (u < H) {
+        if (!p.dHs2) d2[q] = 0.f;
+        if (p.first) cr[q] = 0.f;
+        if (!p.c_prev) cpv[q] = 0.f;
         float dh = d1[q] + d2[q];
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   // (f, k) plane: thread -> k = tid % A, frame group gi = tid / A (A <= 256), else one thread per k
   if (fast) {
     if (gi < G) {
-      const float whk = whk_pre, wk = wk_pre;
+      const float whk = whk_pre + abk_pre, wk = wk_pre;
       float dwh = 0.f, dw = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
