@@ -27,6 +27,7 @@
 #include "../../include/recnet_hip.h"
 #include "kernels.hpp"
 #include "rec_step.hpp"
+#include "rec_chain.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
@@ -58,6 +59,7 @@ struct recnet_handle {
   // workspace
   char* ws = nullptr; size_t ws_bytes = 0; size_t need = 0;
   uint32_t* ctrl;        // [0] seed slot, [1] step slot (int32)
+  uint32_t* gbar;        // [256] grid-barrier flags of rec_chain_kernel
   float* scal;           // [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
   // ---- decoder: fp32 state
   float *slab2 = nullptr;   // second slab buffer (local reconstructor backward: dWhr . W_r)
@@ -74,10 +76,12 @@ struct recnet_handle {
   // ---- reconstructor
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
+  void* Hr_pan = nullptr;
   void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_f, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   void* Whh_g = nullptr;   // gate-interleaved W_hh of the fused recurrent step (rec_step.hpp); global reconstructor, LSTM, bf16
   int fused_rec = 0;
+  int persist_rec = 0;     // rec_chain.hpp: the reconstructor's forward chain as one launch with W_hh resident in registers
   // inference search scratch (beam width <= 8)
   float *sr_logits, *sr_scores, *sr_h[2], *sr_c[2], *sr_hn, *sr_cn, *sr_cum[2], *sr_vals;
   int64_t *sr_tok[2], *sr_hist[2]; int32_t *sr_eos[2], *sr_idx;
@@ -92,7 +96,7 @@ struct recnet_handle {
   bool dec_bound = false, rec_bound = false;
   OptGroup og[2];
   // state between forward and backward
-  int T_last = 0, train_last = 0, fwd_dec_done = 0, fwd_rec_done = 0, rec_bwd_done = 0, early_opt_done = 0, norms_hoisted = 0;
+  int T_last = 0, train_last = 0, fwd_dec_done = 0, fwd_rec_done = 0, rec_bwd_done = 0, early_opt_done = 0, norms_hoisted = 0, join_pending = 0, join_early = 0;
   // optional per-launch timing of the recurrent-step GEMM (recnet_profile_*)
   int prof_on = 0; std::vector<hipEvent_t> prof_ev; size_t prof_used = 0;
 };
@@ -115,6 +119,7 @@ static size_t carve(recnet_handle* h, char* base) {
   const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
                ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
+  h->gbar = (uint32_t*)take(1024);
   h->scal = take(64);
   h->stepw = take(Tm);
   h->msep = take(1024);
@@ -182,6 +187,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->hrmean = take(B * R); h->outm = take(B * R); h->encmean = take(B * R); h->dhrmean = take(B * R);
     h->dmpd = take(Tm * B * H); h->dmp = take(B * H);
     h->Xcat_g = takev(Tm * B * (size_t)h->ld2H); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
+    h->Hr_pan = takev(Tm * R * (size_t)RC_PAN_ROWS / 2 + 64);   // bf16: k-group-major copies of h_t for rec_chain_kernel
     h->dout_lp = takev(B * ldR); h->dGr = takev(Tm * B * ld4R);
     h->Wih_f = takev(4 * R * (size_t)h->ld2H); h->Whh_w = takev(4 * R * ldR);
     h->Whh_g = takev(4 * R * ldR);
@@ -262,6 +268,15 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const char* e = getenv("RN_FUSED_REC");
     const int want = e ? atoi(e) : 0;
     h->fused_rec = want && h->lp && h->kind == RECNET_REC_GLOBAL && !h->rgru && h->B <= 112 && (h->R & 7) == 0 && h->R <= 2048;
+  }
+  {
+    // rec_chain.hpp: every workgroup (8 hidden units) must be resident at once — one per CU
+    const char* e = getenv("RN_PERSIST_REC");
+    int dev = 0, ncu = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    h->persist_rec = (e ? atoi(e) : 1) && !h->fused_rec && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
+                     (h->R & 7) == 0 && h->R <= 1536 && h->R / 8 <= ncu;   // 12 k-steps of resident weights per wave
   }
   {
     const char* e = getenv("RN_DEC_BWD_NT");

@@ -1,0 +1,259 @@
+// The whole recurrent chain of the global reconstructor's forward pass in ONE launch (global_reconstructor.py:43,
+// train.py:93-94):   for t: gates = Xg[t] + h_{t-1} . W_hh^T ;  (h_t, c_t) = cell pointwise      (LSTM or GRU)
+//
+// Every launch of the per-step path streams W_hh (4R x R bf16, 19 MB at R = 1536) from memory again — the L2s of the
+// eight XCDs are not coherent and do not keep it between launches — writes split-K slabs and reads them back in a
+// second kernel.  Here W_hh is read ONCE: a workgroup owns 8 hidden units (their four gate rows, 32 weight rows) over the
+// full contraction and keeps those rows in MFMA B-operand registers for all T steps (R / 8 workgroups x 4 waves x
+// <= 128 registers: the chip's register files hold the matrix).  Per step a workgroup only reads the bf16 copy of
+// h_{t-1} (B x R), adds the precomputed input part, applies the cell to its 8 units x B rows (c_{t-1} stays in
+// registers) and publishes its 8 columns of h_t; steps are separated by a grid-wide barrier (agent-scope release /
+// acquire, i.e. L2 write-back + invalidate, around one atomic counter).  All R / 8 <= CU-count workgroups are
+// co-resident (one per CU; the host checks), which is what makes the spin barrier safe.
+//   * the four waves split K; activations stream through a register ring of PF pairs of k-steps; the four partial
+//     [112 x 32] tiles are summed through LDS; 256 threads apply the cell;
+//   * the weight rows come from the ordinary gate-major packed image (row gate*R + u): the gather happens once.
+#pragma once
+#include "common.hpp"
+
+struct RecChainArgs {
+  int T, B, R, gru;
+  const bf16_t* W; int ldw;       // [4R][ldw]  packed W_hh, gate-major (GRU: 4-block layout, block 2 zero)
+  bf16_t* Hlp; int ld_hlp;        // [T][B][ld_hlp] row-major operand copies of h_t (for the backward's batched GEMMs)
+  bf16_t* Pan;                    // [T][R/8][RC_PAN_ROWS][8] k-group-major copies of h_t: what the next step reads
+  const float* Xg;                // [T][B][4R] input part of the gates + biases
+  float* H; float* C;             // [T][B][R]
+  float* acts;                    // [T][B][4R] post-activation gates, for the backward
+  unsigned* bar;                  // grid barrier flags, one word per workgroup, zero at launch
+};
+
+#define RC_MB 7               // 16-row blocks: B <= 112
+// Layout of the copy of h_t that the chain itself reads back.  An MFMA A-fragment load (16 rows x 32 k, 16 bytes per
+// lane) is issued by the texture unit 16 lanes at a time, and in a row-major matrix those 16 lanes are 16 different
+// rows = 16 different cache lines for 256 bytes (measured: ~58 clocks per wave load, 8 us per step for the 307 KB
+// block).  Stored as [k / 8][row][8] the same 16 lanes read 256 contiguous bytes (two full lines), and a workgroup's
+// 8 units x B rows are one contiguous run for the writer.
+#define RC_PAN_ROWS (RC_MB * 16)
+
+// Grid barrier, split in two so that the stores nobody waits for are issued between the halves.
+//   arrive: the caller has already waited for its write-through stores of h_t (s_waitcnt vmcnt(0) + __syncthreads);
+//           one agent-scope store of the step number into this workgroup's own flag — no read-modify-write, so the
+//           arrivals of the R / 8 workgroups do not serialise on one address;
+//   wait:   wave 0 polls all flags (one agent-scope load per 64 workgroups) until every one has reached the step, then
+//           invalidates this CU's L1 and this XCD's L2 (acquire) so that the next loads of h_t come from memory.
+__device__ __forceinline__ void rc_arrive(unsigned* flags, unsigned step) {
+  if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.y * gridDim.x + blockIdx.x, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
+#ifndef RC_PROBE_NO_BARRIER
+  if (threadIdx.x < 64) {
+    const int n = gridDim.x * gridDim.y;
+    for (;;) {
+      unsigned v = step;
+      for (int j = threadIdx.x; j < n; j += 64) {
+        const unsigned f = __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = f < v ? f : v;
+      }
+      if (__all(v >= step)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+#ifndef RC_PROBE_NO_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+  }
+#endif
+  __syncthreads();
+}
+
+// STEPS = k32-steps per wave (R <= 4 * 32 * STEPS, even); PF = activation prefetch distance in pairs of k-steps.
+// RB x CG = 16-row blocks x 16-column groups of a workgroup's tile: it owns UW = 4 CG hidden units (16 CG weight rows)
+// and reads RB * 16 of the 112 panel rows; gridDim = (R / UW, MS) with MS * RB * 16 >= 112.  <7, 2>: all rows, 8 units.
+// <4, 4>: half of the rows, 16 units — the same number of workgroups and of MFMAs, but each CU pulls 64 instead of 112
+// rows of h_{t-1} through its L1 every step, and that read (every CU x the whole block = 59 MB per step out of the
+// L2s) is what bounds the step: 7.6 us at 112 rows, 2.5 us at 64 (tools/micro/persist_probe.hip).
+template <int STEPS, int PF, int RB, int CG>
+__global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
+  constexpr int UW = 4 * CG, ROWS = RB * 16, RED_LD = CG * 16 + 1, KG = UW / 8;
+  extern __shared__ __attribute__((aligned(16))) float rc_smem[];
+  float* red = rc_smem;                                            // [4 waves][ROWS][RED_LD]
+  bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD);   // [ROWS][UW] this step's columns of h_t (16-byte aligned: ROWS % 16 == 0)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * UW, R = p.R, B = p.B;
+  // rows: this workgroup owns panel rows [own_lo, own_lo + own) and computes [r0, r0 + ROWS) (a superset)
+  const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
+  const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
+  const int kw0 = wave * (STEPS * 32);                   // this wave's K range
+  const int kq = (lane >> 4) * 8;
+  constexpr int NP = STEPS / 2;
+  const int rot = blockIdx.x % NP;                       // workgroups start at different k: spreads the L2 channels
+  auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
+
+  // ---- resident weights: tile column g*16 + c  <->  gate (g*16+c) / UW, unit u0 + (g*16+c) % UW
+  bf16x8 wb[STEPS][CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const int col = g * 16 + (lane & 15), gate = col / UW, ul = col % UW;
+    const bf16_t* wrow = p.W + (size_t)(gate * R + u0 + ul) * p.ldw + kq;
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = k_of(pr, hh);
+        wb[pr * 2 + hh][g] = (k + kq < R) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+  }
+  // ---- this thread's cells: cell = tid + c*256 -> tile row cell / UW, unit u0 + cell % UW
+  constexpr int CPT = (ROWS * UW + 255) / 256;
+  float xg[CPT][4], cpv[CPT];
+  bool mine[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int rg = r0 + (tid + c * 256) / UW;
+    mine[c] = rg >= own_lo && rg < own_lo + own && rg < B;
+    cpv[c] = 0.f;
+  }
+  auto load_x = [&](int t) {
+    const float* X = p.Xg + (size_t)t * B * 4 * R;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const int row = mine[c] ? r0 + cell / UW : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xg[c][q] = X[(size_t)row * 4 * R + q * R + u0 + cell % UW];
+    }
+  };
+  load_x(0);
+
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;   // k-group (lane / 16), row r0 + lane % 16
+  const size_t pan_t = (size_t)(R >> 3) * RC_PAN_ROWS * 8;                   // elements per time step
+
+  for (int t = 0; t < p.T; ++t) {
+    if (t > 0) {
+      const bf16_t* A = p.Pan + (size_t)(t - 1) * pan_t + lane_off;
+      bf16x8 fa[PF][2][RB];
+      auto issue_pair = [&](int slot, int pr) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const int k = k_of(pr, hh);
+#ifdef RC_PROBE_SKIP_A
+            fa[slot][hh][i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; (void)k;
+#else
+            // rows >= B of the panel are never written: whatever they hold stays in accumulator rows nobody reads
+            fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(A + (((k + kq < R) ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+#endif
+          }
+      };
+#pragma unroll
+      for (int pr = 0; pr < PF; ++pr)
+        if (pr < NP) issue_pair(pr, pr);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[RB][CG];
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) {
+        const int slot = pr % PF;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int s = pr * 2 + hh;
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int g = 0; g < CG; ++g)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], wb[s][g], acc[i][g], 0, 0, 0);
+        }
+        if (pr + PF < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_pair(slot, pr + PF);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float* part = red + wave * (ROWS * RED_LD);
+      const int rr = (lane >> 4) * 4, cc = lane & 15;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < CG; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + g * 16 + cc] = acc[i][g][r];
+      __syncthreads();
+    }
+    // ---- cell pointwise for UW units x owned rows
+    float hv[CPT], av[CPT][4];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
+      float g4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = xg[c][q];
+        if (t > 0) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + row * RED_LD + q * UW + ul];
+        }
+        g4[q] = v;
+      }
+      if (p.gru) {
+        const GruOut r = gru_point(g4[0], g4[1], g4[2], g4[3], cpv[c]);
+        hv[c] = r.h; av[c][0] = r.r; av[c][1] = r.z; av[c][2] = r.n; av[c][3] = r.hn; cpv[c] = r.h;
+      } else {
+        const LstmOut r = lstm_point(g4[0], g4[1], g4[2], g4[3], cpv[c]);
+        hv[c] = r.h; av[c][0] = r.i; av[c][1] = r.f; av[c][2] = r.g; av[c][3] = r.o; cpv[c] = r.c;
+      }
+      if (cell < ROWS * UW) hl[cell] = (bf16_t)hv[c];
+    }
+    __syncthreads();
+    // the only data another workgroup waits for: 16 bytes per (row, 8 units), written through to memory,
+    // acknowledged, then flagged
+    const int it_j = tid / own, it_rg = own_lo + tid % own;              // item = (k-group of this workgroup, owned row)
+    const bool it_on = tid < KG * own && it_rg < B;
+    const bf16_t* it_src = hl + (it_rg - r0) * UW + it_j * 8;
+    if (it_on) {
+      const uint64_t* src = reinterpret_cast<const uint64_t*>(it_src);
+      uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)t * pan_t + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8);
+      __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool more = t + 1 < p.T;
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      rc_arrive(p.bar, (unsigned)(t + 1));
+    }
+    // ---- everything below is off the critical path of the chain
+    float* Ht = p.H + (size_t)t * B * R;
+    float* Ct = p.C + (size_t)t * B * R;
+    float* At = p.acts + (size_t)t * B * 4 * R;
+    bf16_t* Lt = p.Hlp + (size_t)t * B * p.ld_hlp;
+    if (it_on) *reinterpret_cast<bf16x8*>(Lt + (size_t)it_rg * p.ld_hlp + u0 + it_j * 8) = *reinterpret_cast<const bf16x8*>(it_src);
+#ifndef RC_PROBE_SKIP_STORE
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      if (mine[c]) {
+        const int row = r0 + cell / UW, u = u0 + cell % UW;
+        const size_t o = (size_t)row * R + u;
+        Ht[o] = hv[c];
+        if (!p.gru) Ct[o] = cpv[c];
+        float* a = At + (size_t)row * 4 * R + u;
+        a[0] = av[c][0]; a[R] = av[c][1]; a[2 * R] = av[c][2]; a[3 * R] = av[c][3];
+      }
+    }
+#endif
+    if (blockIdx.x == 0 && blockIdx.y == 0 && p.ld_hlp > R)   // zero padding of the operand copy, columns [R, ld_hlp)
+      for (int j = tid; j < B * (p.ld_hlp - R); j += 256) {
+        const int row = j / (p.ld_hlp - R), c = R + j % (p.ld_hlp - R);
+        Lt[(size_t)row * p.ld_hlp + c] = (bf16_t)0.f;
+      }
+    if (more) {
+      load_x(t + 1);                                     // independent of the other workgroups: in flight across the barrier
+      rc_wait(p.bar, (unsigned)(t + 1));
+    }
+  }
+}
+template <int RB, int CG> constexpr size_t rc_smem_bytes() { return (size_t)4 * RB * 16 * (CG * 16 + 1) * 4 + (size_t)RB * 16 * 4 * CG * 2; }

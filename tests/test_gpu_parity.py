@@ -267,6 +267,10 @@ EDGE = {
     "F1": ([4, 1, 40, 37, 10, 24, 16, 16], [3, 5, 1, 2]),
     "T1_empty_captions": ([4, 5, 40, 37, 10, 24, 16, 16], [0, 0, 0, 0]),
     "T31_all_full": ([3, 5, 40, 37, 10, 24, 16, 16], [30, 30, 30]),
+    # batches with rows in both halves of the persistent reconstructor chain's row split (csrc/rec_chain.hpp)
+    "B100_two_row_halves": ([100, 3, 48, 29, 8, 24, 16, 16], [(7 * i) % 9 for i in range(100)]),
+    "B57_second_half_one_row": ([57, 3, 32, 29, 8, 24, 16, 16], [(5 * i) % 7 for i in range(57)]),
+    "B112_R40_all_rows": ([112, 2, 40, 29, 8, 24, 16, 16], [(3 * i) % 6 for i in range(112)]),
 }
 
 
@@ -301,4 +305,37 @@ def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
             e = rel_err(gv[k].cpu().numpy(), ref[grp + "_grad"][k])
             if e > tol["grad"]:
                 bad.append((grp, k, e))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+@pytest.mark.parametrize("env", [{"RN_PERSIST_REC": "0"}, {"RN_PERSIST_MS": "1"}, {"RN_PERSIST_MS": "2"}])
+def test_persistent_reconstructor_chain_variants(env, cell, monkeypatch):
+    """The global reconstructor's forward chain as one launch (csrc/rec_chain.hpp: W_hh resident in registers, grid
+    barrier per step) in both tilings (all rows x 8 units / half of the rows x 16 units) and the per-step path it
+    replaces give the same losses and gradients (fp32 summation order differs, nothing else)."""
+    dims = [100, 3, 48, 29, 8, 24, 16, 16]
+    lens = [(7 * i) % 9 for i in range(100)]
+    B, F, D, V, E, H, A, RA = dims
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, cell), 31)
+    recP = GU.formula_params(GU.rec_shapes("global", H, D, RA, cell), 32)
+    enc, targets = GU.make_batch(B, F, D, V, lens, 78)
+
+    def run():
+        C, dec, rec = make_models(dims, "global", "bf16", decP, recP, cells=(cell, cell))
+        step = R.TrainStep(dec, rec)
+        T, w = step.prepare(targets.numpy())
+        step.fwd_bwd(enc.cuda(), targets.cuda(), T, w, seed=6)
+        torch.cuda.synchronize()
+        sc = step.engine.scalar_dict()
+        g = {grp + "." + k: v.cpu().numpy().copy() for grp, md in (("dec", dec), ("rec", rec))
+             for k, v in md["_state"].flat()["grad"].views.items()}
+        return sc, g
+    sc0, g0 = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc1, g1 = run()
+    assert abs(sc0["rec_loss"] - sc1["rec_loss"]) <= 1e-5 * abs(sc0["rec_loss"])
+    assert abs(sc0["dec_loss"] - sc1["dec_loss"]) <= 1e-6 * abs(sc0["dec_loss"])
+    bad = [(k, rel_err(g1[k], g0[k])) for k in g0 if rel_err(g1[k], g0[k]) > 2e-3]
     assert not bad, bad
