@@ -77,6 +77,9 @@ struct recnet_handle {
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void* Hr_pan = nullptr;
+  void* dG_pan = nullptr;   // exchange copies of the gate gradients, rec_chain_bwd_kernel
+  void* WhhT = nullptr;     // [R][ld4R] transpose of Whh_w (K contiguous) for rec_chain_bwd_kernel
+  int persist_rec_bwd = 0;
   void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_f, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   void* Whh_g = nullptr;   // gate-interleaved W_hh of the fused recurrent step (rec_step.hpp); global reconstructor, LSTM, bf16
@@ -119,7 +122,7 @@ static size_t carve(recnet_handle* h, char* base) {
   const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
                ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
-  h->gbar = (uint32_t*)take(1024);
+  h->gbar = (uint32_t*)take(2048);   // two launches (forward, backward) x 256 flags
   h->scal = take(64);
   h->stepw = take(Tm);
   h->msep = take(1024);
@@ -187,7 +190,9 @@ static size_t carve(recnet_handle* h, char* base) {
     h->hrmean = take(B * R); h->outm = take(B * R); h->encmean = take(B * R); h->dhrmean = take(B * R);
     h->dmpd = take(Tm * B * H); h->dmp = take(B * H);
     h->Xcat_g = takev(Tm * B * (size_t)h->ld2H); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
-    h->Hr_pan = takev(Tm * R * (size_t)RC_PAN_ROWS / 2 + 64);   // bf16: k-group-major copies of h_t for rec_chain_kernel
+    h->Hr_pan = takev(Tm * rc_pan_elems((int)R) / 2 + 64);       // bf16: k-group-major copies of h_t for rec_chain_kernel
+    h->dG_pan = takev(Tm * rc_pan_elems((int)(4 * R)) / 2 + 64);
+    h->WhhT = takev(R * (size_t)h->ld4R);
     h->dout_lp = takev(B * ldR); h->dGr = takev(Tm * B * ld4R);
     h->Wih_f = takev(4 * R * (size_t)h->ld2H); h->Whh_w = takev(4 * R * ldR);
     h->Whh_g = takev(4 * R * ldR);
@@ -277,6 +282,8 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     h->persist_rec = (e ? atoi(e) : 1) && !h->fused_rec && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
                      (h->R & 7) == 0 && h->R <= 1536 && h->R / 8 <= ncu;   // 12 k-steps of resident weights per wave
+    const char* eb = getenv("RN_PERSIST_REC_BWD");
+    h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
   }
   {
     const char* e = getenv("RN_DEC_BWD_NT");

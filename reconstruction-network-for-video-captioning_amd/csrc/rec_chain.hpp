@@ -34,6 +34,8 @@ struct RecChainArgs {
 // block).  Stored as [k / 8][row][8] the same 16 lanes read 256 contiguous bytes (two full lines), and a workgroup's
 // 8 units x B rows are one contiguous run for the writer.
 #define RC_PAN_ROWS (RC_MB * 16)
+// elements of one step's panel for a contraction length K (k-groups padded to whole 32-k steps)
+__host__ __device__ inline size_t rc_pan_elems(int K) { return (size_t)(((K + 31) >> 5) << 2) * RC_PAN_ROWS * 8; }
 
 // Grid barrier, split in two so that the stores nobody waits for are issued between the halves.
 //   arrive: the caller has already waited for its write-through stores of h_t (s_waitcnt vmcnt(0) + __syncthreads);
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) float rc_smem[];
   float* red = rc_smem;                                            // [4 waves][ROWS][RED_LD]
   bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD);   // [ROWS][UW] this step's columns of h_t (16-byte aligned: ROWS % 16 == 0)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
   const int u0 = blockIdx.x * UW, R = p.R, B = p.B;
   // rows: this workgroup owns panel rows [own_lo, own_lo + own) and computes [r0, r0 + ROWS) (a superset)
   const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
@@ -125,7 +127,16 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   load_x(0);
 
   const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;   // k-group (lane / 16), row r0 + lane % 16
-  const size_t pan_t = (size_t)(R >> 3) * RC_PAN_ROWS * 8;                   // elements per time step
+  const size_t pan_t = rc_pan_elems(R);                                      // elements per time step
+  if ((R & 31) && blockIdx.x == 0 && blockIdx.y == 0) {
+    // zero the k-groups that pad R to a multiple of 32, in every step's panel: a partly live k-step reads them
+    // (against zero weights — but 0 x garbage could be NaN).  Published by the first barrier like h_0.
+    const int pad0 = R >> 3, padn = (((R + 31) >> 5) << 2) - pad0;
+    for (int t = 0; t < p.T; ++t)
+      for (int j = tid; j < padn * RC_PAN_ROWS * 2; j += 256)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(p.Pan + (size_t)t * pan_t + (size_t)pad0 * RC_PAN_ROWS * 8) + j, (uint64_t)0,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   for (int t = 0; t < p.T; ++t) {
     if (t > 0) {
@@ -141,7 +152,8 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
             fa[slot][hh][i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; (void)k;
 #else
             // rows >= B of the panel are never written: whatever they hold stays in accumulator rows nobody reads
-            fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(A + (((k + kq < R) ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+            // (the k-groups between R and the next multiple of 32 are zeros, see below: the choice is wave-uniform)
+            fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(A + ((k < R ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
 #endif
           }
       };
@@ -257,3 +269,194 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   }
 }
 template <int RB, int CG> constexpr size_t rc_smem_bytes() { return (size_t)4 * RB * 16 * (CG * 16 + 1) * 4 + (size_t)RB * 16 * 4 * CG * 2; }
+
+// =============================================================================================
+// The backward chain of the same LSTM / GRU, one launch:
+//     for t = T-1 .. 0:  dh_t = dh_direct / T + dG_{t+1} . W_hh ;  (dG_t, dc_{t-1}) = cell pointwise backward
+// Same scheme as the forward kernel with the roles of the matrix transposed: a workgroup owns UW = 16 CG OUTPUT units
+// (columns of W_hh, read from the K-contiguous image Wt = W_hh^T [R][4R]) over the full contraction K = 4R, keeps them
+// in registers, and per step reads the bf16 gate gradients of the step before from the k-group-major exchange buffer
+// (4x the forward's: [4R / 8][112][8]), finishes dh for its units, applies the cell backward (dc carry in registers)
+// and publishes its 4 x UW gate-gradient columns.  The row-major copy dG [T][B][ld_dg] that the deferred weight-gradient
+// GEMMs read is written off the critical path.
+struct RecChainBwdArgs {
+  int T, B, R, gru;
+  const bf16_t* Wt; int ldwt;      // [R][ldwt]  W_hh^T, K (= gate row) contiguous
+  bf16_t* Pan;                     // [T][4R/8][RC_PAN_ROWS][8] exchange copies of dG, indexed by chain step
+  bf16_t* dG; int ld_dg;           // [T][B][ld_dg] row-major gate gradients, zero padded
+  const float* dh_direct; float dh_scale;   // [B][R] the part of d loss / d h_t that is the same for every t
+  const float* acts; const float* C; const float* H;   // [T][B][4R], [T][B][R], [T][B][R]
+  unsigned* bar;
+};
+
+template <int STEPS, int PF, int RB, int CG>
+__global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArgs p) {
+  constexpr int UW = 16 * CG, ROWS = RB * 16, RED_LD = UW + 1, KG = UW / 8, NP = STEPS / 2;
+  extern __shared__ __attribute__((aligned(16))) float rc_smem[];
+  float* red = rc_smem;                                                   // [4 waves][ROWS][RED_LD]
+  bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD + (4 - (4 * ROWS * RED_LD) % 4) % 4);   // [ROWS][4][UW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
+  const int u0 = blockIdx.x * UW, R = p.R, B = p.B, K = 4 * R;
+  const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
+  const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
+  const int kw0 = wave * (STEPS * 32);
+  const int kq = (lane >> 4) * 8;
+  const int rot = blockIdx.x % NP;
+  auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
+
+  bf16x8 wb[STEPS][CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const bf16_t* wrow = p.Wt + (size_t)(u0 + g * 16 + (lane & 15)) * p.ldwt + kq;
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = k_of(pr, hh);
+        wb[pr * 2 + hh][g] = (k + kq < K) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+  }
+  constexpr int CPT = (ROWS * UW + 255) / 256;
+  bool mine[CPT];
+  float direct[CPT], carry[CPT], av[CPT][4], cc[CPT], cp[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int cell = tid + c * 256, rg = r0 + cell / UW;
+    mine[c] = cell < ROWS * UW && rg >= own_lo && rg < own_lo + own && rg < B;
+    direct[c] = mine[c] ? p.dh_scale * p.dh_direct[(size_t)rg * R + u0 + cell % UW] : 0.f;
+    carry[c] = 0.f;
+  }
+  auto prefetch = [&](int t) {                            // saved activations and states of step t
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const size_t row = mine[c] ? r0 + cell / UW : 0;
+      const int u = u0 + cell % UW;
+      const float* a = p.acts + ((size_t)t * B + row) * 4 * R + u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) av[c][q] = a[(size_t)q * R];
+      cc[c] = p.gru ? 0.f : p.C[((size_t)t * B + row) * R + u];
+      cp[c] = t > 0 ? (p.gru ? p.H : p.C)[((size_t)(t - 1) * B + row) * R + u] : 0.f;
+    }
+  };
+  prefetch(p.T - 1);
+
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
+  const size_t pan_t = rc_pan_elems(K);
+
+  // what this thread publishes every step: items (gate, k-group, owned row) of 16 bytes
+  constexpr int IPT = (4 * KG * RC_PAN_ROWS + 255) / 256;            // upper bound: own <= 112
+  const bf16_t* it_src[IPT]; int it_rg[IPT], it_col[IPT]; bool it_on[IPT];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int idx = tid + j * 256;
+    const int q = idx / (KG * own), rem = idx - q * (KG * own), kgi = rem / own, rg = own_lo + rem % own;
+    it_on[j] = idx < 4 * KG * own && rg < B;
+    it_rg[j] = rg; it_col[j] = q * R + u0 + kgi * 8;
+    it_src[j] = hl + ((size_t)(it_on[j] ? rg - r0 : 0) * 4 + (it_on[j] ? q : 0)) * UW + kgi * 8;
+  }
+
+  for (int s = 0; s < p.T; ++s) {
+    const int t = p.T - 1 - s;
+    if (s > 0) {
+      const bf16_t* A = p.Pan + (size_t)(s - 1) * pan_t + lane_off;
+      bf16x8 fa[PF][2][RB];
+      auto issue_pair = [&](int slot, int pr) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const int k = k_of(pr, hh);
+            fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(A + ((k < K ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);   // K % 64 == 0
+          }
+      };
+#pragma unroll
+      for (int pr = 0; pr < PF; ++pr)
+        if (pr < NP) issue_pair(pr, pr);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[RB][CG];
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) {
+        const int slot = pr % PF;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int ks = pr * 2 + hh;
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int g = 0; g < CG; ++g)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], wb[ks][g], acc[i][g], 0, 0, 0);
+        }
+        if (pr + PF < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_pair(slot, pr + PF);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float* part = red + wave * (ROWS * RED_LD);
+      const int rr = (lane >> 4) * 4, cl = lane & 15;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < CG; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + g * 16 + cl] = acc[i][g][r];
+      __syncthreads();
+    }
+    // ---- cell pointwise backward for UW units x owned rows
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
+      float dh = direct[c];
+      if (s > 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) dh += red[w * (ROWS * RED_LD) + row * RED_LD + ul];
+      }
+      const LstmGrad g = p.gru ? gru_point_bwd(dh + carry[c], av[c][0], av[c][1], av[c][2], av[c][3], cp[c])
+                               : lstm_point_bwd(dh, carry[c], av[c][0], av[c][1], av[c][2], av[c][3], cc[c], cp[c]);
+      carry[c] = g.dc_prev;
+      if (cell < ROWS * UW) {
+        bf16_t* d = hl + (size_t)row * 4 * UW + ul;
+        d[0] = (bf16_t)g.di; d[UW] = (bf16_t)g.df; d[2 * UW] = (bf16_t)g.dg; d[3 * UW] = (bf16_t)g.d_o;
+      }
+    }
+    __syncthreads();
+    // publish: 16 bytes per (gate, k-group, owned row), written through, acknowledged, then flagged
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+      if (it_on[j]) {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(it_src[j]);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)s * pan_t + ((size_t)(it_col[j] >> 3) * RC_PAN_ROWS + it_rg[j]) * 8);
+        __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    const bool more = s + 1 < p.T;
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      rc_arrive(p.bar, (unsigned)(s + 1));
+    }
+    // ---- off the critical path: the row-major copy for the deferred weight-gradient GEMMs
+    bf16_t* Gt = p.dG + (size_t)t * B * p.ld_dg;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j)
+      if (it_on[j]) *reinterpret_cast<bf16x8*>(Gt + (size_t)it_rg[j] * p.ld_dg + it_col[j]) = *reinterpret_cast<const bf16x8*>(it_src[j]);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && p.ld_dg > K)
+      for (int j = tid; j < B * (p.ld_dg - K); j += 256) {
+        const int row = j / (p.ld_dg - K), c = K + j % (p.ld_dg - K);
+        Gt[(size_t)row * p.ld_dg + c] = (bf16_t)0.f;
+      }
+    if (more) {
+      prefetch(t - 1);
+      rc_wait(p.bar, (unsigned)(s + 1));
+    }
+  }
+}
+template <int RB, int CG> constexpr size_t rc_bwd_smem_bytes() {
+  return ((size_t)4 * RB * 16 * (16 * CG + 1) + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * CG * 2;
+}

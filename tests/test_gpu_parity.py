@@ -309,7 +309,7 @@ def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
-@pytest.mark.parametrize("env", [{"RN_PERSIST_REC": "0"}, {"RN_PERSIST_MS": "1"}, {"RN_PERSIST_MS": "2"}])
+@pytest.mark.parametrize("env", [{"RN_PERSIST_REC": "0"}, {"RN_PERSIST_REC_BWD": "0"}, {"RN_PERSIST_MS": "1"}, {"RN_PERSIST_MS": "2"}])
 def test_persistent_reconstructor_chain_variants(env, cell, monkeypatch):
     """The global reconstructor's forward chain as one launch (csrc/rec_chain.hpp: W_hh resident in registers, grid
     barrier per step) in both tilings (all rows x 8 units / half of the rows x 16 units) and the per-step path it
