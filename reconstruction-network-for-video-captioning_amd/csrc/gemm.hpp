@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
   CT* sA = reinterpret_cast<CT*>(smem);
   CT* sB = reinterpret_cast<CT*>(smem + GEMM_SMEM_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int m0 = blockIdx.y * GEMM_TILE, n0 = blockIdx.x * GEMM_TILE;
   const int z = blockIdx.z;

@@ -23,7 +23,7 @@ template <int NG, int NKT, int TAG>
 __global__ __launch_bounds__(256) void gemm_chain_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char gc_smem[];
   constexpr int BN = 64 * NG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * BN + wave * (16 * NG);
   const int z = blockIdx.z;
   const int kbeg = z * p.kchunk;

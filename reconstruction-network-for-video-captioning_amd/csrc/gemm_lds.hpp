@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
   constexpr int NPB = BN / 32;                 // DMA pieces per wave of the B tile = 16-column groups per wave
   constexpr int STAGE = 16384 + BN * 128;      // A image 16 KiB + B image
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
   const int m0 = blockIdx.y * GEMM_TILE, n0 = blockIdx.x * BN;
   const int z = blockIdx.z;

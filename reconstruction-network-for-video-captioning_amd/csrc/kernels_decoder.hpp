@@ -39,7 +39,7 @@ __global__ __launch_bounds__(1024) void dec_cell_kernel(const DecCellArgs p) {
   float* sa = swh + p.A;        // [F]
   float* spre = sa + p.F;       // [4 * UC]
   const int NT = blockDim.x, UC = NT >> 2, NW = NT >> 6;
-  const int b = blockIdx.x, u0 = blockIdx.y * UC, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, u0 = blockIdx.y * UC, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
   const size_t zs = (size_t)p.B * WS;
   // ---- every global load of the kernel is issued up front (the kernel is one link of a dependent chain and
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
   float* swh = smem;            // [A]
   float* sa = swh + p.A;        // [F] (+ pad to 16 B)
   float* spre = sa + ((p.F + 3) & ~3);   // [4][512]
-  const int b = blockIdx.x, u0 = blockIdx.y * 512, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const int b = blockIdx.x, u0 = blockIdx.y * 512, tid = threadIdx.x, lane = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, W4 = 4 * H, WS = 4 * H + A;
   const size_t zs = (size_t)p.B * WS;
   const int u = u0 + lane * 8;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   float* sdg = smem;            // [4H]
   float* sda = sdg + 4 * p.H;   // [F]
   float* spart = sda + p.F;     // [2][G][A] partial sums
-  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, W4 = 4 * H;
   const size_t zs = (size_t)p.B * H;
   AT* dgx = reinterpret_cast<AT*>(p.dGx) + (size_t)b * p.ld_dgx;

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* swh = smem;            // [A]
   float* sbeta = swh + p.A;     // [T]
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y * 256 + tid;
   const size_t zs = (size_t)p.B * p.A;
   // Hs[t', b, h] for this thread's column: issued before anything that depends on the scores (T <= 32 fast path)
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   float* sdb = sdx + p.H;       // [T]
   float* sbt = sdb + p.T;       // [T] beta / T
   float* spart = sbt + p.T;     // [2][G][A]
-  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, R = p.R, A = p.A, T = p.T;
   const int W2 = H + R;
   const size_t zs = (size_t)p.B * W2;
