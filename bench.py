@@ -64,11 +64,15 @@ def roofline(eng, run_step, kind, precision, iters=5):
     kname = "%s (recurrent-step GEMM, %s)" % ("gemm_lds_kernel<false, false, 4, 3, 96>" if kind else "gemm_chain_kernel<1, 2, 1>", "reconstructor fwd" if kind else "decoder fwd")
     which = 1 if kind else 0
     if n == 0 and kind == "global":
-        # the forward chain runs as one persistent launch (csrc/rec_chain.hpp): the per-step GEMM that is left, and the
-        # largest one of the step, is the backward form dgates . W_hh
-        site, which = 4, 2
+        # both reconstructor chains run as one persistent launch each (csrc/rec_chain.hpp: W_hh resident in registers,
+        # one grid barrier per time step).  The backward one is the longest kernel of the step.
+        site, which = 8, 4
         n, ms_raw = run_step(site)
-        kname = "gemm_lds_kernel<false, true, 4, 4, 128> (recurrent-step GEMM, reconstructor bwd)"
+        kname = "rec_chain_bwd_kernel<48, 3, 4, 1> (reconstructor backward chain, T steps in one launch)"
+        if n == 0:      # RN_PERSIST_REC_BWD=0: the per-step backward GEMM dgates . W_hh
+            site, which = 4, 2
+            n, ms_raw = run_step(site)
+            kname = "gemm_lds_kernel<false, true, 4, 4, 128> (recurrent-step GEMM, reconstructor bwd)"
     # What the two event records add to a bracket (E), from brackets around 1 and around 17 empty kernels in the same
     # mode (graph nodes / eager): b(c) = E + c * f.  The kernel's dispatch-to-completion time — what rocprofv3 reports as
     # its duration — is its bracket minus E.

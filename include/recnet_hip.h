@@ -257,6 +257,9 @@ int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* s
 #define RECNET_SITE_REC_FWD 3   /* reconstructor gates (global: hr . W_hh^T; local: [x, hr] . [W_ih | W_hh]^T) */
 #define RECNET_SITE_REC_BWD 4
 #define RECNET_SITE_REC_ATT 5   /* local reconstructor: hr . attn_W^T                           */
+#define RECNET_SITE_REC_ATT_BWD 6
+#define RECNET_SITE_REC_CHAIN_FWD 7   /* global reconstructor, bf16: the whole forward chain as one persistent launch */
+#define RECNET_SITE_REC_CHAIN_BWD 8   /* ... and the whole backward chain                                              */
 int recnet_profile_begin(recnet_handle* h, int32_t site);
 int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms);
 /* Same read-out without leaving profiling mode: when the bracketed launches were captured into a hipGraph (the event
@@ -279,7 +282,8 @@ int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, i
                      int32_t splitk, float* splitk_ws, int32_t tag, void* stream);
 /* Name / start / duration of the dominant kernel's launches inside the last train step are measured
  * by the caller with hipEvents; this returns the algorithmic bytes one recurrent-step launch moves. */
-double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which /*0 decoder,1 reconstructor*/);
+double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which /*0 decoder fwd step, 1 reconstructor fwd step,
+    2 reconstructor bwd step, 3 / 4 one launch of the persistent reconstructor fwd / bwd chain over the last T*/);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,9 @@
 #define RN_TAG_REC_BWD 4
 #define RN_TAG_REC_ATT 5
 #define RN_TAG_REC_ATT_BWD 6
+// profile sites of the persistent reconstructor chains (rec_chain.hpp), one launch each per step
+#define RN_SITE_REC_CHAIN_FWD 7
+#define RN_SITE_REC_CHAIN_BWD 8
 
 // ---- gemm.hip
 int rn_gemm_bk(int prec);
