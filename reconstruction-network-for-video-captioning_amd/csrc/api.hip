@@ -28,6 +28,7 @@
 #include "kernels.hpp"
 #include "rec_step.hpp"
 #include "rec_chain.hpp"
+#include "dec_chain.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
@@ -80,6 +81,8 @@ struct recnet_handle {
   void* dG_pan = nullptr;   // exchange copies of the gate gradients, rec_chain_bwd_kernel
   void* WhhT = nullptr;     // [R][ld4R] transpose of Whh_w (K contiguous) for rec_chain_bwd_kernel
   int persist_rec_bwd = 0;
+  int persist_dec = 0;      // dec_chain.hpp: the decoder's teacher-forced forward chain as one launch
+  float* dc_G1 = nullptr; void* dc_pan = nullptr;
   void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_f, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   void* Whh_g = nullptr;   // gate-interleaved W_hh of the fused recurrent step (rec_step.hpp); global reconstructor, LSTM, bf16
@@ -122,7 +125,8 @@ static size_t carve(recnet_handle* h, char* base) {
   const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
                ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
-  h->gbar = (uint32_t*)take(2048);   // two launches (forward, backward) x 256 flags
+  h->gbar = (uint32_t*)take(4096);   // up to four persistent launches x 256 flags
+  h->dc_G1 = take(Tm * B * (4 * H + A)); h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
   h->scal = take(64);
   h->stepw = take(Tm);
   h->msep = take(1024);
@@ -282,6 +286,10 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     h->persist_rec = (e ? atoi(e) : 1) && !h->fused_rec && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
                      (h->R & 7) == 0 && h->R <= 1536 && h->R / 8 <= ncu;   // 12 k-steps of resident weights per wave
+    const char* ed = getenv("RN_PERSIST_DEC");
+    const int N = 4 * h->H + h->A, NA = N / 16;
+    h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 && h->A <= 128 &&
+                     (N & 15) == 0 && h->B <= RC_PAN_ROWS && (NA > h->B ? NA : h->B) <= ncu;
     const char* eb = getenv("RN_PERSIST_REC_BWD");
     h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
   }

@@ -36,15 +36,29 @@ __host__ __forceinline__ uint32_t rn_drop_thr(float p) {
 }
 
 // ---------------------------------------------------------------- reductions
+// Wave-wide reductions (all 64 lanes active; every lane gets the result).  Four DPP steps (quad swaps, half-row and row
+// mirrors: ~10 clocks each) leave the sum of each 16-lane row in all of its lanes, four v_readlane fetch the row sums.
+// (The __shfl_xor butterfly costs six dependent ds_bpermute round trips, ~700 clocks — measured: seven of them in a row
+// were 2.5 us of a 16 us decoder step.)
+template <int CTRL> __device__ __forceinline__ float rn_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float rn_readlane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += rn_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += rn_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += rn_dpp<0x141>(v);    // row_half_mirror
+  v += rn_dpp<0x140>(v);    // row_mirror
+  return (rn_readlane(v, 0) + rn_readlane(v, 16)) + (rn_readlane(v, 32) + rn_readlane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, rn_dpp<0xB1>(v));
+  v = fmaxf(v, rn_dpp<0x4E>(v));
+  v = fmaxf(v, rn_dpp<0x141>(v));
+  v = fmaxf(v, rn_dpp<0x140>(v));
+  return fmaxf(fmaxf(rn_readlane(v, 0), rn_readlane(v, 16)), fmaxf(rn_readlane(v, 32), rn_readlane(v, 48)));
 }
 // block-wide sum for blockDim.x == 256 (4 waves); sm: >= 4 floats of LDS scratch. All threads get the result.
 __device__ __forceinline__ float block_sum256(float v, float* sm) {

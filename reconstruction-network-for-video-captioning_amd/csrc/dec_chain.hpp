@@ -1,0 +1,263 @@
+// The decoder's teacher-forced forward chain (decoder.py:45-70 inside train.py:39-52) as ONE launch.
+//
+// Per step the per-launch path runs two kernels: h_{t-1} . [W_hh ; attn_W]^T (split-K slabs) and the cell kernel (one
+// workgroup per caption: attention scores, context = (1/F) sum_f a_f P[b,f,:], gates, pointwise), each re-reading its
+// loop invariants — the packed weights (2.2 MB) and the caption's block of P = enc . W_ih[:,E:]^T (115 KB bf16 per
+// caption, 11.5 MB per step) — from L2 / memory every step.  Here both stay on chip for all T steps and the step becomes
+// two phases of one persistent kernel, separated by grid barriers (rec_chain.hpp):
+//   phase A, workgroup a < NA = (4H + A) / 16: owns 16 columns of [W_hh ; attn_W] (in MFMA B-operand registers), reads
+//            the bf16 copy of h_{t-1} of all captions (k-group-major exchange panel), writes the finished fp32
+//            pre-activations of its columns for every caption (no split-K slabs);
+//   phase B, workgroup b < B: owns caption b — its block of P in registers (wave = gate, lane = 8 units, 32 frames x 16
+//            bytes), its rows of Uv, c_{t-1}; reads its 4H + A pre-activations, computes scores, context, gates and the
+//            cell, publishes h_t (bf16) for phase A of the next step and writes everything the backward needs.
+// A workgroup takes part in both phases (grid = max(NA, B) <= CU count, one workgroup per CU).
+// Limits: bf16 path, H % 8 == 0, H <= 512, F <= 32, A <= 128, (4H + A) % 16 == 0, B <= 112.
+#pragma once
+#include "common.hpp"
+#include "rec_chain.hpp"
+
+struct DecChainArgs {
+  int T, B, F, H, A, gru;
+  const bf16_t* W; int ldw;        // [4H + A ..][ldw] packed [W_hh ; attn_W] (Wcomb)
+  const bf16_t* P; int ldp;        // [B][F][ldp]
+  const float* Uv; const float* ab; const float* w;
+  const float* Xe;                 // [T][B][4H] emb . W_e^T + biases
+  float* G1;                       // [T][B][4H + A] exchange: recurrent pre-activations
+  bf16_t* Pan;                     // [T][rc_pan_elems(H)] exchange: h_t, k-group-major
+  float* Hs; float* Cs; float* acts;   // [T][B][H], [T][B][H], [T][B][4H]
+  bf16_t* Hlp; int ld_hlp;         // [T][B][ld_hlp] row-major operand copy of h_t, zero padded
+  float* Wh; float* att;           // [T][B][A], [T][B][F]
+  unsigned* bar;
+  unsigned long long* ts;          // probe only (DC_PROBE_TS): [T][12] timestamps of one workgroup
+};
+
+#define DC_RED_LD 17
+#ifdef DC_PROBE_TS
+#define DC_TS(i) do { if (wg == DC_PROBE_WG && tid == 0) p.ts[(size_t)t * 12 + (i)] = wall_clock64(); } while (0)
+#else
+#define DC_TS(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
+  __shared__ float red[4 * RC_PAN_ROWS * DC_RED_LD];                 // phase A: 4 K-partials of the [112 x 16] tile
+  __shared__ __attribute__((aligned(16))) float spre[4 * 512];       // phase B: gate pre-activations
+  __shared__ float swh[128], sa[32];
+  __shared__ __attribute__((aligned(16))) bf16_t hl[512];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, A = p.A, F = p.F, B = p.B, W4 = 4 * H, N = 4 * H + A;
+  const int NA = N >> 4;
+  const int wg = blockIdx.x;
+  const bool isA = wg < NA, isB = wg < B;
+  const int kq = (lane >> 4) * 8;
+  const size_t pan_t = rc_pan_elems(H);
+
+  // ---- phase A residents: 16 weight rows x K = H (4 waves x 4 k-steps of 32)
+  bf16x8 wb[4];
+  {
+    const bf16_t* wrow = p.W + (size_t)((isA ? wg : 0) * 16 + (lane & 15)) * p.ldw + kq;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = wave * 128 + s * 32;
+      wb[s] = (k + kq < H) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  if ((H & 31) && wg == 0) {     // zero the k-groups that pad H to a multiple of 32 in every step's panel (see rec_chain.hpp)
+    const int pad0 = H >> 3, padn = (((H + 31) >> 5) << 2) - pad0;
+    for (int t = 0; t < p.T; ++t)
+      for (int j = tid; j < padn * RC_PAN_ROWS * 2; j += 256)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(p.Pan + (size_t)t * pan_t + (size_t)pad0 * RC_PAN_ROWS * 8) + j, (uint64_t)0,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- phase B residents (caption b = wg): P block, Uv rows, attention vectors; wave = gate g, lane = 8 units
+  const int b = isB ? wg : 0, g = wave;
+  const int u = lane * 8;
+  const bool live = isB && u < H;
+  const int col = g * H + u;
+  Raw8<bf16_t> pv[32];
+  float uvr[8][2], wk[2], bk[2], cpre[2] = {0.f, 0.f};
+  {
+    const bf16_t* pp = p.P + (size_t)b * F * p.ldp + (live ? col : 0);
+#pragma unroll
+    for (int f = 0; f < 32; ++f) { if (live && f < F) pv[f].load(pp + (size_t)f * p.ldp); else pv[f].zero(); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = g + 4 * i;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = lane + 64 * j;
+        uvr[i][j] = (isB && f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = lane + 64 * j;
+      wk[j] = k < A ? p.w[k] : 0.f; bk[j] = k < A ? p.ab[k] : 0.f;
+    }
+  }
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + (lane & 15)) * 8;
+  unsigned ph = 0;
+
+  for (int t = 0; t < p.T; ++t) {
+    // input part of the gates of this step: independent of the chain, requested before any waiting
+    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+    if (live) {
+      const float* xe = p.Xe + ((size_t)t * B + b) * W4 + col;
+      x0 = *reinterpret_cast<const f32x4*>(xe); x1 = *reinterpret_cast<const f32x4*>(xe + 4);
+    }
+    if (t > 0) {
+      // ================= phase A: G1[t][:, 16 columns] = h_{t-1} . W^T
+      DC_TS(0);
+      if (isA) {
+        const bf16_t* Ap = p.Pan + (size_t)(t - 1) * pan_t + lane_off;
+        bf16x8 fa[4][RC_MB];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int k = wave * 128 + s * 32;
+#pragma unroll
+          for (int i = 0; i < RC_MB; ++i)
+            fa[s][i] = *reinterpret_cast<const bf16x8*>(Ap + ((k < H ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[RC_MB];
+#pragma unroll
+        for (int i = 0; i < RC_MB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < RC_MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], wb[s], acc[i], 0, 0, 0);
+        float* part = red + wave * (RC_PAN_ROWS * DC_RED_LD);
+        const int rr = (lane >> 4) * 4, cl = lane & 15;
+#pragma unroll
+        for (int i = 0; i < RC_MB; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * DC_RED_LD + cl] = acc[i][r];
+        __syncthreads();
+        DC_TS(1);
+        float* Gt = p.G1 + (size_t)t * B * N + wg * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = tid + j * 256, row = idx >> 3, pc = (idx & 7) * 2;
+          if (idx < RC_PAN_ROWS * 8 && row < B) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              v0 += red[w * (RC_PAN_ROWS * DC_RED_LD) + row * DC_RED_LD + pc];
+              v1 += red[w * (RC_PAN_ROWS * DC_RED_LD) + row * DC_RED_LD + pc + 1];
+            }
+            union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(Gt + (size_t)row * N + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      DC_TS(2);
+      ++ph;
+      rc_arrive(p.bar, ph);
+      rc_wait(p.bar, ph);
+      DC_TS(3);
+    }
+    // ================= phase B: caption b
+    if (isB) {
+      float pre[8];
+      pre[0] = x0[0]; pre[1] = x0[1]; pre[2] = x0[2]; pre[3] = x0[3]; pre[4] = x1[0]; pre[5] = x1[1]; pre[6] = x1[2]; pre[7] = x1[3];
+      float whv = 0.f;
+      if (t > 0) {
+        const float* gr = p.G1 + ((size_t)t * B + b) * N;
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+        if (live) { g0 = *reinterpret_cast<const f32x4*>(gr + col); g1 = *reinterpret_cast<const f32x4*>(gr + col + 4); }
+        if (tid < A) whv = gr[W4 + tid];
+        pre[0] += g0[0]; pre[1] += g0[1]; pre[2] += g0[2]; pre[3] += g0[3];
+        pre[4] += g1[0]; pre[5] += g1[1]; pre[6] += g1[2]; pre[7] += g1[3];
+      }
+      if (tid < A) { swh[tid] = whv; p.Wh[((size_t)t * B + b) * A + tid] = whv; }
+      __syncthreads();
+      DC_TS(4);
+      {
+        float hk[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int k = lane + 64 * j; hk[j] = k < A ? swh[k] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int f = g + 4 * i;
+          if (f < F) {
+            float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
+            if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
+            s = wave_sum(s);
+            if (lane == 0) { sa[f] = s; p.att[((size_t)t * B + b) * F + f] = s; }
+          }
+        }
+      }
+      __syncthreads();
+      DC_TS(8);
+      if (live) {
+        float c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = 0.f;
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+          if (f < F) {
+            const float a = sa[f];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[j] += a * pv[f].at(j);
+          }
+        const float invF = 1.0f / (float)F;
+        float* dst = spre + g * 512 + lane * 8;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{pre[0] + c[0] * invF, pre[1] + c[1] * invF, pre[2] + c[2] * invF, pre[3] + c[3] * invF};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{pre[4] + c[4] * invF, pre[5] + c[5] * invF, pre[6] + c[6] * invF, pre[7] + c[7] * invF};
+      }
+      __syncthreads();
+      DC_TS(9);
+      float hv[2], av[2][4], cn[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int uu = tid + 256 * jj;
+        hv[jj] = 0.f; cn[jj] = 0.f; av[jj][0] = av[jj][1] = av[jj][2] = av[jj][3] = 0.f;
+        if (uu < H) {
+          if (p.gru) {
+            const GruOut r = gru_point(spre[uu], spre[512 + uu], spre[1024 + uu], spre[1536 + uu], cpre[jj]);
+            hv[jj] = r.h; av[jj][0] = r.r; av[jj][1] = r.z; av[jj][2] = r.n; av[jj][3] = r.hn; cpre[jj] = r.h;
+          } else {
+            const LstmOut r = lstm_point(spre[uu], spre[512 + uu], spre[1024 + uu], spre[1536 + uu], cpre[jj]);
+            hv[jj] = r.h; av[jj][0] = r.i; av[jj][1] = r.f; av[jj][2] = r.g; av[jj][3] = r.o; cpre[jj] = r.c; cn[jj] = r.c;
+          }
+          hl[uu] = (bf16_t)hv[jj];
+        }
+      }
+      __syncthreads();
+      DC_TS(5);
+      // publish h_t[b]: 16 bytes per k-group, written through
+      if (tid < (H >> 3)) {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(hl + tid * 8);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)t * pan_t + ((size_t)tid * RC_PAN_ROWS + b) * 8);
+        __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (t + 1 < p.T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (the stores below are issued after the arrive, see the end of the loop body)
+      if (t + 1 < p.T) { __syncthreads(); DC_TS(6); ++ph; rc_arrive(p.bar, ph); }
+      bf16_t* Lt = p.Hlp + ((size_t)t * B + b) * p.ld_hlp;
+      if (tid < (H >> 3)) *reinterpret_cast<bf16x8*>(Lt + tid * 8) = *reinterpret_cast<const bf16x8*>(hl + tid * 8);
+      for (int j = H + tid; j < p.ld_hlp; j += 256) Lt[j] = (bf16_t)0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int uu = tid + 256 * jj;
+        if (uu < H) {
+          const size_t o = ((size_t)t * B + b) * H + uu;
+          p.Hs[o] = hv[jj];
+          if (!p.gru) p.Cs[o] = cn[jj];
+          float* a = p.acts + ((size_t)t * B + b) * W4 + uu;
+          a[0] = av[jj][0]; a[H] = av[jj][1]; a[2 * H] = av[jj][2]; a[3 * H] = av[jj][3];
+        }
+      }
+      if (t + 1 < p.T) rc_wait(p.bar, ph);
+      DC_TS(7);
+    } else if (t + 1 < p.T) {
+      __syncthreads();
+      ++ph;
+      rc_arrive(p.bar, ph);
+      rc_wait(p.bar, ph);
+    }
+  }
+}

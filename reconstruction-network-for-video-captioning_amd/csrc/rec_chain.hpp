@@ -49,13 +49,19 @@ __device__ __forceinline__ void rc_arrive(unsigned* flags, unsigned step) {
 __device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
 #ifndef RC_PROBE_NO_BARRIER
   if (threadIdx.x < 64) {
+    // n <= 256 flags: four loads per lane, all in flight together (a loop that folds each flag into a running minimum
+    // waits for every load before issuing the next one: three memory round trips per poll instead of one)
     const int n = gridDim.x * gridDim.y;
+    const unsigned* f0 = flags + (threadIdx.x < n ? threadIdx.x : n - 1);
+    const unsigned* f1 = flags + (threadIdx.x + 64 < n ? threadIdx.x + 64 : n - 1);
+    const unsigned* f2 = flags + (threadIdx.x + 128 < n ? threadIdx.x + 128 : n - 1);
+    const unsigned* f3 = flags + (threadIdx.x + 192 < n ? threadIdx.x + 192 : n - 1);
     for (;;) {
-      unsigned v = step;
-      for (int j = threadIdx.x; j < n; j += 64) {
-        const unsigned f = __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = f < v ? f : v;
-      }
+      const unsigned a0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned a1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned a2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned a3 = __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned m01 = a0 < a1 ? a0 : a1, m23 = a2 < a3 ? a2 : a3, v = m01 < m23 ? m01 : m23;
       if (__all(v >= step)) break;
       __builtin_amdgcn_s_sleep(1);
     }
