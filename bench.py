@@ -88,8 +88,8 @@ def roofline(eng, run_step, kind, precision, iters=5):
     # FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py) — only valid for the configuration it was
     # collected on (global reconstructor, bf16, B=100, 28x1536)
     traffic = None
-    tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic_rec_fwd_gemm.json")
-    if which == 1 and kind == "global" and precision == "bf16" and eng.dims["B"] == 100 and eng.dims["D"] == 1536 and os.path.exists(tf):
+    tf = os.path.join(ROOT, "profiles", {1: "r01_pmc_traffic_rec_fwd_gemm.json", 4: "r01_pmc_traffic_rec_chain_bwd.json"}.get(which, "-"))
+    if which in (1, 4) and kind == "global" and precision == "bf16" and eng.dims["B"] == 100 and eng.dims["D"] == 1536 and os.path.exists(tf):
         traffic = int(json.load(open(tf))["traffic_bytes_per_launch"])
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,

@@ -3,7 +3,7 @@ per-launch HBM-side traffic of the dominant kernel.  gfx950 correction (MI355X_M
 FETCH_SIZE under-reports wide coalesced reads by exactly 2x -> doubled; WRITE_SIZE is exact; both are in KiB."""
 import csv, glob, json, sys
 def per_launch(d, counter, pat):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     tot = 0.0; ids = set()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter and pat in r["Kernel_Name"]:
