@@ -83,6 +83,8 @@ struct recnet_handle {
   int persist_rec_bwd = 0;
   int persist_dec = 0;      // dec_chain.hpp: the decoder's teacher-forced forward chain as one launch
   float* dc_G1 = nullptr; void* dc_pan = nullptr;
+  int persist_dec_bwd = 0;  // ... and its BPTT chain
+  float* dc_G2 = nullptr; void* dc_pan2 = nullptr;
   void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_f, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
   void* Whh_g = nullptr;   // gate-interleaved W_hh of the fused recurrent step (rec_step.hpp); global reconstructor, LSTM, bf16
@@ -127,6 +129,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->ctrl = (uint32_t*)take(64);
   h->gbar = (uint32_t*)take(4096);   // up to four persistent launches x 256 flags
   h->dc_G1 = take(Tm * B * (4 * H + A)); h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
+  h->dc_G2 = take(Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
   h->scal = take(64);
   h->stepw = take(Tm);
   h->msep = take(1024);
@@ -296,6 +299,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   {
     const char* e = getenv("RN_DEC_BWD_NT");
     h->use_wcomb_t = (e ? atoi(e) : 1) && h->lp && h->B <= 128;
+    const char* eb = getenv("RN_PERSIST_DEC_BWD");
+    int dev = 0, ncu = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int NAb = (h->H / 16) * DCB_PARTS;
+    h->persist_dec_bwd = (eb ? atoi(eb) : 1) && h->persist_dec && h->use_wcomb_t && (h->H & 15) == 0 && (h->ldWS & 7) == 0 &&
+                         (NAb > h->B ? NAb : h->B) <= ncu;
   }
   h->need = carve(h, nullptr);
   *out = h;

@@ -261,3 +261,275 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
     }
   }
 }
+
+// =============================================================================================
+// The decoder's BPTT chain as one launch.  Per step (t = T-1 .. 0):
+//   dh_t = dHs[t] + dhid[t] + [dgates_{t+1} | dWh_{t+1}] . [W_hh ; attn_W]        (phase A', unit-owner workgroups)
+//   cell backward -> dgates_t ; da = (1/F) P_b . dgates_t ; attention backward -> dWh_t, dUv += , dw +=     (phase B')
+// Phase A': workgroup (16 output units, one of 4 row parts) keeps its 16 rows of [W_hh ; attn_W]^T (K = 4H + A
+// contiguous, from WcombT) in registers and reads the bf16 rows [dgates | dWh] of the step before from the exchange panel.
+// Phase B': workgroup b owns caption b.  Its block of P sits in registers as MFMA A-operand fragments (frames x gate
+// columns), so da is 2 x H/32 MFMAs per wave against the bf16 dgates broadcast over the 16 B-columns; Uv, the dUv and dw
+// accumulators and the dc carry stay in registers for all T steps (the per-launch path re-read and re-wrote dUv every
+// step and split each caption over four workgroups whose dWh partials the next GEMM had to sum).
+// Output rows keep the layout of the per-launch path, [dgates (4H) | dWh (A) | 0 (3A) | pad], so the deferred
+// weight-gradient GEMMs are unchanged.
+struct DecChainBwdArgs {
+  int T, B, F, H, A, gru;
+  const bf16_t* Wt; int ldwt;      // [H][ldwt] WcombT: column n of [W_hh ; attn_W ..], K contiguous
+  const bf16_t* P; int ldp;        // [B][F][ldp]
+  const float* Uv; const float* ab; const float* w;
+  const float* dHs; const float* dHs2;                      // [T][B][H]; dHs2 may be null
+  const float* acts; const float* Cs; const float* Hs;      // [T][B][4H], [T][B][H], [T][B][H]
+  const float* Wh;                 // [T][B][A]
+  float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh
+  bf16_t* Pan;                     // [T][rc_pan_elems(4H + A)] exchange (by chain step): rows [dgates | dWh]
+  bf16_t* dGx; int ld_dgx;         // [T][B][ld_dgx]
+  float* dUv; bf16_t* dUv_lp; int ld_dUv;                   // [B][F][A], [B F][ld_dUv]
+  float* dwacc;                    // [RN_FCH][B][A]
+  unsigned* bar;
+};
+
+#define DCB_STEPS 17          // k32-steps per wave: 4 x 17 x 32 = 2176 >= 4H + A
+#define DCB_RB 2              // 32 rows per workgroup in phase A', 4 row parts
+#define DCB_PARTS 4
+
+__global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArgs p) {
+  __shared__ float red[4 * DCB_RB * 16 * DC_RED_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t srow[4 * 512 + 128 + 64];   // [dgates | dWh] of this step (+ zero tail)
+  __shared__ float spartf[4 * 32], sda[32], spart[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, A = p.A, F = p.F, B = p.B, W4 = 4 * H, KA = 4 * H + A;
+  const int NU = H >> 4, NA = NU * DCB_PARTS;
+  const int wg = blockIdx.x;
+  const bool isA = wg < NA, isB = wg < B;
+  const int kq = (lane >> 4) * 8;
+  const size_t pan_t = rc_pan_elems(KA);
+
+  // ---- phase A' residents
+  const int ug = isA ? wg % NU : 0, part = isA ? wg / NU : 0;
+  const int own = RC_PAN_ROWS / DCB_PARTS, own_lo = part * own;
+  const int r0 = own_lo < RC_PAN_ROWS - DCB_RB * 16 ? own_lo : RC_PAN_ROWS - DCB_RB * 16;
+  bf16x8 wb[DCB_STEPS];
+  {
+    const bf16_t* wrow = p.Wt + (size_t)(ug * 16 + (lane & 15)) * p.ldwt + kq;
+#pragma unroll
+    for (int s = 0; s < DCB_STEPS; ++s) {
+      const int k = (wave * DCB_STEPS + s) * 32;
+      wb[s] = (k + kq < KA) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  if ((KA & 31) && wg == 0) {    // zero the k-groups that pad KA to a multiple of 32 in every step's panel
+    const int pad0 = KA >> 3, padn = (((KA + 31) >> 5) << 2) - pad0;
+    for (int t = 0; t < p.T; ++t)
+      for (int j = tid; j < padn * RC_PAN_ROWS * 2; j += 256)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(p.Pan + (size_t)t * pan_t + (size_t)pad0 * RC_PAN_ROWS * 8) + j, (uint64_t)0,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- phase B' residents (caption b = wg)
+  const int b = isB ? wg : 0, g = wave;
+  // P as MFMA A-operand fragments: rows = frames (2 blocks of 16), K = this wave's gate block [g H, (g+1) H)
+  bf16x8 pa[2][16];
+#pragma unroll
+  for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int f = fb * 16 + (lane & 15), ku = ks * 32 + kq;
+      pa[fb][ks] = (isB && f < F && ku < H) ? *reinterpret_cast<const bf16x8*>(p.P + ((size_t)b * F + f) * p.ldp + g * H + ku)
+                                            : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  // (f, k) plane: k = tid % A, frame group gi = tid / A, G = 256 / A groups (A <= 128 -> G >= 2)
+  const int G = 256 / A, kk = tid % A, gi = tid / A;
+  const bool fk_on = isB && gi < G;
+  float uvr[16], duv[16], dwa = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int f = gi + q * G;
+    uvr[q] = (fk_on && f < F) ? p.Uv[((size_t)b * F + f) * A + kk] : 0.f;
+    duv[q] = 0.f;
+  }
+  const float abk = fk_on ? p.ab[kk] : 0.f, wk = fk_on ? p.w[kk] : 0.f;
+  float carry[2] = {0.f, 0.f};
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
+  for (int j = tid; j < 64; j += 256) srow[W4 + 128 + j] = (bf16_t)0.f;
+  unsigned ph = 0;
+
+  // saved tensors of step t for this thread's two units, and Wh[t][b][kk]
+  float d1[2], d2[2], av[2][4], cv[2], cpv[2], whk;
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int u = tid + 256 * q;
+      const size_t o = ((size_t)t * B + b) * H + (u < H ? u : 0);
+      d1[q] = p.dHs[o];
+      d2[q] = p.dHs2 ? p.dHs2[o] : 0.f;
+      const float* a = p.acts + ((size_t)t * B + b) * W4 + (u < H ? u : 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[q][j] = a[(size_t)j * H];
+      cv[q] = p.Cs[o];
+      cpv[q] = t > 0 ? (p.gru ? p.Hs : p.Cs)[o - (size_t)B * H] : 0.f;
+    }
+    whk = p.Wh[((size_t)t * B + b) * A + kk];
+  };
+  if (isB) prefetch(p.T - 1);
+
+  for (int s = 0; s < p.T; ++s) {
+    const int t = p.T - 1 - s;
+    if (s > 0) {
+      // ================= phase A': G2[s][rows, 16 units] = rows_{s-1} . W
+      if (isA) {
+        const bf16_t* Ap = p.Pan + (size_t)(s - 1) * pan_t + lane_off;
+        bf16x8 fa[DCB_STEPS][DCB_RB];
+#pragma unroll
+        for (int ks = 0; ks < DCB_STEPS; ++ks) {
+          const int k = (wave * DCB_STEPS + ks) * 32;
+#pragma unroll
+          for (int i = 0; i < DCB_RB; ++i)
+            fa[ks][i] = *reinterpret_cast<const bf16x8*>(Ap + ((k < KA ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[DCB_RB];
+#pragma unroll
+        for (int i = 0; i < DCB_RB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < DCB_STEPS; ++ks)
+#pragma unroll
+          for (int i = 0; i < DCB_RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], wb[ks], acc[i], 0, 0, 0);
+        float* prt = red + wave * (DCB_RB * 16 * DC_RED_LD);
+        const int rr = (lane >> 4) * 4, cl = lane & 15;
+#pragma unroll
+        for (int i = 0; i < DCB_RB; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prt[(i * 16 + rr + r) * DC_RED_LD + cl] = acc[i][r];
+        __syncthreads();
+        {
+          const int rg = own_lo + (tid >> 3), pc = (tid & 7) * 2, rl = rg - r0;
+          if (tid < own * 8 && rg < B) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              v0 += red[w * (DCB_RB * 16 * DC_RED_LD) + rl * DC_RED_LD + pc];
+              v1 += red[w * (DCB_RB * 16 * DC_RED_LD) + rl * DC_RED_LD + pc + 1];
+            }
+            union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(p.G2 + ((size_t)s * B + rg) * H + ug * 16 + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      ++ph;
+      rc_arrive(p.bar, ph);
+      rc_wait(p.bar, ph);
+    }
+    // ================= phase B': caption b
+    if (isB) {
+      // (1) cell backward of the thread's two units -> dgates (bf16) into the row buffer
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int u = tid + 256 * q;
+        if (u < H) {
+          float dh = d1[q] + d2[q];
+          if (s > 0) dh += p.G2[((size_t)s * B + b) * H + u];
+          const LstmGrad gr = p.gru ? gru_point_bwd(dh + carry[q], av[q][0], av[q][1], av[q][2], av[q][3], cpv[q])
+                                    : lstm_point_bwd(dh, carry[q], av[q][0], av[q][1], av[q][2], av[q][3], cv[q], cpv[q]);
+          carry[q] = gr.dc_prev;
+          srow[u] = (bf16_t)gr.di; srow[H + u] = (bf16_t)gr.df; srow[2 * H + u] = (bf16_t)gr.dg; srow[3 * H + u] = (bf16_t)gr.d_o;
+        }
+      }
+      __syncthreads();
+      // (2) da[f] = (1/F) sum_n P[b,f,n] dgates[n]: MFMA, this wave's gate block, dgates replicated over the 16 columns
+      {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const int ku = ks * 32 + kq;
+          const bf16x8 bv = (ks * 32 < H) ? *reinterpret_cast<const bf16x8*>(srow + (ku < H ? g * H + ku : W4 + 128)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (ks * 32 < H) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0][ks], bv, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1][ks], bv, acc[1], 0, 0, 0);
+          }
+        }
+        if ((lane & 15) == 0) {
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) spartf[g * 32 + fb * 16 + (lane >> 4) * 4 + r] = acc[fb][r];
+        }
+      }
+      __syncthreads();
+      if (tid < 32) sda[tid] = (spartf[tid] + spartf[32 + tid] + spartf[64 + tid] + spartf[96 + tid]) * (1.0f / (float)F);
+      __syncthreads();
+      // (3) attention backward on the (f, k) plane
+      float dwh = 0.f;
+      if (fk_on) {
+        const float wh = whk + abk;
+        float dw = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int f = gi + q * G;
+          if (f < F) {
+            const float tz = rn_tanh(wh + uvr[q]);
+            const float daf = sda[f];
+            const float ds = daf * wk * (1.f - tz * tz);
+            dw += daf * tz;
+            dwh += ds;
+            duv[q] += ds;
+          }
+        }
+        dwa += dw;
+        spart[gi * A + kk] = dwh;
+      }
+      __syncthreads();
+      if (tid < A) {
+        float a = 0.f;
+        for (int j = 0; j < G; ++j) a += spart[j * A + tid];
+        srow[W4 + tid] = (bf16_t)a;
+      }
+      __syncthreads();
+      // (4) publish the row [dgates | dWh]: 16 bytes per k-group, written through
+      const bool more = s + 1 < p.T;
+      for (int kg = tid; kg < (KA >> 3); kg += 256) {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(srow + kg * 8);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)s * pan_t + ((size_t)kg * RC_PAN_ROWS + b) * 8);
+        __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; rc_arrive(p.bar, ph); }
+      // ---- off the critical path: the row-major copy [dgates | dWh | 0 ..] for the deferred GEMMs
+      bf16_t* Gt = p.dGx + ((size_t)t * B + b) * p.ld_dgx;
+      for (int kg = tid; kg < (p.ld_dgx >> 3); kg += 256)
+        *reinterpret_cast<bf16x8*>(Gt + kg * 8) = kg < (KA >> 3) ? *reinterpret_cast<const bf16x8*>(srow + kg * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (more) { prefetch(t - 1); rc_wait(p.bar, ph); }
+    } else if (s + 1 < p.T) {
+      __syncthreads();
+      ++ph;
+      rc_arrive(p.bar, ph);
+      rc_wait(p.bar, ph);
+    }
+  }
+  // ---- the accumulators: dUv (+ operand copy, zero padded), dw
+  if (isB) {
+    if (fk_on) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int f = gi + q * G;
+        if (f < F) {
+          p.dUv[((size_t)b * F + f) * A + kk] = duv[q];
+          p.dUv_lp[((size_t)b * F + f) * p.ld_dUv + kk] = (bf16_t)duv[q];
+        }
+      }
+      spart[gi * A + kk] = dwa;
+    }
+    for (int f = wave; f < F; f += 4)
+      for (int j = A + lane; j < p.ld_dUv; j += 64) p.dUv_lp[((size_t)b * F + f) * p.ld_dUv + j] = (bf16_t)0.f;
+    __syncthreads();
+    if (tid < A) {
+      float a = 0.f;
+      for (int j = 0; j < G; ++j) a += spart[j * A + tid];
+      p.dwacc[(size_t)b * A + tid] = a;
+#pragma unroll
+      for (int ch = 1; ch < RN_FCH; ++ch) p.dwacc[((size_t)ch * B + b) * A + tid] = 0.f;
+    }
+  }
+}
