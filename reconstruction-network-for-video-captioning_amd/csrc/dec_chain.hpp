@@ -23,7 +23,8 @@ struct DecChainArgs {
   const bf16_t* P; int ldp;        // [B][F][ldp]
   const float* Uv; const float* ab; const float* w;
   const float* Xe;                 // [T][B][4H] emb . W_e^T + biases
-  float* G1;                       // [T][B][4H + A] exchange: recurrent pre-activations
+  float* G1;                       // [T][B][4H + A] exchange: recurrent pre-activations (ll: 8-byte words {value, stamp})
+  unsigned* epoch; int ll;         // ll = 1: phase A -> B hand-over through stamped words instead of a grid barrier
   bf16_t* Pan;                     // [T][rc_pan_elems(H)] exchange: h_t, k-group-major
   float* Hs; float* Cs; float* acts;   // [T][B][H], [T][B][H], [T][B][4H]
   bf16_t* Hlp; int ld_hlp;         // [T][B][ld_hlp] row-major operand copy of h_t, zero padded
@@ -97,6 +98,10 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   }
   const int lane_off = ((lane >> 4) * RC_PAN_ROWS + (lane & 15)) * 8;
   unsigned ph = 0;
+  // Stamped hand-over (ll): a word is {fp32 value, stamp = launch epoch << 6 | t}, written by one 8-byte store, so the
+  // consumer can poll the data itself: no acknowledgement wait, no flag, no barrier between phase A and phase B.  The
+  // epoch (one more per launch, kept in device memory) makes the words of earlier launches stale.
+  const unsigned ep = p.ll ? (__hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 6) : 0u;
 
   for (int t = 0; t < p.T; ++t) {
     // input part of the gates of this step: independent of the chain, requested before any waiting
@@ -145,17 +150,26 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
               v0 += red[w * (RC_PAN_ROWS * DC_RED_LD) + row * DC_RED_LD + pc];
               v1 += red[w * (RC_PAN_ROWS * DC_RED_LD) + row * DC_RED_LD + pc + 1];
             }
-            union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
-            __hip_atomic_store(reinterpret_cast<uint64_t*>(Gt + (size_t)row * N + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.ll) {
+              uint64_t* L = reinterpret_cast<uint64_t*>(p.G1) + ((size_t)t * B + row) * N + wg * 16 + pc;
+              const uint64_t st = (uint64_t)(ep | (unsigned)t) << 32;
+              __hip_atomic_store(L, st | __builtin_bit_cast(unsigned, v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(L + 1, st | __builtin_bit_cast(unsigned, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
+              __hip_atomic_store(reinterpret_cast<uint64_t*>(Gt + (size_t)row * N + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!p.ll) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __syncthreads();
-      DC_TS(2);
-      ++ph;
-      rc_arrive(p.bar, ph);
-      rc_wait(p.bar, ph);
+      if (!p.ll) {
+        __syncthreads();
+        DC_TS(2);
+        ++ph;
+        rc_arrive(p.bar, ph);
+        rc_wait(p.bar, ph);
+      }
       DC_TS(3);
     }
     // ================= phase B: caption b
@@ -163,7 +177,28 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       float pre[8];
       pre[0] = x0[0]; pre[1] = x0[1]; pre[2] = x0[2]; pre[3] = x0[3]; pre[4] = x1[0]; pre[5] = x1[1]; pre[6] = x1[2]; pre[7] = x1[3];
       float whv = 0.f;
-      if (t > 0) {
+      if (t > 0 && p.ll) {
+        // poll this caption's words until every stamp is this step's
+        const uint64_t* L = reinterpret_cast<const uint64_t*>(p.G1) + ((size_t)t * B + b) * N;
+        const uint64_t* lc = L + (live ? col : 0);
+        const uint64_t* lw = L + W4 + (tid < A ? tid : 0);
+        const unsigned want = ep | (unsigned)t;
+        uint64_t wv[8], ww;
+        for (;;) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv[j] = __hip_atomic_load(lc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ww = __hip_atomic_load(lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool ok = (unsigned)(ww >> 32) == want;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ok = ok && (unsigned)(wv[j] >> 32) == want;
+          if (__all(ok)) break;
+        }
+        if (live) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pre[j] += __builtin_bit_cast(float, (unsigned)wv[j]);
+        }
+        if (tid < A) whv = __builtin_bit_cast(float, (unsigned)ww);
+      } else if (t > 0) {
         const float* gr = p.G1 + ((size_t)t * B + b) * N;
         f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
         if (live) { g0 = *reinterpret_cast<const f32x4*>(gr + col); g1 = *reinterpret_cast<const f32x4*>(gr + col + 4); }
@@ -260,6 +295,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       rc_wait(p.bar, ph);
     }
   }
+  if (p.ll && wg == 0 && tid == 0) __hip_atomic_store(p.epoch, (ep >> 6) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =============================================================================================

@@ -17,7 +17,7 @@ int main() {
   c.W = dalloc<bf16_t>((size_t)(4 * H + 4 * A) * H); c.ldw = H;
   c.P = dalloc<bf16_t>((size_t)B * F * 4 * H); c.ldp = 4 * H;
   c.Uv = dalloc<float>((size_t)B * F * A); c.ab = dalloc<float>(A); c.w = dalloc<float>(A);
-  c.Xe = dalloc<float>((size_t)T * B * 4 * H); c.G1 = dalloc<float>((size_t)T * B * N);
+  c.Xe = dalloc<float>((size_t)T * B * 4 * H); c.G1 = dalloc<float>((size_t)2 * T * B * N); c.epoch = dalloc<unsigned>(16); c.ll = getenv("LL") ? atoi(getenv("LL")) : 1;
   c.Pan = dalloc<bf16_t>((size_t)T * rc_pan_elems(H));
   c.Hs = dalloc<float>((size_t)T * B * H); c.Cs = dalloc<float>((size_t)T * B * H); c.acts = dalloc<float>((size_t)T * B * 4 * H);
   c.Hlp = dalloc<bf16_t>((size_t)T * B * H); c.ld_hlp = H; c.Wh = dalloc<float>((size_t)T * B * A); c.att = dalloc<float>((size_t)T * B * F);
