@@ -130,7 +130,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->gbar = (uint32_t*)take(4096 + 64);   // up to four persistent launches x 256 flags, then the launch-epoch words
   h->dc_G1 = take(2 * Tm * B * (4 * H + A));   // fp32, or 8-byte stamped words
   h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
-  h->dc_G2 = take(Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
+  h->dc_G2 = take(2 * Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
   h->scal = take(64);
   h->stepw = take(Tm);
   h->msep = take(1024);
@@ -388,6 +388,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   carve(h, h->ws);
   // stamped exchange buffers and the launch-epoch words start from zero (a stamp is never zero)
   HIPCHK(hipMemset(h->gbar, 0, 4096 + 64)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
+  HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * 4));
   h->gws_cur = h->gws;
   if (!h->s2) {
     const char* ov = getenv("RN_OVERLAP");

@@ -318,7 +318,8 @@ struct DecChainBwdArgs {
   const float* dHs; const float* dHs2;                      // [T][B][H]; dHs2 may be null
   const float* acts; const float* Cs; const float* Hs;      // [T][B][4H], [T][B][H], [T][B][H]
   const float* Wh;                 // [T][B][A]
-  float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh
+  float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh (ll: stamped 8-byte words)
+  unsigned* epoch; int ll;
   bf16_t* Pan;                     // [T][rc_pan_elems(4H + A)] exchange (by chain step): rows [dgates | dWh]
   bf16_t* dGx; int ld_dgx;         // [T][B][ld_dgx]
   float* dUv; bf16_t* dUv_lp; int ld_dUv;                   // [B][F][A], [B F][ld_dUv]
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
   const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
   for (int j = tid; j < 64; j += 256) srow[W4 + 128 + j] = (bf16_t)0.f;
   unsigned ph = 0;
+  const unsigned ep = p.ll ? (__hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 6) : 0u;   // see dec_chain_kernel
 
   // saved tensors of step t for this thread's two units, and Wh[t][b][kk]
   float d1[2], d2[2], av[2][4], cv[2], cpv[2], whk;
@@ -447,26 +449,51 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
               v0 += red[w * (DCB_RB * 16 * DC_RED_LD) + rl * DC_RED_LD + pc];
               v1 += red[w * (DCB_RB * 16 * DC_RED_LD) + rl * DC_RED_LD + pc + 1];
             }
-            union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
-            __hip_atomic_store(reinterpret_cast<uint64_t*>(p.G2 + ((size_t)s * B + rg) * H + ug * 16 + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.ll) {
+              uint64_t* L = reinterpret_cast<uint64_t*>(p.G2) + ((size_t)s * B + rg) * H + ug * 16 + pc;
+              const uint64_t st = (uint64_t)(ep | (unsigned)s) << 32;
+              __hip_atomic_store(L, st | __builtin_bit_cast(unsigned, v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(L + 1, st | __builtin_bit_cast(unsigned, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
+              __hip_atomic_store(reinterpret_cast<uint64_t*>(p.G2 + ((size_t)s * B + rg) * H + ug * 16 + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!p.ll) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __syncthreads();
-      ++ph;
-      rc_arrive(p.bar, ph);
-      rc_wait(p.bar, ph);
+      if (!p.ll) {
+        __syncthreads();
+        ++ph;
+        rc_arrive(p.bar, ph);
+        rc_wait(p.bar, ph);
+      }
     }
     // ================= phase B': caption b
     if (isB) {
       // (1) cell backward of the thread's two units -> dgates (bf16) into the row buffer
+      float grec[2] = {0.f, 0.f};
+      if (s > 0 && p.ll) {
+        const uint64_t* L = reinterpret_cast<const uint64_t*>(p.G2) + ((size_t)s * B + b) * H;
+        const uint64_t* l0 = L + (tid < H ? tid : 0);
+        const uint64_t* l1 = L + (tid + 256 < H ? tid + 256 : 0);
+        const unsigned want = ep | (unsigned)s;
+        uint64_t w0, w1;
+        for (;;) {
+          w0 = __hip_atomic_load(l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1 = __hip_atomic_load(l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((unsigned)(w0 >> 32) == want && (unsigned)(w1 >> 32) == want)) break;
+        }
+        grec[0] = __builtin_bit_cast(float, (unsigned)w0); grec[1] = __builtin_bit_cast(float, (unsigned)w1);
+      } else if (s > 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int u = tid + 256 * q; if (u < H) grec[q] = p.G2[((size_t)s * B + b) * H + u]; }
+      }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int u = tid + 256 * q;
         if (u < H) {
-          float dh = d1[q] + d2[q];
-          if (s > 0) dh += p.G2[((size_t)s * B + b) * H + u];
+          float dh = d1[q] + d2[q] + grec[q];
           const LstmGrad gr = p.gru ? gru_point_bwd(dh + carry[q], av[q][0], av[q][1], av[q][2], av[q][3], cpv[q])
                                     : lstm_point_bwd(dh, carry[q], av[q][0], av[q][1], av[q][2], av[q][3], cv[q], cpv[q]);
           carry[q] = gr.dc_prev;
@@ -568,4 +595,5 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       for (int ch = 1; ch < RN_FCH; ++ch) p.dwacc[((size_t)ch * B + b) * A + tid] = 0.f;
     }
   }
+  if (p.ll && wg == 0 && tid == 0) __hip_atomic_store(p.epoch, (ep >> 6) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
