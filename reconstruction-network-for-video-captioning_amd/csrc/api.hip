@@ -84,6 +84,7 @@ struct recnet_handle {
   int persist_dec = 0;      // dec_chain.hpp: the decoder's teacher-forced forward chain as one launch
   float* dc_G1 = nullptr; void* dc_pan = nullptr;
   int persist_dec_bwd = 0;  // ... and its BPTT chain
+  int ctx_done = 0;         // the attended features of all steps were computed early (fwd_bwd_impl)
   int hoist_pending = 0, hoist_par = 0, encmean_hoisted = 0; const float* hoist_enc = nullptr;   // see hoist_side_work (abi_step.inc)
   float* dc_G2 = nullptr; void* dc_pan2 = nullptr;
   void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
