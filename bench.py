@@ -52,24 +52,38 @@ def cpu_baseline(kind, B, F, D, V, steps, warmup, cell="LSTM"):
 
 
 def roofline(eng, run_step, kind, precision, iters=5):
-    """Dominant kernel = the reconstructor's recurrent-step GEMM (forward form): T-1 dependent launches per
-    step, each streaming the packed recurrent weights once for a 100-row activation block.  `achieved` =
-    algorithmic bytes of one launch / its average duration, measured with hipEvents on the launch stream;
-    bound = HBM (weight streaming; the weights are cache-resident across steps, so this is the
-    conservative bound SURVEY.md §8d names).  run_step(site) -> (launches, avg ms)."""
+    """Dominant kernel = the longest of the persistent recurrent-chain kernels (one launch = all T dependent steps of
+    one chain, weights resident on chip, grid barrier / stamped hand-over per step), else the per-step recurrent GEMM.
+    `achieved` = algorithmic bytes of one launch (recnet_recurrent_step_bytes) / its average duration, measured with
+    hipEvents on the launch stream inside the replayed step; bound = HBM, the bound SURVEY.md §8d names — the chains are
+    latency-bound by their per-step exchange, so the fraction is small by construction.
+    run_step(site) -> (launches, avg ms)."""
     import torch
-    site = 3 if kind else 1
     torch.cuda.synchronize()
-    n, ms_raw = run_step(site)
-    kname = "%s (recurrent-step GEMM, %s)" % ("gemm_lds_kernel<false, false, 4, 3, 96>" if kind else "gemm_chain_kernel<1, 2, 1>", "reconstructor fwd" if kind else "decoder fwd")
-    which = 1 if kind else 0
-    if n == 0 and kind == "global":
-        # both reconstructor chains run as one persistent launch each (csrc/rec_chain.hpp: W_hh resident in registers,
-        # one grid barrier per time step).  The backward one is the longest kernel of the step.
-        site, which = 8, 4
+    # All four recurrent chains run as persistent launches when the shape allows (csrc/rec_chain.hpp, csrc/dec_chain.hpp):
+    # the dominant kernel is the longest of them.  Otherwise the per-step recurrent GEMM of the reconstructor / decoder.
+    cands = [(10, 6, "dec_chain_bwd_kernel (decoder BPTT chain, T steps in one launch)"),
+             (9, 5, "dec_chain_kernel (decoder forward chain, T steps in one launch)"),
+             (8, 4, "rec_chain_bwd_kernel<48, 3, 4, 1> (reconstructor backward chain, T steps in one launch)"),
+             (7, 3, "rec_chain_kernel<12, 2, 4, 4> (reconstructor forward chain, T steps in one launch)")]
+    best = None
+    chains = {}
+    for s_id, wh, nm in cands:
+        if wh in (3, 4) and kind != "global":
+            continue
+        n_, ms_ = run_step(s_id)
+        if n_ > 0:
+            chains[nm.split(" ")[0].split("<")[0]] = round(ms_ * 1e3, 1)
+        if n_ > 0 and (best is None or ms_ > best[1]):
+            best = (n_, ms_, s_id, wh, nm)
+    if best is not None:
+        n, ms_raw, site, which, kname = best
+    else:
+        site = 3 if kind else 1
+        which = 1 if kind else 0
         n, ms_raw = run_step(site)
-        kname = "rec_chain_bwd_kernel<48, 3, 4, 1> (reconstructor backward chain, T steps in one launch)"
-        if n == 0:      # RN_PERSIST_REC_BWD=0: the per-step backward GEMM dgates . W_hh
+        kname = "%s (recurrent-step GEMM, %s)" % ("gemm_lds_kernel<false, false, 4, 3, 96>" if kind else "gemm_chain_kernel<1, 2, 1>", "reconstructor fwd" if kind else "decoder fwd")
+        if n == 0 and kind == "global":
             site, which = 4, 2
             n, ms_raw = run_step(site)
             kname = "gemm_lds_kernel<false, true, 4, 4, 128> (recurrent-step GEMM, reconstructor bwd)"
@@ -88,14 +102,16 @@ def roofline(eng, run_step, kind, precision, iters=5):
     # FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py) — only valid for the configuration it was
     # collected on (global reconstructor, bf16, B=100, 28x1536)
     traffic = None
-    tf = os.path.join(ROOT, "profiles", {1: "r01_pmc_traffic_rec_fwd_gemm.json", 4: "r01_pmc_traffic_rec_chain_bwd.json"}.get(which, "-"))
-    if which in (1, 4) and kind == "global" and precision == "bf16" and eng.dims["B"] == 100 and eng.dims["D"] == 1536 and os.path.exists(tf):
+    tf = os.path.join(ROOT, "profiles", {1: "r01_pmc_traffic_rec_fwd_gemm.json", 4: "r01_pmc_traffic_rec_chain_bwd.json",
+                                         6: "r01_pmc_traffic_dec_chain_bwd.json", 5: "r01_pmc_traffic_dec_chain_fwd.json"}.get(which, "-"))
+    if which in (1, 4, 5, 6) and kind == "global" and precision == "bf16" and eng.dims["B"] == 100 and eng.dims["D"] == 1536 and os.path.exists(tf):
         traffic = int(json.load(open(tf))["traffic_bytes_per_launch"])
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
             "kernel": kname,
             "launches_timed": n, "avg_launch_us": round(ms * 1e3, 3), "bracket_us": round(ms_raw * 1e3, 3),
-            "event_pair_overhead_us": round(ms_null * 1e3, 3), "empty_kernel_us": round(f_empty * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch)}
+            "event_pair_overhead_us": round(ms_null * 1e3, 3), "empty_kernel_us": round(f_empty * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch),
+            "chain_kernel_brackets_us": chains}
 
 
 def main():

@@ -260,6 +260,8 @@ int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* s
 #define RECNET_SITE_REC_ATT_BWD 6
 #define RECNET_SITE_REC_CHAIN_FWD 7   /* global reconstructor, bf16: the whole forward chain as one persistent launch */
 #define RECNET_SITE_REC_CHAIN_BWD 8   /* ... and the whole backward chain                                              */
+#define RECNET_SITE_DEC_CHAIN_FWD 9   /* decoder, bf16, teacher-forced: the whole forward chain as one persistent launch */
+#define RECNET_SITE_DEC_CHAIN_BWD 10  /* ... and the whole BPTT chain                                                    */
 int recnet_profile_begin(recnet_handle* h, int32_t site);
 int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms);
 /* Same read-out without leaving profiling mode: when the bracketed launches were captured into a hipGraph (the event
@@ -283,7 +285,8 @@ int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, i
 /* Name / start / duration of the dominant kernel's launches inside the last train step are measured
  * by the caller with hipEvents; this returns the algorithmic bytes one recurrent-step launch moves. */
 double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which /*0 decoder fwd step, 1 reconstructor fwd step,
-    2 reconstructor bwd step, 3 / 4 one launch of the persistent reconstructor fwd / bwd chain over the last T*/);
+    2 reconstructor bwd step, 3 / 4 one launch of the persistent reconstructor fwd / bwd chain over the last T,
+    5 / 6 one launch of the persistent decoder fwd / BPTT chain*/);
 
 #ifdef __cplusplus
 }

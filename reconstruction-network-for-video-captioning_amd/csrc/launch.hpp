@@ -16,6 +16,8 @@
 // profile sites of the persistent reconstructor chains (rec_chain.hpp), one launch each per step
 #define RN_SITE_REC_CHAIN_FWD 7
 #define RN_SITE_REC_CHAIN_BWD 8
+#define RN_SITE_DEC_CHAIN_FWD 9
+#define RN_SITE_DEC_CHAIN_BWD 10
 
 // ---- gemm.hip
 int rn_gemm_bk(int prec);
