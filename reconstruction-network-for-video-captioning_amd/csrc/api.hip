@@ -14,7 +14,8 @@
 //   abi_search.inc           per-step decoder API, greedy / beam search
 //   abi_step.inc             sequence-level entry points and the fused train step (stream orchestration)
 //   abi_misc.inc             profiling hooks, bare GEMM entry points
-// Device code: kernels.hpp -> kernels_{util,decoder,reconstructor,search,optim}.hpp, gemm*.hpp (GEMMs), rec_step.hpp
+// Device code: kernels.hpp -> kernels_{util,decoder,reconstructor,search,optim}.hpp, gemm*.hpp (GEMMs), rec_step.hpp,
+// rec_chain.hpp / dec_chain.hpp (the four recurrent chains as persistent kernels)
 // (experimental fused step), common.hpp.
 #include <hip/hip_runtime.h>
 #include <math.h>
