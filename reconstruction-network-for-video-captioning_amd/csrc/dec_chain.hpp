@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   // Stamped hand-over (ll): a word is {fp32 value, stamp = launch epoch << 6 | t}, written by one 8-byte store, so the
   // consumer can poll the data itself: no acknowledgement wait, no flag, no barrier between phase A and phase B.  The
   // epoch (one more per launch, kept in device memory) makes the words of earlier launches stale.
-  const unsigned ep = p.ll ? (__hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 6) : 0u;
+  const unsigned ep0 = rc_epoch_read(p.epoch), ep = ep0 << 6, fb = ep0 << 7;
 
   for (int t = 0; t < p.T; ++t) {
     // input part of the gates of this step: independent of the chain, requested before any waiting
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
         __syncthreads();
         DC_TS(2);
         ++ph;
-        rc_arrive(p.bar, ph);
-        rc_wait(p.bar, ph);
+        rc_arrive(p.bar, fb + ph);
+        rc_wait(p.bar, fb + ph);
       }
       DC_TS(3);
     }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       }
       if (t + 1 < p.T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // (the stores below are issued after the arrive, see the end of the loop body)
-      if (t + 1 < p.T) { __syncthreads(); DC_TS(6); ++ph; rc_arrive(p.bar, ph); }
+      if (t + 1 < p.T) { __syncthreads(); DC_TS(6); ++ph; rc_arrive(p.bar, fb + ph); }
       bf16_t* Lt = p.Hlp + ((size_t)t * B + b) * p.ld_hlp;
       if (tid < (H >> 3)) *reinterpret_cast<bf16x8*>(Lt + tid * 8) = *reinterpret_cast<const bf16x8*>(hl + tid * 8);
       for (int j = H + tid; j < p.ld_hlp; j += 256) Lt[j] = (bf16_t)0.f;
@@ -286,16 +286,16 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
           a[0] = av[jj][0]; a[H] = av[jj][1]; a[2 * H] = av[jj][2]; a[3 * H] = av[jj][3];
         }
       }
-      if (t + 1 < p.T) rc_wait(p.bar, ph);
+      if (t + 1 < p.T) rc_wait(p.bar, fb + ph);
       DC_TS(7);
     } else if (t + 1 < p.T) {
       __syncthreads();
       ++ph;
-      rc_arrive(p.bar, ph);
-      rc_wait(p.bar, ph);
+      rc_arrive(p.bar, fb + ph);
+      rc_wait(p.bar, fb + ph);
     }
   }
-  if (p.ll && wg == 0 && tid == 0) __hip_atomic_store(p.epoch, (ep >> 6) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  rc_epoch_bump(p.epoch, ep0);
 }
 
 // =============================================================================================
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
   const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
   for (int j = tid; j < 64; j += 256) srow[W4 + 128 + j] = (bf16_t)0.f;
   unsigned ph = 0;
-  const unsigned ep = p.ll ? (__hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 6) : 0u;   // see dec_chain_kernel
+  const unsigned ep0 = rc_epoch_read(p.epoch), ep = ep0 << 6, fb = ep0 << 7;   // see rec_chain.hpp
 
   // saved tensors of step t for this thread's two units, and Wh[t][b][kk]
   float d1[2], d2[2], av[2][4], cv[2], cpv[2], whk;
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       if (!p.ll) {
         __syncthreads();
         ++ph;
-        rc_arrive(p.bar, ph);
-        rc_wait(p.bar, ph);
+        rc_arrive(p.bar, fb + ph);
+        rc_wait(p.bar, fb + ph);
       }
     }
     // ================= phase B': caption b
@@ -558,17 +558,17 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; rc_arrive(p.bar, ph); }
+      if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; rc_arrive(p.bar, fb + ph); }
       // ---- off the critical path: the row-major copy [dgates | dWh | 0 ..] for the deferred GEMMs
       bf16_t* Gt = p.dGx + ((size_t)t * B + b) * p.ld_dgx;
       for (int kg = tid; kg < (p.ld_dgx >> 3); kg += 256)
         *reinterpret_cast<bf16x8*>(Gt + kg * 8) = kg < (KA >> 3) ? *reinterpret_cast<const bf16x8*>(srow + kg * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (more) { prefetch(t - 1); rc_wait(p.bar, ph); }
+      if (more) { prefetch(t - 1); rc_wait(p.bar, fb + ph); }
     } else if (s + 1 < p.T) {
       __syncthreads();
       ++ph;
-      rc_arrive(p.bar, ph);
-      rc_wait(p.bar, ph);
+      rc_arrive(p.bar, fb + ph);
+      rc_wait(p.bar, fb + ph);
     }
   }
   // ---- the accumulators: dUv (+ operand copy, zero padded), dw
@@ -595,5 +595,5 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       for (int ch = 1; ch < RN_FCH; ++ch) p.dwacc[((size_t)ch * B + b) * A + tid] = 0.f;
     }
   }
-  if (p.ll && wg == 0 && tid == 0) __hip_atomic_store(p.epoch, (ep >> 6) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  rc_epoch_bump(p.epoch, ep0);
 }

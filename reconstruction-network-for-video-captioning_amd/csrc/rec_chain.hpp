@@ -24,7 +24,8 @@ struct RecChainArgs {
   const float* Xg;                // [T][B][4R] input part of the gates + biases
   float* H; float* C;             // [T][B][R]
   float* acts;                    // [T][B][4R] post-activation gates, for the backward
-  unsigned* bar;                  // grid barrier flags, one word per workgroup, zero at launch
+  unsigned* bar;                  // grid barrier flags, one word per workgroup (never cleared: see rc_epoch_read)
+  unsigned* epoch;
 };
 
 #define RC_MB 7               // 16-row blocks: B <= 112
@@ -43,6 +44,14 @@ __host__ __device__ inline size_t rc_pan_elems(int K) { return (size_t)(((K + 31
 //           arrivals of the R / 8 workgroups do not serialise on one address;
 //   wait:   wave 0 polls all flags (one agent-scope load per 64 workgroups) until every one has reached the step, then
 //           invalidates this CU's L1 and this XCD's L2 (acquire) so that the next loads of h_t come from memory.
+// Launch epoch: one word per chain kernel in device memory, read by every workgroup at the start and incremented by
+// workgroup 0 at the end (a workgroup that has passed a barrier knows every other one has started).  Barrier flags are
+// epoch << 7 | phase and stamped words carry epoch << 6 | step, so neither needs clearing between launches — in a replayed
+// hipGraph each clearing memset was a 6 us node on the critical path.
+__device__ __forceinline__ unsigned rc_epoch_read(const unsigned* epoch) { return __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rc_epoch_bump(unsigned* epoch, unsigned e) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) __hip_atomic_store(epoch, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void rc_arrive(unsigned* flags, unsigned step) {
   if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.y * gridDim.x + blockIdx.x, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -61,8 +70,9 @@ __device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
       const unsigned a1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned a2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned a3 = __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned m01 = a0 < a1 ? a0 : a1, m23 = a2 < a3 ? a2 : a3, v = m01 < m23 ? m01 : m23;
-      if (__all(v >= step)) break;
+      // flags count up across launches (base = launch epoch << 7, see rc_epoch_base): signed distance, wrap-safe
+      const bool ok = (int)(a0 - step) >= 0 && (int)(a1 - step) >= 0 && (int)(a2 - step) >= 0 && (int)(a3 - step) >= 0;
+      if (__all(ok)) break;
       __builtin_amdgcn_s_sleep(1);
     }
 #ifndef RC_PROBE_NO_FENCE
@@ -93,6 +103,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   const int kw0 = wave * (STEPS * 32);                   // this wave's K range
   const int kq = (lane >> 4) * 8;
   constexpr int NP = STEPS / 2;
+  const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
   const int rot = blockIdx.x % NP;                       // workgroups start at different k: spreads the L2 channels
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     if (more) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      rc_arrive(p.bar, (unsigned)(t + 1));
+      rc_arrive(p.bar, fb + (unsigned)(t + 1));
     }
     // ---- everything below is off the critical path of the chain
     float* Ht = p.H + (size_t)t * B * R;
@@ -270,9 +281,10 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
       }
     if (more) {
       load_x(t + 1);                                     // independent of the other workgroups: in flight across the barrier
-      rc_wait(p.bar, (unsigned)(t + 1));
+      rc_wait(p.bar, fb + (unsigned)(t + 1));
     }
   }
+  rc_epoch_bump(p.epoch, ep);
 }
 template <int RB, int CG> constexpr size_t rc_smem_bytes() { return (size_t)4 * RB * 16 * (CG * 16 + 1) * 4 + (size_t)RB * 16 * 4 * CG * 2; }
 
@@ -292,7 +304,7 @@ struct RecChainBwdArgs {
   bf16_t* dG; int ld_dg;           // [T][B][ld_dg] row-major gate gradients, zero padded
   const float* dh_direct; float dh_scale;   // [B][R] the part of d loss / d h_t that is the same for every t
   const float* acts; const float* C; const float* H;   // [T][B][4R], [T][B][R], [T][B][R]
-  unsigned* bar;
+  unsigned* bar; unsigned* epoch;
 };
 
 template <int STEPS, int PF, int RB, int CG>
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
   const int kw0 = wave * (STEPS * 32);
   const int kq = (lane >> 4) * 8;
+  const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
   const int rot = blockIdx.x % NP;
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
     if (more) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      rc_arrive(p.bar, (unsigned)(s + 1));
+      rc_arrive(p.bar, fb + (unsigned)(s + 1));
     }
     // ---- off the critical path: the row-major copy for the deferred weight-gradient GEMMs
     bf16_t* Gt = p.dG + (size_t)t * B * p.ld_dg;
@@ -459,9 +472,10 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
       }
     if (more) {
       prefetch(t - 1);
-      rc_wait(p.bar, (unsigned)(s + 1));
+      rc_wait(p.bar, fb + (unsigned)(s + 1));
     }
   }
+  rc_epoch_bump(p.epoch, ep);
 }
 template <int RB, int CG> constexpr size_t rc_bwd_smem_bytes() {
   return ((size_t)4 * RB * 16 * (16 * CG + 1) + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * CG * 2;
