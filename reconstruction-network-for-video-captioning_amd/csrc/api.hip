@@ -294,7 +294,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     h->persist_rec = (e ? atoi(e) : 1) && !h->fused_rec && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
-                     (h->R & 7) == 0 && h->R <= 1536 && h->R / 8 <= ncu;   // 12 k-steps of resident weights per wave
+                     (h->R & 7) == 0 && h->R <= 2048 && h->R / 8 <= ncu;   // <= 16 k-steps of resident weights per wave
     const char* ed = getenv("RN_PERSIST_DEC");
     const int N = 4 * h->H + h->A, NA = N / 16;
     h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 && h->A <= 128 &&

@@ -316,18 +316,26 @@ def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
 @pytest.mark.parametrize("env", [{"RN_PERSIST_REC": "0"}, {"RN_PERSIST_REC_BWD": "0"}, {"RN_PERSIST_MS": "1"}, {"RN_PERSIST_MS": "2"},
                                  {"RN_PERSIST_DEC": "0"}, {"RN_PERSIST_DEC_BWD": "0"}])
 def test_persistent_reconstructor_chain_variants(env, cell, monkeypatch):
+    _chain_variants(env, cell, monkeypatch, [100, 3, 48, 29, 8, 32, 16, 16], [(7 * i) % 9 for i in range(100)])
+
+
+@pytest.mark.parametrize("env", [{"RN_PERSIST_REC": "0"}, {"RN_PERSIST_REC_BWD": "0"}])
+def test_persistent_reconstructor_chains_R2048(env, monkeypatch):
+    """The largest reconstructor the chain kernels take (16 / 64 k-steps of resident weights per wave)."""
+    _chain_variants(env, "LSTM", monkeypatch, [60, 2, 2048, 29, 8, 32, 16, 16], [(5 * i) % 4 for i in range(60)])
+
+
+def _chain_variants(env, cell, monkeypatch, dims, lens):
     """The persistent chain kernels (csrc/rec_chain.hpp: reconstructor forward in both tilings and backward;
     csrc/dec_chain.hpp: decoder forward and BPTT) against the per-step paths they replace: same losses and gradients
     (fp32 summation order differs; the decoder BPTT also forms da = P . dgates from the bf16 dgates)."""
-    dims = [100, 3, 48, 29, 8, 32, 16, 16]
-    lens = [(7 * i) % 9 for i in range(100)]
     B, F, D, V, E, H, A, RA = dims
     decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, cell), 31)
     recP = GU.formula_params(GU.rec_shapes("global", H, D, RA, cell), 32)
     enc, targets = GU.make_batch(B, F, D, V, lens, 78)
 
     def run():
-        C, dec, rec = make_models(dims, "global", "bf16", decP, recP, cells=(cell, cell))
+        C, dec, rec = make_models(list(dims), "global", "bf16", decP, recP, cells=(cell, cell))
         step = R.TrainStep(dec, rec)
         T, w = step.prepare(targets.numpy())
         step.fwd_bwd(enc.cuda(), targets.cuda(), T, w, seed=6)
