@@ -87,6 +87,7 @@ struct recnet_handle {
   int persist_dec_bwd = 0;  // ... and its BPTT chain
   int side_pending = 0, side_T = 0, side_phase = 0, side_err = 0;   // side_after_decoder_fwd (abi_step.inc)
   const int64_t* side_targets = nullptr; const float* side_stepw = nullptr; const float* side_enc = nullptr;
+  int late_join = 0;
   int ctx_done = 0;         // the attended features of all steps were computed early (fwd_bwd_impl)
   int hoist_pending = 0, hoist_par = 0, encmean_hoisted = 0; const float* hoist_enc = nullptr;   // see hoist_side_work (abi_step.inc)
   float* dc_G2 = nullptr; void* dc_pan2 = nullptr;
