@@ -88,6 +88,7 @@ struct recnet_handle {
   int side_pending = 0, side_T = 0, side_phase = 0, side_err = 0;   // side_after_decoder_fwd (abi_step.inc)
   const int64_t* side_targets = nullptr; const float* side_stepw = nullptr; const float* side_enc = nullptr;
   int late_join = 0;
+  int ncu = 0;
   int ctx_done = 0;         // the attended features of all steps were computed early (fwd_bwd_impl)
   int hoist_pending = 0, hoist_par = 0, encmean_hoisted = 0; const float* hoist_enc = nullptr;   // see hoist_side_work (abi_step.inc)
   float* dc_G2 = nullptr; void* dc_pan2 = nullptr;
@@ -133,7 +134,7 @@ static size_t carve(recnet_handle* h, char* base) {
   const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
                ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
-  h->gbar = (uint32_t*)take(4096 + 64);   // up to four persistent launches x 256 flags, then the launch-epoch words
+  h->gbar = (uint32_t*)take(4096 + 64);   // (floats: 16 KB) per chain kernel 256 arrival flags + 256 release words; epochs behind   // up to four persistent launches x 256 flags, then the launch-epoch words
   h->dc_G1 = take(2 * Tm * B * (4 * H + A));   // fp32, or 8-byte stamped words
   h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
   h->dc_G2 = take(2 * Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
@@ -294,12 +295,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     int dev = 0, ncu = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    h->ncu = ncu;
     h->persist_rec = (e ? atoi(e) : 1) && !h->fused_rec && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
                      (h->R & 7) == 0 && h->R <= 2048 && h->R / 8 <= ncu;   // <= 16 k-steps of resident weights per wave
     const char* ed = getenv("RN_PERSIST_DEC");
     const int N = 4 * h->H + h->A, NA = N / 16;
     h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 && h->A <= 128 &&
-                     (N & 15) == 0 && h->B <= RC_PAN_ROWS && (NA > h->B ? NA : h->B) <= ncu;
+                     (N & 15) == 0 && h->B <= RC_PAN_ROWS && (NA > h->B ? NA : h->B) + 1 <= ncu;
     const char* eb = getenv("RN_PERSIST_REC_BWD");
     h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
   }
@@ -312,7 +314,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const int NAb = (h->H / 16) * DCB_PARTS;
     h->persist_dec_bwd = (eb ? atoi(eb) : 1) && h->persist_dec && h->use_wcomb_t && (h->H & 15) == 0 && (h->ldWS & 7) == 0 &&
-                         (NAb > h->B ? NAb : h->B) <= ncu;
+                         (NAb > h->B ? NAb : h->B) + 1 <= ncu;
   }
   h->need = carve(h, nullptr);
   *out = h;
@@ -393,7 +395,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   h->ws = (char*)workspace; h->ws_bytes = bytes;
   carve(h, h->ws);
   // stamped exchange buffers and the launch-epoch words start from zero (a stamp is never zero)
-  HIPCHK(hipMemset(h->gbar, 0, 4096 + 64)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
+  HIPCHK(hipMemset(h->gbar, 0, (4096 + 64) * 4)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
   HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * 4));
   h->gws_cur = h->gws;
   if (!h->s2) {

@@ -25,6 +25,7 @@ struct DecChainArgs {
   const float* Xe;                 // [T][B][4H] emb . W_e^T + biases
   float* G1;                       // [T][B][4H + A] exchange: recurrent pre-activations (ll: 8-byte words {value, stamp})
   unsigned* epoch; int ll;         // ll = 1: phase A -> B hand-over through stamped words instead of a grid barrier
+  int master;                      // 1: the last workgroup of the grid is the barrier master (rc_master_loop)
   bf16_t* Pan;                     // [T][rc_pan_elems(H)] exchange: h_t, k-group-major
   float* Hs; float* Cs; float* acts;   // [T][B][H], [T][B][H], [T][B][4H]
   bf16_t* Hlp; int ld_hlp;         // [T][B][ld_hlp] row-major operand copy of h_t, zero padded
@@ -102,6 +103,10 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   // consumer can poll the data itself: no acknowledgement wait, no flag, no barrier between phase A and phase B.  The
   // epoch (one more per launch, kept in device memory) makes the words of earlier launches stale.
   const unsigned ep0 = rc_epoch_read(p.epoch), ep = ep0 << 6, fb = ep0 << 7;
+  if (p.master && wg == (int)gridDim.x - 1) {
+    rc_master_loop(p.bar, p.bar + 256, (int)gridDim.x - 1, fb, (p.ll ? 1 : 2) * (p.T - 1));
+    return;
+  }
 
   for (int t = 0; t < p.T; ++t) {
     // input part of the gates of this step: independent of the chain, requested before any waiting
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
         DC_TS(2);
         ++ph;
         rc_arrive(p.bar, fb + ph);
-        rc_wait(p.bar, fb + ph);
+        { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
       }
       DC_TS(3);
     }
@@ -286,13 +291,13 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
           a[0] = av[jj][0]; a[H] = av[jj][1]; a[2 * H] = av[jj][2]; a[3 * H] = av[jj][3];
         }
       }
-      if (t + 1 < p.T) rc_wait(p.bar, fb + ph);
+      if (t + 1 < p.T) { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
       DC_TS(7);
     } else if (t + 1 < p.T) {
       __syncthreads();
       ++ph;
       rc_arrive(p.bar, fb + ph);
-      rc_wait(p.bar, fb + ph);
+      { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
     }
   }
   rc_epoch_bump(p.epoch, ep0);
@@ -319,7 +324,7 @@ struct DecChainBwdArgs {
   const float* acts; const float* Cs; const float* Hs;      // [T][B][4H], [T][B][H], [T][B][H]
   const float* Wh;                 // [T][B][A]
   float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh (ll: stamped 8-byte words)
-  unsigned* epoch; int ll;
+  unsigned* epoch; int ll; int master;
   bf16_t* Pan;                     // [T][rc_pan_elems(4H + A)] exchange (by chain step): rows [dgates | dWh]
   bf16_t* dGx; int ld_dgx;         // [T][B][ld_dgx]
   float* dUv; bf16_t* dUv_lp; int ld_dUv;                   // [B][F][A], [B F][ld_dUv]
@@ -391,6 +396,10 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
   for (int j = tid; j < 64; j += 256) srow[W4 + 128 + j] = (bf16_t)0.f;
   unsigned ph = 0;
   const unsigned ep0 = rc_epoch_read(p.epoch), ep = ep0 << 6, fb = ep0 << 7;   // see rec_chain.hpp
+  if (p.master && wg == (int)gridDim.x - 1) {
+    rc_master_loop(p.bar, p.bar + 256, (int)gridDim.x - 1, fb, (p.ll ? 1 : 2) * (p.T - 1));
+    return;
+  }
 
   // saved tensors of step t for this thread's two units, and Wh[t][b][kk]
   float d1[2], d2[2], av[2][4], cv[2], cpv[2], whk;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         __syncthreads();
         ++ph;
         rc_arrive(p.bar, fb + ph);
-        rc_wait(p.bar, fb + ph);
+        { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
       }
     }
     // ================= phase B': caption b
@@ -563,12 +572,12 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       bf16_t* Gt = p.dGx + ((size_t)t * B + b) * p.ld_dgx;
       for (int kg = tid; kg < (p.ld_dgx >> 3); kg += 256)
         *reinterpret_cast<bf16x8*>(Gt + kg * 8) = kg < (KA >> 3) ? *reinterpret_cast<const bf16x8*>(srow + kg * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (more) { prefetch(t - 1); rc_wait(p.bar, fb + ph); }
+      if (more) { prefetch(t - 1); { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); } }
     } else if (s + 1 < p.T) {
       __syncthreads();
       ++ph;
       rc_arrive(p.bar, fb + ph);
-      rc_wait(p.bar, fb + ph);
+      { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
     }
   }
   // ---- the accumulators: dUv (+ operand copy, zero padded), dw

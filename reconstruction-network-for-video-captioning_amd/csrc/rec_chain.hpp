@@ -26,6 +26,7 @@ struct RecChainArgs {
   float* acts;                    // [T][B][4R] post-activation gates, for the backward
   unsigned* bar;                  // grid barrier flags, one word per workgroup (never cleared: see rc_epoch_read)
   unsigned* epoch;
+  int master;                     // 1: gridDim.x has one extra column; block (gridDim.x - 1, 0) is the barrier master
 };
 
 #define RC_MB 7               // 16-row blocks: B <= 112
@@ -55,6 +56,9 @@ __device__ __forceinline__ void rc_epoch_bump(unsigned* epoch, unsigned e) {
 __device__ __forceinline__ void rc_arrive(unsigned* flags, unsigned step) {
   if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.y * gridDim.x + blockIdx.x, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void rc_arrive_at(unsigned* flags, int idx, unsigned step) {
+  if (threadIdx.x == 0) __hip_atomic_store(flags + idx, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
 #ifndef RC_PROBE_NO_BARRIER
   if (threadIdx.x < 64) {
@@ -83,6 +87,39 @@ __device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
   __syncthreads();
 }
 
+// Barrier through a master workgroup.  With every workgroup polling every flag, the 130-190 pollers (four wave loads each
+// per round, all to the same six lines) queue up at the memory side: the flag round cost 2.7 us, while an uncontended
+// store -> load hand-over between two CUs is 0.3-0.4 us (tools/micro/xcd_pingpong.hip).  Here one extra workgroup does
+// nothing but poll the arrival flags and, when all have reached a phase, write that phase into eight release words (one
+// 128-byte line per XCD-sized group of workgroups); the workers poll only their release word.
+__device__ __forceinline__ void rc_master_loop(unsigned* flags, unsigned* release, int n, unsigned fb, int phases) {
+  if (threadIdx.x >= 64) return;
+  const unsigned* f0 = flags + (threadIdx.x < n ? threadIdx.x : n - 1);
+  const unsigned* f1 = flags + (threadIdx.x + 64 < n ? threadIdx.x + 64 : n - 1);
+  const unsigned* f2 = flags + (threadIdx.x + 128 < n ? threadIdx.x + 128 : n - 1);
+  const unsigned* f3 = flags + (threadIdx.x + 192 < n ? threadIdx.x + 192 : n - 1);
+  for (int ph = 1; ph <= phases; ++ph) {
+    const unsigned step = fb + (unsigned)ph;
+    for (;;) {
+      const unsigned a0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned a1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned a2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned a3 = __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ok = (int)(a0 - step) >= 0 && (int)(a1 - step) >= 0 && (int)(a2 - step) >= 0 && (int)(a3 - step) >= 0;
+      if (__all(ok)) break;
+    }
+    if (threadIdx.x < 8) __hip_atomic_store(release + threadIdx.x * 32, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void rc_wait_release(const unsigned* release, unsigned step) {
+  if (threadIdx.x < 64) {
+    const unsigned* r = release + (blockIdx.x & 7) * 32;
+    while ((int)(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) {}
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
 // STEPS = k32-steps per wave (R <= 4 * 32 * STEPS, even); PF = activation prefetch distance in pairs of k-steps.
 // RB x CG = 16-row blocks x 16-column groups of a workgroup's tile: it owns UW = 4 CG hidden units (16 CG weight rows)
 // and reads RB * 16 of the 112 panel rows; gridDim = (R / UW, MS) with MS * RB * 16 >= 112.  <7, 2>: all rows, 8 units.
@@ -104,6 +141,11 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   const int kq = (lane >> 4) * 8;
   constexpr int NP = STEPS / 2;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
+  const int nwx = (int)gridDim.x - (p.master ? 1 : 0), widx = blockIdx.y * nwx + blockIdx.x;   // workers per row, my flag
+  if (p.master && (int)blockIdx.x == nwx) {
+    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1);
+    return;
+  }
   const int rot = blockIdx.x % NP;                       // workgroups start at different k: spreads the L2 channels
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
@@ -252,7 +294,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     if (more) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      rc_arrive(p.bar, fb + (unsigned)(t + 1));
+      rc_arrive_at(p.bar, widx, fb + (unsigned)(t + 1));
     }
     // ---- everything below is off the critical path of the chain
     float* Ht = p.H + (size_t)t * B * R;
@@ -281,7 +323,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
       }
     if (more) {
       load_x(t + 1);                                     // independent of the other workgroups: in flight across the barrier
-      rc_wait(p.bar, fb + (unsigned)(t + 1));
+      if (p.master) rc_wait_release(p.bar + 256, fb + (unsigned)(t + 1)); else rc_wait(p.bar, fb + (unsigned)(t + 1));
     }
   }
   rc_epoch_bump(p.epoch, ep);
@@ -304,7 +346,7 @@ struct RecChainBwdArgs {
   bf16_t* dG; int ld_dg;           // [T][B][ld_dg] row-major gate gradients, zero padded
   const float* dh_direct; float dh_scale;   // [B][R] the part of d loss / d h_t that is the same for every t
   const float* acts; const float* C; const float* H;   // [T][B][4R], [T][B][R], [T][B][R]
-  unsigned* bar; unsigned* epoch;
+  unsigned* bar; unsigned* epoch; int master;
 };
 
 template <int STEPS, int PF, int RB, int CG>
@@ -320,6 +362,11 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   const int kw0 = wave * (STEPS * 32);
   const int kq = (lane >> 4) * 8;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
+  const int nwx = (int)gridDim.x - (p.master ? 1 : 0), widx = blockIdx.y * nwx + blockIdx.x;
+  if (p.master && (int)blockIdx.x == nwx) {
+    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1);
+    return;
+  }
   const int rot = blockIdx.x % NP;
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
@@ -458,7 +505,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
     if (more) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      rc_arrive(p.bar, fb + (unsigned)(s + 1));
+      rc_arrive_at(p.bar, widx, fb + (unsigned)(s + 1));
     }
     // ---- off the critical path: the row-major copy for the deferred weight-gradient GEMMs
     bf16_t* Gt = p.dG + (size_t)t * B * p.ld_dg;
@@ -472,7 +519,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
       }
     if (more) {
       prefetch(t - 1);
-      rc_wait(p.bar, fb + (unsigned)(s + 1));
+      if (p.master) rc_wait_release(p.bar + 256, fb + (unsigned)(s + 1)); else rc_wait(p.bar, fb + (unsigned)(s + 1));
     }
   }
   rc_epoch_bump(p.epoch, ep);

@@ -12,14 +12,14 @@ int main(int argc, char** argv) {
   bf16_t *L, *W, *Pn; float *X, *C, *Hh, *acts; unsigned* bar;
   hipMalloc(&L, (size_t)T * B * R * 2); hipMalloc(&W, (size_t)4 * R * R * 2); hipMalloc(&X, (size_t)T * B * 4 * R * 4);
   hipMalloc(&C, (size_t)T * B * R * 4); hipMalloc(&Hh, (size_t)T * B * R * 4); hipMalloc(&acts, (size_t)T * B * 4 * R * 4);
-  hipMalloc(&bar, 1024); hipMalloc(&Pn, (size_t)T * R * RC_PAN_ROWS * 2); hipMemset(Pn, 0, (size_t)T * R * RC_PAN_ROWS * 2);
+  hipMalloc(&bar, 4096); hipMalloc(&Pn, (size_t)T * R * RC_PAN_ROWS * 2); hipMemset(Pn, 0, (size_t)T * R * RC_PAN_ROWS * 2);
   hipMemset(L, 0, (size_t)T * B * R * 2); hipMemset(W, 0, (size_t)4 * R * R * 2); hipMemset(X, 0, (size_t)T * B * 4 * R * 4);
   hipStream_t st; hipStreamCreate(&st);
   hipGraph_t g; hipGraphExec_t ge;
   hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   RecChainArgs a;
-  a.T = T; a.B = B; a.R = R; a.gru = 0; a.W = W; a.ldw = R; a.Hlp = L; a.ld_hlp = R; a.Pan = Pn; a.Xg = X; a.H = Hh; a.C = C; a.acts = acts; a.bar = bar; a.epoch = bar + 200;
-  hipMemsetAsync(bar, 0, 1024, st);
+  a.T = T; a.B = B; a.R = R; a.gru = 0; a.W = W; a.ldw = R; a.Hlp = L; a.ld_hlp = R; a.Pan = Pn; a.Xg = X; a.H = Hh; a.C = C; a.acts = acts; a.bar = bar; a.epoch = bar + 600; a.master = 0;
+  hipMemsetAsync(bar, 0, 4096, st);
 #ifdef RC_PROBE_MS2
   hipFuncSetAttribute(reinterpret_cast<const void*>(rec_chain_kernel<12, RC_PF, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rc_smem_bytes<4, 4>());
   const size_t sm = rc_smem_bytes<4, 4>();
