@@ -30,6 +30,18 @@ struct RecChainArgs {
 };
 
 #define RC_MB 7               // 16-row blocks: B <= 112
+// Acquire side of the barriers.  An agent-scope acquire fence is `buffer_inv sc1`: it drops every non-local line of the
+// XCD's L2 — under all other workgroups of the chain and under the batched GEMMs of the side stream — 120-190 times
+// per time step (measured: 0.12 ms of a 2.29 ms train step).  It is not needed here: (a) every exchange block has its own
+// address per time step and nobody touches it before the barrier that publishes it, so no L1 / L2 can hold a line of it
+// from an earlier step of this launch; (b) lines from an earlier LAUNCH are dropped by the acquire of the kernel dispatch
+// itself (the same mechanism every producer -> consumer pair of kernels on different XCDs relies on); (c) producers write
+// through (sc1 stores) and are acknowledged before they arrive at the barrier, so memory holds the data when the
+// consumer's first — necessarily missing — load goes out; (d) flags, release words and stamped words are read with sc1
+// loads.  RC_ACQUIRE_INV=1 compiles the fences back in (same results on every test).
+#ifndef RC_ACQUIRE_INV
+#define RC_ACQUIRE_INV 0
+#endif
 // Layout of the copy of h_t that the chain itself reads back.  An MFMA A-fragment load (16 rows x 32 k, 16 bytes per
 // lane) is issued by the texture unit 16 lanes at a time, and in a row-major matrix those 16 lanes are 16 different
 // rows = 16 different cache lines for 256 bytes (measured: ~58 clocks per wave load, 8 us per step for the 307 KB
@@ -80,7 +92,7 @@ __device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
       __builtin_amdgcn_s_sleep(1);
     }
 #ifndef RC_PROBE_NO_FENCE
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
   }
 #endif
@@ -115,7 +127,7 @@ __device__ __forceinline__ void rc_wait_release(const unsigned* release, unsigne
   if (threadIdx.x < 64) {
     const unsigned* r = release + (blockIdx.x & 7) * 32;
     while ((int)(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) {}
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }

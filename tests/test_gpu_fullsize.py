@@ -111,3 +111,33 @@ def test_step_is_a_pure_function_of_its_inputs():
             else:
                 assert torch.equal(a[k], b[k]), k
     assert torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("cell", ["LSTM", "GRU"])
+def test_chain_kernels_over_changing_batches_match_per_step_kernels(cell, monkeypatch):
+    """The persistent chain kernels keep per-time-step exchange buffers in the workspace and do not invalidate caches at
+    their barriers (csrc/rec_chain.hpp, RC_ACQUIRE_INV): run three DIFFERENT batches through one engine — every
+    buffer then holds the previous batch's data when the next one starts — and hold each against an engine running the
+    per-step kernels.  A stale line anywhere would show up as an O(1) error, not as rounding."""
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, cell), 21)
+    recP = GU.formula_params(GU.rec_shapes("global", H, D, RA, cell), 22)
+    _, dec_a, rec_a = make_models(list(DIMS), "global", "bf16", decP, recP, cells=(cell, cell))
+    step_a = R.TrainStep(dec_a, rec_a)
+    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC"):
+        monkeypatch.setenv(k, "0")
+    _, dec_b, rec_b = make_models(list(DIMS), "global", "bf16", decP, recP, cells=(cell, cell))
+    step_b = R.TrainStep(dec_b, rec_b)
+    for seed in (11, 12, 13):
+        enc = synthetic_features(B, F, D, seed=seed).cuda()
+        tg = synthetic_targets(B, V, seed=seed)
+        T, w = step_a.prepare(tg.numpy())
+        for st in (step_a, step_b):
+            st.fwd_bwd(enc, tg.cuda(), T, w, seed=seed)
+        torch.cuda.synchronize()
+        sa, sb = step_a.engine.scalar_dict(), step_b.engine.scalar_dict()
+        for k in ("dec_ce", "rec_mse"):
+            assert abs(sa[k] - sb[k]) <= 2e-4 * abs(sb[k]), (seed, k, sa[k], sb[k])
+        for grp, ma, mb in (("dec", dec_a, dec_b), ("rec", rec_a, rec_b)):
+            ga, gb = _grads(ma), _grads(mb)
+            for k in ga:
+                assert rel_err(ga[k].cpu().numpy(), gb[k].cpu().numpy()) <= 1e-2, (seed, grp, k)
