@@ -28,9 +28,15 @@ def _batches(n, seed=0):
     return out
 
 
+# bf16 with H % 16 == 0: the persistent chain kernels (csrc/dec_chain.hpp, csrc/rec_chain.hpp) inside replayed hipGraphs,
+# held bit for bit against the same kernels launched eagerly (every eager dispatch starts with a full acquire)
+DIMS_CHAIN = dict(DIMS, decoder_hidden_size=32, decoder_attn_size=16, precision="bf16")
+
+
+@pytest.mark.parametrize("dims", [DIMS, DIMS_CHAIN], ids=["f32", "bf16_chain_kernels"])
 @pytest.mark.parametrize("kind", ["global", "local"])
-def test_fit_equals_plain_steps_and_writes_checkpoints(kind, tmp_path):
-    C = R.make_config(use_recon=True, reconstructor_type=kind, **DIMS)
+def test_fit_equals_plain_steps_and_writes_checkpoints(kind, dims, tmp_path):
+    C = R.make_config(use_recon=True, reconstructor_type=kind, **dims)
     data = _batches(7)
     torch.manual_seed(0)
     tr = R.Trainer(C, V)                                  # 2 eager steps, then one hipGraph per T
