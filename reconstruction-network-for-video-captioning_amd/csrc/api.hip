@@ -395,7 +395,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   h->ws = (char*)workspace; h->ws_bytes = bytes;
   carve(h, h->ws);
   // stamped exchange buffers and the launch-epoch words start from zero (a stamp is never zero)
-  HIPCHK(hipMemset(h->gbar, 0, (4096 + 64) * 4)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
+  HIPCHK(hipMemset(h->gbar, 0, (4096 + 64) * 4)); HIPCHK(hipMemset(h->scal, 0, 64 * 4)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
   HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * 4));
   h->gws_cur = h->gws;
   if (!h->s2) {

@@ -26,6 +26,7 @@ struct DecChainArgs {
   float* G1;                       // [T][B][4H + A] exchange: recurrent pre-activations (ll: 8-byte words {value, stamp})
   unsigned* epoch; int ll;         // ll = 1: phase A -> B hand-over through stamped words instead of a grid barrier
   int master;                      // 1: the last workgroup of the grid is the barrier master (rc_master_loop)
+  float* poison;                   // see rc_give_up (rec_chain.hpp)
   bf16_t* Pan;                     // [T][rc_pan_elems(H)] exchange: h_t, k-group-major
   float* Hs; float* Cs; float* acts;   // [T][B][H], [T][B][H], [T][B][4H]
   bf16_t* Hlp; int ld_hlp;         // [T][B][ld_hlp] row-major operand copy of h_t, zero padded
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
         const uint64_t* lw = L + W4 + (tid < A ? tid : 0);
         const unsigned want = ep | (unsigned)t;
         uint64_t wv[8], ww;
+        unsigned spin = 0;
         for (;;) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) wv[j] = __hip_atomic_load(lc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) ok = ok && (unsigned)(wv[j] >> 32) == want;
           if (__all(ok)) break;
+          if (rc_give_up(p.bar, spin)) break;
         }
         if (live) {
 #pragma unroll
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
     }
   }
   rc_epoch_bump(p.epoch, ep0);
+  rc_poison(p.bar, p.poison);
 }
 
 // =============================================================================================
@@ -324,7 +328,7 @@ struct DecChainBwdArgs {
   const float* acts; const float* Cs; const float* Hs;      // [T][B][4H], [T][B][H], [T][B][H]
   const float* Wh;                 // [T][B][A]
   float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh (ll: stamped 8-byte words)
-  unsigned* epoch; int ll; int master;
+  unsigned* epoch; int ll; int master; float* poison;
   bf16_t* Pan;                     // [T][rc_pan_elems(4H + A)] exchange (by chain step): rows [dgates | dWh]
   bf16_t* dGx; int ld_dgx;         // [T][B][ld_dgx]
   float* dUv; bf16_t* dUv_lp; int ld_dUv;                   // [B][F][A], [B F][ld_dUv]
@@ -488,10 +492,12 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         const uint64_t* l1 = L + (tid + 256 < H ? tid + 256 : 0);
         const unsigned want = ep | (unsigned)s;
         uint64_t w0, w1;
+        unsigned spin = 0;
         for (;;) {
           w0 = __hip_atomic_load(l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           w1 = __hip_atomic_load(l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__all((unsigned)(w0 >> 32) == want && (unsigned)(w1 >> 32) == want)) break;
+          if (rc_give_up(p.bar, spin)) break;
         }
         grec[0] = __builtin_bit_cast(float, (unsigned)w0); grec[1] = __builtin_bit_cast(float, (unsigned)w1);
       } else if (s > 0) {
@@ -605,4 +611,5 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
     }
   }
   rc_epoch_bump(p.epoch, ep0);
+  rc_poison(p.bar, p.poison);
 }

@@ -27,6 +27,7 @@ struct RecChainArgs {
   unsigned* bar;                  // grid barrier flags, one word per workgroup (never cleared: see rc_epoch_read)
   unsigned* epoch;
   int master;                     // 1: gridDim.x has one extra column; block (gridDim.x - 1, 0) is the barrier master
+  float* poison;                  // see rc_give_up
 };
 
 #define RC_MB 7               // 16-row blocks: B <= 112
@@ -65,6 +66,21 @@ __device__ __forceinline__ unsigned rc_epoch_read(const unsigned* epoch) { retur
 __device__ __forceinline__ void rc_epoch_bump(unsigned* epoch, unsigned e) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) __hip_atomic_store(epoch, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Every wait in the chain kernels is bounded: a launch whose workgroups are not all resident (two such launches sharing
+// the GPU) would otherwise spin forever and take the device with it.  After ~2^22 polls (seconds) a waiter raises the
+// sticky word bar[257]; every wait of this and of later launches then falls through, and the kernel poisons the step's
+// total loss with NaN (rc_poison) — wrong loudly instead of hung.
+#define RC_SPIN_LIMIT (1u << 22)
+__device__ __forceinline__ bool rc_give_up(unsigned* bar, unsigned& spin) {
+  if ((++spin & 0x3ffu) != 0) return false;
+  if (spin <= RC_SPIN_LIMIT && __hip_atomic_load(bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return false;
+  __hip_atomic_store(bar + 257, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+__device__ __forceinline__ void rc_poison(unsigned* bar, float* poison) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && __hip_atomic_load(bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    *poison = __builtin_nanf("");
+}
 __device__ __forceinline__ void rc_arrive(unsigned* flags, unsigned step) {
   if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.y * gridDim.x + blockIdx.x, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -81,6 +97,7 @@ __device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
     const unsigned* f1 = flags + (threadIdx.x + 64 < n ? threadIdx.x + 64 : n - 1);
     const unsigned* f2 = flags + (threadIdx.x + 128 < n ? threadIdx.x + 128 : n - 1);
     const unsigned* f3 = flags + (threadIdx.x + 192 < n ? threadIdx.x + 192 : n - 1);
+    unsigned spin = 0;
     for (;;) {
       const unsigned a0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned a1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -89,6 +106,7 @@ __device__ __forceinline__ void rc_wait(unsigned* flags, unsigned step) {
       // flags count up across launches (base = launch epoch << 7, see rc_epoch_base): signed distance, wrap-safe
       const bool ok = (int)(a0 - step) >= 0 && (int)(a1 - step) >= 0 && (int)(a2 - step) >= 0 && (int)(a3 - step) >= 0;
       if (__all(ok)) break;
+      if (rc_give_up(flags, spin)) break;
       __builtin_amdgcn_s_sleep(1);
     }
 #ifndef RC_PROBE_NO_FENCE
@@ -110,6 +128,7 @@ __device__ __forceinline__ void rc_master_loop(unsigned* flags, unsigned* releas
   const unsigned* f1 = flags + (threadIdx.x + 64 < n ? threadIdx.x + 64 : n - 1);
   const unsigned* f2 = flags + (threadIdx.x + 128 < n ? threadIdx.x + 128 : n - 1);
   const unsigned* f3 = flags + (threadIdx.x + 192 < n ? threadIdx.x + 192 : n - 1);
+  unsigned spin = 0;
   for (int ph = 1; ph <= phases; ++ph) {
     const unsigned step = fb + (unsigned)ph;
     for (;;) {
@@ -119,6 +138,7 @@ __device__ __forceinline__ void rc_master_loop(unsigned* flags, unsigned* releas
       const unsigned a3 = __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool ok = (int)(a0 - step) >= 0 && (int)(a1 - step) >= 0 && (int)(a2 - step) >= 0 && (int)(a3 - step) >= 0;
       if (__all(ok)) break;
+      if (rc_give_up(flags, spin)) break;
     }
     if (threadIdx.x < 8) __hip_atomic_store(release + threadIdx.x * 32, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -126,7 +146,8 @@ __device__ __forceinline__ void rc_master_loop(unsigned* flags, unsigned* releas
 __device__ __forceinline__ void rc_wait_release(const unsigned* release, unsigned step) {
   if (threadIdx.x < 64) {
     const unsigned* r = release + (blockIdx.x & 7) * 32;
-    while ((int)(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) {}
+    unsigned spin = 0;
+    while ((int)(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) { if (rc_give_up(const_cast<unsigned*>(release) - 256, spin)) break; }
     if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -339,6 +360,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     }
   }
   rc_epoch_bump(p.epoch, ep);
+  rc_poison(p.bar, p.poison);
 }
 template <int RB, int CG> constexpr size_t rc_smem_bytes() { return (size_t)4 * RB * 16 * (CG * 16 + 1) * 4 + (size_t)RB * 16 * 4 * CG * 2; }
 
@@ -358,7 +380,7 @@ struct RecChainBwdArgs {
   bf16_t* dG; int ld_dg;           // [T][B][ld_dg] row-major gate gradients, zero padded
   const float* dh_direct; float dh_scale;   // [B][R] the part of d loss / d h_t that is the same for every t
   const float* acts; const float* C; const float* H;   // [T][B][4R], [T][B][R], [T][B][R]
-  unsigned* bar; unsigned* epoch; int master;
+  unsigned* bar; unsigned* epoch; int master; float* poison;
 };
 
 template <int STEPS, int PF, int RB, int CG>
@@ -535,6 +557,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
     }
   }
   rc_epoch_bump(p.epoch, ep);
+  rc_poison(p.bar, p.poison);
 }
 template <int RB, int CG> constexpr size_t rc_bwd_smem_bytes() {
   return ((size_t)4 * RB * 16 * (16 * CG + 1) + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * CG * 2;
