@@ -275,6 +275,9 @@ EDGE = {
     "H32_A16_persistent_decoder": ([100, 5, 48, 29, 8, 32, 16, 16], [(7 * i) % 9 for i in range(100)]),
     "H48_A40_F3_partial_ksteps": ([37, 3, 32, 29, 8, 48, 40, 16], [(5 * i) % 8 for i in range(37)]),
     "H512_A128_one_chunk": ([9, 4, 32, 29, 8, 512, 128, 16], [3, 1, 4, 1, 5, 2, 6, 5, 3]),
+    "H32_T1_chain_without_barriers": ([5, 3, 32, 29, 8, 32, 16, 16], [0, 0, 0, 0, 0]),
+    "H32_T2_one_hand_over": ([70, 3, 32, 29, 8, 32, 16, 16], [i % 2 for i in range(70)]),
+    "H32_T31_longest": ([3, 3, 32, 29, 8, 32, 16, 16], [30, 7, 30]),
 }
 
 
