@@ -18,15 +18,15 @@ int main(int argc, char** argv) {
   hipGraph_t g; hipGraphExec_t ge;
   hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   RecChainArgs a;
-  a.T = T; a.B = B; a.R = R; a.gru = 0; a.W = W; a.ldw = R; a.Hlp = L; a.ld_hlp = R; a.Pan = Pn; a.Xg = X; a.H = Hh; a.C = C; a.acts = acts; a.bar = bar; a.epoch = bar + 600; a.master = 0; a.poison = (float*)(bar + 700);
+  a.T = T; a.B = B; a.R = R; a.gru = 0; a.W = W; a.ldw = R; a.Hlp = L; a.ld_hlp = R; a.Pan = Pn; a.Xg = X; a.H = Hh; a.C = C; a.acts = acts; a.bar = bar; a.epoch = bar + 600; a.master = getenv("MASTER") ? atoi(getenv("MASTER")) : 1; a.poison = (float*)(bar + 700);
   hipMemsetAsync(bar, 0, 4096, st);
 #ifdef RC_PROBE_MS2
   hipFuncSetAttribute(reinterpret_cast<const void*>(rec_chain_kernel<12, RC_PF, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rc_smem_bytes<4, 4>());
   const size_t sm = rc_smem_bytes<4, 4>();
-  hipLaunchKernelGGL((rec_chain_kernel<12, RC_PF, 4, 4>), dim3(R / 16, 2), dim3(256), sm, st, a);
+  hipLaunchKernelGGL((rec_chain_kernel<12, RC_PF, 4, 4>), dim3(R / 16 + a.master, 2), dim3(256), sm, st, a);
 #else
   const size_t sm = rc_smem_bytes<7, 2>();
-  hipLaunchKernelGGL((rec_chain_kernel<12, RC_PF, 7, 2>), dim3(R / 8, 1), dim3(256), sm, st, a);
+  hipLaunchKernelGGL((rec_chain_kernel<12, RC_PF, 7, 2>), dim3(R / 8 + a.master, 1), dim3(256), sm, st, a);
 #endif
   hipStreamEndCapture(st, &g); hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
