@@ -88,6 +88,7 @@ struct recnet_handle {
   int side_pending = 0, side_T = 0, side_phase = 0, side_err = 0;   // side_after_decoder_fwd (abi_step.inc)
   const int64_t* side_targets = nullptr; const float* side_stepw = nullptr; const float* side_enc = nullptr;
   int late_join = 0;
+  int mp_done = 0;          // h->mp holds the mean-pooled decoder states of the last decoder forward (dec_chain_kernel)
   int ncu = 0;
   int ctx_done = 0;         // the attended features of all steps were computed early (fwd_bwd_impl)
   int hoist_pending = 0, hoist_par = 0, encmean_hoisted = 0; const float* hoist_enc = nullptr;   // see hoist_side_work (abi_step.inc)

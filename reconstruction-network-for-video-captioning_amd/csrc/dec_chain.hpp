@@ -27,6 +27,7 @@ struct DecChainArgs {
   unsigned* epoch; int ll;         // ll = 1: phase A -> B hand-over through stamped words instead of a grid barrier
   int master;                      // 1: the last workgroup of the grid is the barrier master (rc_master_loop)
   float* poison;                   // see rc_give_up (rec_chain.hpp)
+  float* mp; float mp_scale;       // optional: mp_scale * sum_t h_t [B][H] (the global reconstructor's mean-pooled input)
   bf16_t* Pan;                     // [T][rc_pan_elems(H)] exchange: h_t, k-group-major
   float* Hs; float* Cs; float* acts;   // [T][B][H], [T][B][H], [T][B][4H]
   bf16_t* Hlp; int ld_hlp;         // [T][B][ld_hlp] row-major operand copy of h_t, zero padded
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   const bool live = isB && u < H;
   const int col = g * H + u;
   Raw8<bf16_t> pv[32];
-  float uvr[8][2], wk[2], bk[2], cpre[2] = {0.f, 0.f};
+  float uvr[8][2], wk[2], bk[2], cpre[2] = {0.f, 0.f}, hs_sum[2] = {0.f, 0.f};
   {
     const bf16_t* pp = p.P + (size_t)b * F * p.ldp + (live ? col : 0);
 #pragma unroll
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
             hv[jj] = r.h; av[jj][0] = r.i; av[jj][1] = r.f; av[jj][2] = r.g; av[jj][3] = r.o; cpre[jj] = r.c; cn[jj] = r.c;
           }
           hl[uu] = (bf16_t)hv[jj];
+          hs_sum[jj] += hv[jj];
         }
       }
       __syncthreads();
@@ -302,6 +304,10 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       rc_arrive(p.bar, fb + ph);
       { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
     }
+  }
+  if (p.mp && isB) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) { const int uu = tid + 256 * jj; if (uu < H) p.mp[(size_t)b * H + uu] = hs_sum[jj] * p.mp_scale; }
   }
   rc_epoch_bump(p.epoch, ep0);
   rc_poison(p.bar, p.poison);

@@ -28,6 +28,7 @@ struct RecChainArgs {
   unsigned* epoch;
   int master;                     // 1: gridDim.x has one extra column; block (gridDim.x - 1, 0) is the barrier master
   float* poison;                  // see rc_give_up
+  float* hmean; bf16_t* hmean_lp; int ld_hmean;   // mean_t h_t [B][R] (+ operand copy, zero padded): what the output layer reads
 };
 
 #define RC_MB 7               // 16-row blocks: B <= 112
@@ -200,11 +201,12 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   constexpr int CPT = (ROWS * UW + 255) / 256;
   float xg[CPT][4], cpv[CPT];
   bool mine[CPT];
+  float hsum[CPT];                                       // sum_t h_t of this thread's cells (the output layer wants the mean)
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
     const int rg = r0 + (tid + c * 256) / UW;
     mine[c] = rg >= own_lo && rg < own_lo + own && rg < B;
-    cpv[c] = 0.f;
+    cpv[c] = 0.f; hsum[c] = 0.f;
   }
   auto load_x = [&](int t) {
     const float* X = p.Xg + (size_t)t * B * 4 * R;
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
         hv[c] = r.h; av[c][0] = r.i; av[c][1] = r.f; av[c][2] = r.g; av[c][3] = r.o; cpv[c] = r.c;
       }
       if (cell < ROWS * UW) hl[cell] = (bf16_t)hv[c];
+      hsum[c] += hv[c];
     }
     __syncthreads();
     // the only data another workgroup waits for: 16 bytes per (row, 8 units), written through to memory,
@@ -358,6 +361,23 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
       load_x(t + 1);                                     // independent of the other workgroups: in flight across the barrier
       if (p.master) rc_wait_release(p.bar + 256, fb + (unsigned)(t + 1)); else rc_wait(p.bar, fb + (unsigned)(t + 1));
     }
+  }
+  // mean_t h_t (train.py:96-98 averages the outputs; the output layer is linear, so it runs once on the mean)
+  if (p.hmean) {
+    const float sc = 1.0f / (float)p.T;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      if (mine[c]) {
+        const int row = r0 + cell / UW, u = u0 + cell % UW;
+        const float m = hsum[c] * sc;
+        p.hmean[(size_t)row * R + u] = m;
+        p.hmean_lp[(size_t)row * p.ld_hmean + u] = (bf16_t)m;
+      }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+      for (int j = tid; j < B * (p.ld_hmean - R); j += 256)
+        p.hmean_lp[(size_t)(j / (p.ld_hmean - R)) * p.ld_hmean + R + j % (p.ld_hmean - R)] = (bf16_t)0.f;
   }
   rc_epoch_bump(p.epoch, ep);
   rc_poison(p.bar, p.poison);

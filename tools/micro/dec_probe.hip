@@ -21,7 +21,7 @@ int main() {
   c.Pan = dalloc<bf16_t>((size_t)T * rc_pan_elems(H));
   c.Hs = dalloc<float>((size_t)T * B * H); c.Cs = dalloc<float>((size_t)T * B * H); c.acts = dalloc<float>((size_t)T * B * 4 * H);
   c.Hlp = dalloc<bf16_t>((size_t)T * B * H); c.ld_hlp = H; c.Wh = dalloc<float>((size_t)T * B * A); c.att = dalloc<float>((size_t)T * B * F);
-  c.bar = dalloc<unsigned>(1024); c.poison = dalloc<float>(4); c.master = getenv("MASTER") ? atoi(getenv("MASTER")) : 1; c.ts = dalloc<unsigned long long>((size_t)T * 12);
+  c.bar = dalloc<unsigned>(1024); c.poison = dalloc<float>(4); c.mp = nullptr; c.mp_scale = 1.f; c.master = getenv("MASTER") ? atoi(getenv("MASTER")) : 1; c.ts = dalloc<unsigned long long>((size_t)T * 12);
   hipStream_t st; hipStreamCreate(&st);
   const int NA = N / 16;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -18,7 +18,7 @@ int main(int argc, char** argv) {
   hipGraph_t g; hipGraphExec_t ge;
   hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   RecChainArgs a;
-  a.T = T; a.B = B; a.R = R; a.gru = 0; a.W = W; a.ldw = R; a.Hlp = L; a.ld_hlp = R; a.Pan = Pn; a.Xg = X; a.H = Hh; a.C = C; a.acts = acts; a.bar = bar; a.epoch = bar + 600; a.master = getenv("MASTER") ? atoi(getenv("MASTER")) : 1; a.poison = (float*)(bar + 700);
+  a.T = T; a.B = B; a.R = R; a.gru = 0; a.W = W; a.ldw = R; a.Hlp = L; a.ld_hlp = R; a.Pan = Pn; a.Xg = X; a.H = Hh; a.C = C; a.acts = acts; a.bar = bar; a.epoch = bar + 600; a.master = getenv("MASTER") ? atoi(getenv("MASTER")) : 1; a.poison = (float*)(bar + 700); a.hmean = nullptr; a.hmean_lp = nullptr; a.ld_hmean = R;
   hipMemsetAsync(bar, 0, 4096, st);
 #ifdef RC_PROBE_MS2
   hipFuncSetAttribute(reinterpret_cast<const void*>(rec_chain_kernel<12, RC_PF, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rc_smem_bytes<4, 4>());
