@@ -62,20 +62,25 @@ def roofline(eng, run_step, kind, precision, iters=5):
     torch.cuda.synchronize()
     # All four recurrent chains run as persistent launches when the shape allows (csrc/rec_chain.hpp, csrc/dec_chain.hpp):
     # the dominant kernel is the longest of them.  Otherwise the per-step recurrent GEMM of the reconstructor / decoder.
-    cands = [(10, 6, "dec_chain_bwd_kernel (decoder BPTT chain, T steps in one launch)"),
-             (9, 5, "dec_chain_kernel (decoder forward chain, T steps in one launch)"),
+    cands = [(9, 5, "dec_chain_kernel (decoder forward chain, T steps in one launch)"),
+             (10, 6, "dec_chain_bwd_kernel (decoder BPTT chain, T steps in one launch)"),
              (8, 4, "rec_chain_bwd_kernel<48, 3, 4, 1> (reconstructor backward chain, T steps in one launch)"),
              (7, 3, "rec_chain_kernel<12, 2, 4, 4> (reconstructor forward chain, T steps in one launch)")]
     best = None
     chains = {}
+    meas = []
     for s_id, wh, nm in cands:
         if wh in (3, 4) and kind != "global":
             continue
         n_, ms_ = run_step(s_id)
         if n_ > 0:
             chains[nm.split(" ")[0].split("<")[0]] = round(ms_ * 1e3, 1)
-        if n_ > 0 and (best is None or ms_ > best[1]):
-            best = (n_, ms_, s_id, wh, nm)
+            meas.append((n_, ms_, s_id, wh, nm))
+    if meas:
+        # the chains of the benchmark shape are within a few percent of each other: the first in the list above that is
+        # within 5 % of the longest is reported, so that the choice does not flip from run to run
+        top = max(m[1] for m in meas)
+        best = next(m for m in meas if m[1] >= 0.95 * top)
     if best is not None:
         n, ms_raw, site, which, kname = best
     else:
@@ -103,8 +108,9 @@ def roofline(eng, run_step, kind, precision, iters=5):
     # collected on (global reconstructor, bf16, B=100, 28x1536)
     traffic = None
     tf = os.path.join(ROOT, "profiles", {1: "r01_pmc_traffic_rec_fwd_gemm.json", 4: "r01_pmc_traffic_rec_chain_bwd.json",
-                                         6: "r01_pmc_traffic_dec_chain_bwd.json", 5: "r01_pmc_traffic_dec_chain_fwd.json"}.get(which, "-"))
-    if which in (1, 4, 5, 6) and kind == "global" and precision == "bf16" and eng.dims["B"] == 100 and eng.dims["D"] == 1536 and os.path.exists(tf):
+                                         6: "r01_pmc_traffic_dec_chain_bwd.json", 5: "r01_pmc_traffic_dec_chain_fwd.json",
+                                         3: "r01_pmc_traffic_rec_chain_fwd.json"}.get(which, "-"))
+    if which in (1, 3, 4, 5, 6) and kind == "global" and precision == "bf16" and eng.dims["B"] == 100 and eng.dims["D"] == 1536 and os.path.exists(tf):
         traffic = int(json.load(open(tf))["traffic_bytes_per_launch"])
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -224,6 +230,10 @@ def main():
                     return
                 eng.train_step_dev(enc, targets, T, w, step.step_impl.seed_base, 3)
             s_id = site if site > 0 else 5
+            if site >= 7:
+                # a chain kernel runs for hundreds of microseconds: bracketed in eager launches of the step (event
+                # records inside a replayed graph can be scheduled long before the node they precede)
+                return eng.profile_site(s_id, one, 5)
             if args.graph and not step.reduce:
                 return eng.profile_site_graph(s_id, one)
             return eng.profile_site(s_id, one if site < 0 else (lambda: step(enc, targets, T, w)), 5)
