@@ -236,7 +236,8 @@ def main():
                 return eng.profile_site(s_id, one, 5)
             if args.graph and not step.reduce:
                 return eng.profile_site_graph(s_id, one)
-            return eng.profile_site(s_id, one if site < 0 else (lambda: step(enc, targets, T, w)), 5)
+            # (never the data-parallel step itself: this runs on rank 0 only, a collective here would wait for ever)
+            return eng.profile_site(s_id, one, 5)
         prof = roofline(eng, prof_pass, kind, args.precision)
         out = {
             "metric": "captions/sec (train step) MSVD bs=100 28x1536 feats", "value": round(Bg * 1e3 / ms, 1),
