@@ -457,7 +457,7 @@ class TrainStep:
 
 
 class GraphedStep:
-    """Replays the train step from captured hipGraphs (one per fixed T): the step is ~340 dependent
+    """Replays the train step from captured hipGraphs (one per fixed T): the step is ~100 (per-step kernels: ~340) dependent
     launches, so eager launching is host-bound; a graph removes the launch overhead.  The optimiser
     step count and the dropout seed advance on the device (recnet_train_step_*_dev), so every replay is
     a new training step.
