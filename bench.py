@@ -51,6 +51,29 @@ def cpu_baseline(kind, B, F, D, V, steps, warmup, cell="LSTM"):
     return B / med, torch.get_num_threads(), med
 
 
+def algorithmic_flops(kind, B, F, D, T, V=4188, E=468, H=512, A=128, RA=128):
+    """loop invariants counted once, multiply-add = 2, backward = 2 x forward (train = 3 x)."""
+    R = D
+    per = 2 * F * D * A + T * (2 * H * A + 2 * F * A + 2 * F * D + 8 * H * (E + D + H) + 2 * H * V)
+    if kind == "local":
+        per += 2 * T * H * RA + F * (2 * R * RA + 2 * T * RA + 2 * T * H + 8 * R * (H + R) + 2 * R * R)
+    elif kind == "global":
+        per += T * (8 * R * (2 * H + R) + 2 * R * R)
+    return 3.0 * per * B
+
+
+def algorithmic_hbm_bytes(kind, B, F, D, V=4188, E=468, H=512, A=128, RA=128):
+    """optimiser + regulariser traffic (36 B / parameter with AMSGrad, 28 B without) + the inputs."""
+    R = D
+    p_dec = A + V * E + A * H + A * D + A + 4 * H * (E + D) + 4 * H * H + 8 * H + V * H + V
+    p_rec = 0
+    if kind == "local":
+        p_rec = RA + RA * R + RA * H + RA + 4 * R * H + 4 * R * R + 8 * R + R * R + R
+    elif kind == "global":
+        p_rec = 4 * R * 2 * H + 4 * R * R + 8 * R + R * R + R
+    return 36.0 * p_dec + 28.0 * p_rec + 4.0 * B * F * D + 8.0 * 31 * B
+
+
 def roofline(eng, run_step, kind, precision, iters=5):
     """Dominant kernel = the longest of the persistent recurrent-chain kernels (one launch = all T dependent steps of
     one chain, weights resident on chip, grid barrier / stamped hand-over per step), else the per-step recurrent GEMM.

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RECNET_ABI_VERSION 2
+#define RECNET_ABI_VERSION 3
 #define RECNET_OK 0
 #define RECNET_EINVAL (-1)      /* bad dimension / null pointer / unsupported variant */
 #define RECNET_ESTATE (-2)      /* call order violated (e.g. backward before forward) */
@@ -282,11 +282,30 @@ int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, c
 int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, int32_t b_col, int32_t ldb, float* C,
                      int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
                      int32_t splitk, float* splitk_ws, int32_t tag, void* stream);
+/* One reconstructor step with the reference's per-step semantics — GlobalReconstructor.forward(input, hidden,
+ * decoder_hiddens) (models/global_reconstructor.py:30-46, called at train.py:94) and LocalReconstructor.forward(hidden,
+ * decoder_hiddens) (models/local_reconstructor.py:37-55, called at train.py:123).  input [B][H] (global only: the layer-0
+ * slice of decoder_hiddens[t]); hr_in / cr_in [B][R] or NULL for the zero state (GRU: cr_* unused); decoder_hiddens
+ * [T][B][H] fp32, or NULL to reuse the loop invariants of the previous call; out [B][R] = out(h'), hr_out / cr_out
+ * [B][R].  t indexes the dropout mask of this call (the reference draws a fresh mask per call).  Forward only. */
+int recnet_reconstructor_step(recnet_handle* h, const float* input, const float* hr_in, const float* cr_in,
+                              const float* decoder_hiddens, int32_t T, float* out, float* hr_out, float* cr_out,
+                              int32_t train, uint32_t seed, int32_t t, void* stream);
+/* Health of the persistent chain kernels (bounded waits): status bits 1/2 reconstructor fwd/bwd chain, 4/8 decoder
+ * fwd/BPTT chain, 16/32 local reconstructor fwd/bwd chain gave up a wait; 256 the step's loss was poisoned (NaN) and the
+ * optimiser kernels skip their updates.  Synchronises `stream`.  recnet_chain_reset clears the sticky words;
+ * disable_persistent != 0 switches the handle to the per-step kernels for every later call. */
+int recnet_chain_status(recnet_handle* h, int32_t* status_out, void* stream);
+int recnet_chain_reset(recnet_handle* h, int32_t disable_persistent, void* stream);
 /* Name / start / duration of the dominant kernel's launches inside the last train step are measured
- * by the caller with hipEvents; this returns the algorithmic bytes one recurrent-step launch moves. */
+ * by the caller with hipEvents; this returns the ALGORITHMIC bytes of one launch: loop invariants once, every input /
+ * saved tensor once.  The step-to-step exchange blocks of a persistent chain kernel are not part of it. */
 double recnet_recurrent_step_bytes(const recnet_handle* h, int32_t which /*0 decoder fwd step, 1 reconstructor fwd step,
     2 reconstructor bwd step, 3 / 4 one launch of the persistent reconstructor fwd / bwd chain over the last T,
     5 / 6 one launch of the persistent decoder fwd / BPTT chain*/);
+/* Bytes of the exchange blocks (h_t / dgates_t panels, stamped words) one launch of chain kernel `which` (3..6) writes
+ * and reads back: implementation traffic, reported beside the algorithmic bytes. */
+double recnet_chain_exchange_bytes(const recnet_handle* h, int32_t which);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 REC_NONE, REC_GLOBAL, REC_LOCAL = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
@@ -77,6 +77,7 @@ EXPORTS = {
     "recnet_gemm": (_i, [_i, C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _f,
                          _i, _i, C.c_void_p, C.c_void_p]),
     "recnet_recurrent_step_bytes": (_d, [C.c_void_p, _i]),
+    "recnet_chain_exchange_bytes": (_d, [C.c_void_p, _i]),
 }
 
 _lib = None
@@ -136,3 +137,6 @@ EXPORTS["recnet_train_step_part_dev"] = (_i, [C.c_void_p, _i, C.c_void_p, C.c_vo
 EXPORTS["recnet_decoder_prepare"] = (_i, [C.c_void_p, C.c_void_p, C.c_void_p])
 EXPORTS["recnet_greedy_search"] = (_i, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p])
 EXPORTS["recnet_beam_search"] = (_i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_void_p, C.c_void_p])
+EXPORTS["recnet_reconstructor_step"] = (_i, [C.c_void_p] * 5 + [_i] + [C.c_void_p] * 3 + [_i, C.c_uint32, _i, C.c_void_p])
+EXPORTS["recnet_chain_status"] = (_i, [C.c_void_p, C.POINTER(_i), C.c_void_p])
+EXPORTS["recnet_chain_reset"] = (_i, [C.c_void_p, _i, C.c_void_p])

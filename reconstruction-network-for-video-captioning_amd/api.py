@@ -170,6 +170,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._ms.step += 1
         skip = _lib.OPT_SKIP_RECONSTRUCTOR if self._which == 0 else _lib.OPT_SKIP_DECODER
         eng.optimizer_step(self._ms.step, skip)
+        self._ms.model.mark_weights_changed()
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._ms.step))
 
@@ -445,6 +446,12 @@ class TrainStep:
         if self.reconstructor:
             self.reconstructor["_state"].step = ms.step
         self.engine.optimizer_step(ms.step, _lib.OPT_REG | _lib.OPT_CLIP)
+        self._mark()
+
+    def _mark(self):
+        self.decoder["model"].mark_weights_changed()
+        if self.reconstructor:
+            self.reconstructor["model"].mark_weights_changed()
 
     def __call__(self, enc, targets, T, step_weight, seed=None):
         ms = self.decoder["_state"]
@@ -453,6 +460,7 @@ class TrainStep:
         if self.reconstructor:
             self.reconstructor["_state"].step = ms.step
         self.engine.train_step(enc, targets, T, step_weight, seed, ms.step)
+        self._mark()
         return self.engine.scalars
 
 
@@ -529,8 +537,10 @@ class GraphedStep:
 
     def _bump(self):
         self.ms.step += 1
+        self.ms.model.mark_weights_changed()
         if self.rs:
             self.rs.step = self.ms.step
+            self.rs.model.mark_weights_changed()
 
     def __call__(self):
         if not self.split:

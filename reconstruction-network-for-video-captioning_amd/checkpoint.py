@@ -74,6 +74,16 @@ def load_checkpoint(path, decoder, reconstructor=None, load_optimizer=True, map_
             raise KeyError("checkpoint has no reconstructor ('rec')")
         rm = reconstructor["model"] if isinstance(reconstructor, dict) else reconstructor
         rm.load_state_dict(ckpt["rec"])
+    # Engines that are already bound (a Trainer built before the load) hold packed operand images of the OLD weights:
+    # refresh them, and tell the per-step / search engines of the modules that the weights moved.
+    for md in (decoder, reconstructor):
+        if md is None:
+            continue
+        model = md["model"] if isinstance(md, dict) else md
+        model.mark_weights_changed()
+        if isinstance(md, dict):
+            for eng in {id(e): e for e in md["_state"].engines.values()}.values():
+                eng.pack_weights()
     if load_optimizer and isinstance(decoder, dict):
         decoder["optimizer"].load_state_dict(ckpt["dec_opt"])
         if reconstructor is not None and isinstance(reconstructor, dict):

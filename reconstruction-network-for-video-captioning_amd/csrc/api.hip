@@ -82,6 +82,7 @@ struct recnet_handle {
   void* dG_pan = nullptr;   // exchange copies of the gate gradients, rec_chain_bwd_kernel
   void* WhhT = nullptr;     // [R][ld4R] transpose of Whh_w (K contiguous) for rec_chain_bwd_kernel
   int persist_rec_bwd = 0;
+  int persist_loc = 0, persist_loc_bwd = 0;   // loc_chain.hpp: the local reconstructor's chains as persistent launches
   int persist_dec = 0;      // dec_chain.hpp: the decoder's teacher-forced forward chain as one launch
   float* dc_G1 = nullptr; void* dc_pan = nullptr;
   int persist_dec_bwd = 0;  // ... and its BPTT chain

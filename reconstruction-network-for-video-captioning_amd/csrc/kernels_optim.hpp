@@ -104,7 +104,12 @@ struct AdamHyper { double lr, beta1, beta2; float eps, wd, one_m_b1, beta2f, one
 __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
                                                          AdamHyper hp, const float* __restrict__ pnorm,
                                                          const float* __restrict__ clip, const int32_t* __restrict__ step_ptr,
-                                                         const PackDesc* __restrict__ pack, int lp) {
+                                                         const PackDesc* __restrict__ pack, int lp,
+                                                         const float* __restrict__ poison) {
+  // A persistent chain kernel of this step gave up waiting (rec_chain.hpp: rc_give_up) and marked the step: its gradients
+  // are garbage, so parameters, moments and the packed images stay as they are (the host sees the flag through
+  // recnet_chain_status and the NaN total loss).
+  if (poison && *poison != 0.f) return;
   __shared__ float sc[2];
   if (threadIdx.x == 0) {
     const double st = (double)(*step_ptr);

@@ -201,14 +201,14 @@ __global__ void mean_over_t_kernel(const float* __restrict__ X, int T, int Bn, i
 //   xcat[t,b, 0:H) = h_t (copy of the decoder's operand copy),  xcat[t,b, H:2H) = mp[b] * dropmask(t,b,.),  zero padded
 template <typename AT>
 __global__ void xcat_global_kernel(const AT* __restrict__ hs, int ld_hs, const float* __restrict__ mp, AT* __restrict__ xcat, int ld,
-                                   int T, int B, int H, DropDesc dd) {
+                                   int T, int B, int H, DropDesc dd, int t0) {
   const uint32_t key = drop_key(dd);
   const size_t total = (size_t)T * B * ld;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % ld), b = (int)((i / ld) % B), t = (int)(i / ((size_t)ld * B));
     AT v = (AT)0.f;
     if (c < H) v = hs[((size_t)t * B + b) * ld_hs + c];
-    else if (c < 2 * H) v = (AT)(mp[(size_t)b * H + (c - H)] * drop_at(dd, key, t, b, H, c - H));
+    else if (c < 2 * H) v = (AT)(mp[(size_t)b * H + (c - H)] * drop_at(dd, key, t0 + t, b, H, c - H));   // t0: the per-step API
     xcat[i] = v;
   }
 }

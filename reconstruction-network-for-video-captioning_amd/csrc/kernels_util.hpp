@@ -159,6 +159,15 @@ __global__ void pack_block_kernel(AT* __restrict__ dst, int ld_dst, const float*
     dst[i] = (AT)(c < cols ? scale * src[(size_t)r * ld_src + c] : 0.f);
   }
 }
+// dst[r][c] = (AT) src[r * ld_src + c] for c < cols only (a column window of wider operand rows; nothing else is touched)
+template <typename AT>
+__global__ void pack_cols_kernel(AT* __restrict__ dst, int ld_dst, const float* __restrict__ src, int ld_src, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(size_t)r * ld_dst + c] = (AT)src[(size_t)r * ld_src + c];
+  }
+}
 // dst[r] = [src1[r, 0:c1) | src2[r, 0:c2) | 0 ...] with leading dimension ld_dst  (concatenated weight image)
 template <typename DT>
 __global__ void pack2_kernel(DT* __restrict__ dst, int ld_dst, const float* __restrict__ src1, int ld1, int c1,

@@ -235,6 +235,37 @@ class Engine:
                                                 int(t), _stream()), "recnet_decoder_step")
         return logits, h_out, c_out
 
+    def reconstructor_step(self, inp, hr_in, cr_in, decoder_hiddens, T, train=False, seed=0, t=0):
+        """One step of GlobalReconstructor.forward / LocalReconstructor.forward (global_reconstructor.py:30-46,
+        local_reconstructor.py:37-55).  inp [B,H] (global only), hr_in / cr_in [B,R] or None (zero state),
+        decoder_hiddens [T,1,B,H] or None (reuse the previous call's loop invariants) -> (out [B,R], hr', cr')."""
+        d = self.dims
+        B, R = d["B"], d.get("R", d["D"])
+        for nm, x in (("hr", hr_in), ("cr", cr_in)):
+            if x is not None:
+                _chk_tensor(x, (B, R), torch.float32, "reconstructor state " + nm)
+        if inp is not None:
+            _chk_tensor(inp, (B, d["H"]), torch.float32, "input")
+        if decoder_hiddens is not None:
+            _chk_tensor(decoder_hiddens, (T, 1, B, d["H"]), torch.float32, "decoder_hiddens")
+        out = torch.empty(B, R, dtype=torch.float32, device=self.device)
+        hr = torch.empty_like(out)
+        cr = torch.empty_like(out)
+        _lib.check(self.lib.recnet_reconstructor_step(self.handle, _ptr(inp), _ptr(hr_in), _ptr(cr_in),
+                                                      _ptr(decoder_hiddens), int(T), _ptr(out), _ptr(hr), _ptr(cr),
+                                                      int(train), seed & 0xFFFFFFFF, int(t), _stream()),
+                   "recnet_reconstructor_step")
+        return out, hr, cr
+
+    def chain_status(self):
+        """Bit mask of persistent chain kernels that gave up a bounded wait (0 = healthy).  Synchronises the stream."""
+        s = C.c_int32(0)
+        _lib.check(self.lib.recnet_chain_status(self.handle, C.byref(s), _stream()), "recnet_chain_status")
+        return s.value
+
+    def chain_reset(self, disable_persistent=True):
+        _lib.check(self.lib.recnet_chain_reset(self.handle, int(bool(disable_persistent)), _stream()), "recnet_chain_reset")
+
     def forward_decoder(self, enc, targets, T, step_weight, train=True, seed=0, want_hiddens=True):
         d = self.dims
         B = d["B"]
@@ -400,6 +431,9 @@ class Engine:
 
     def recurrent_step_bytes(self, which):
         return float(self.lib.recnet_recurrent_step_bytes(self.handle, int(which)))
+
+    def chain_exchange_bytes(self, which):
+        return float(self.lib.recnet_chain_exchange_bytes(self.handle, int(which)))
 
     def scalar_dict(self):
         """Host copy of the device scalars (synchronises)."""

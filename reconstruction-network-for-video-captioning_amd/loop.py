@@ -17,7 +17,7 @@ import torch
 from . import metrics
 from .api import (GraphedStep, build_decoder, build_reconstructor, forward_decoder, forward_global_reconstructor,
                   forward_local_reconstructor)
-from .checkpoint import save_checkpoint
+from .checkpoint import load_checkpoint, save_checkpoint
 from .dp import DataParallelTrainStep
 from .feed import DeviceFeeder
 from .search import beam_search, greedy_search
@@ -35,12 +35,55 @@ class Trainer:
         self.use_graphs, self.eager_steps = use_graphs, eager_steps
         self._graphs, self._static = {}, None
         self.iteration = 0
+        self._eager_until = eager_steps       # optimiser step count up to which steps are launched eagerly
+
+    def resume(self, path):
+        """Continue a run from a checkpoint written by `fit` (or by the reference's train.py:398-420): parameters, Adam
+        state, step count and iteration are restored, the packed operand images of every bound engine are refreshed
+        (checkpoint.load_checkpoint), captured graphs are dropped and the next `eager_steps` steps run eagerly again
+        (module loading, RCCL set-up) before a graph is captured."""
+        ckpt = load_checkpoint(path, self.decoder, self.reconstructor)
+        self.iteration = int(ckpt.get("iteration", self.decoder["_state"].step))
+        self._graphs.clear()
+        self._eager_until = self.decoder["_state"].step + self.eager_steps
+        return ckpt
+
+    def check_health(self, scalars=None):
+        """Raises if a persistent chain kernel gave up a bounded wait (the step's gradients were garbage; the optimiser
+        kernels skipped the update) or the loss is not finite.  Before raising, the handle is switched to the per-step
+        kernels and the captured graphs are dropped, so a caller that catches the error can keep training."""
+        eng = self.dp.step_impl.engine
+        st = eng.chain_status()
+        bad_loss = scalars is not None and not bool(torch.isfinite(scalars[6]))
+        if st or bad_loss:
+            eng.chain_reset(disable_persistent=True)
+            self._graphs.clear()
+            raise RuntimeError("train step %d: %s; the optimiser updates of the affected steps were skipped, the engine now "
+                               "uses the per-step kernels" % (self.iteration, "persistent chain kernel gave up waiting (status "
+                               "0x%x: another kernel held the CUs it needs)" % st if st else "non-finite loss"))
+
+    def global_scalars(self, acc):
+        """acc: device scalars summed over steps on THIS rank.  Under data parallelism the CE / MSE parts ([0], [3]) are
+        per-rank partial sums (dp.py): all-reduce them (a collective: every rank must call this) and rebuild the derived
+        values.  Returns a host list in _lib.SCALAR_NAMES order."""
+        a = acc.clone()
+        if self.world > 1:
+            import torch.distributed as dist
+            part = torch.stack([a[0], a[3]])
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.dp.group)
+            a[0], a[3] = part[0], part[1]
+        v = a.cpu().tolist()
+        hy = self.decoder["_hyper"]
+        v[2] = v[0] + hy["decoder_lambda_reg"] * v[1]
+        v[5] = v[3] + hy["reconstructor_lambda_reg"] * v[4] if self.reconstructor else 0.0
+        v[6] = v[2] + (hy["lambda_recon"] * v[5] if self.reconstructor else 0.0)
+        return v
 
     # ------------------------------------------------------------------ one optimiser step
     def step(self, enc, targets, T, w):
         """enc [B_local,F,D], targets [31,B_local] on the device; T / w from the GLOBAL batch (feed.DeviceFeeder)."""
         self.iteration += 1
-        if not self.use_graphs or self.decoder["_state"].step < self.eager_steps:
+        if not self.use_graphs or self.decoder["_state"].step < self._eager_until:
             return self.dp(enc, targets, T, w)         # first steps eagerly: module loading, RCCL set-up
         if self._static is None:
             self._static = (torch.empty_like(enc), torch.empty_like(targets))
@@ -102,7 +145,9 @@ class Trainer:
             n_acc += 1
             it = self.iteration
             if log_every and it % log_every == 0:
-                a = (acc / n_acc).cpu().tolist()
+                self.check_health(sc)
+                # the reference divides its running sums by log_every * batch_size (train.py:282-286)
+                a = [x / (n_acc * C.batch_size) for x in self.global_scalars(acc)]
                 rec = {"iteration": it, "loss": a[6], "dec": a[2], "rec": a[5]}
                 hist.append(rec)
                 msg = "Iter {} / {} ({:.1f}%): loss {:.5f}".format(it, n_iterations, it / n_iterations * 100, a[6])
@@ -116,10 +161,13 @@ class Trainer:
                 hist.append({"iteration": it, "val_loss": v["loss"], "val_dec": v["dec"], "val_rec": v["rec"]})
                 log("[Validation] Iter {} / {}: loss {:.5f} (dec {:.5f} + rec {:.5f})".format(it, n_iterations, v["loss"],
                                                                                             v["dec"], v["rec"]))
-            if save_every and save_dpath and it % save_every == 0 and self.rank == 0:
-                os.makedirs(save_dpath, exist_ok=True)
-                save_checkpoint(os.path.join(save_dpath, "{}_checkpoint.tar".format(it)), it, self.decoder,
-                                self.reconstructor, loss=sc[6], config=C)
+            if save_every and save_dpath and it % save_every == 0:
+                self.check_health(sc)                  # never write weights of a step that went wrong
+                gl = self.global_scalars(sc)           # collective under data parallelism: every rank
+                if self.rank == 0:
+                    os.makedirs(save_dpath, exist_ok=True)
+                    save_checkpoint(os.path.join(save_dpath, "{}_checkpoint.tar".format(it)), it, self.decoder,
+                                    self.reconstructor, loss=torch.tensor(gl[6]), config=C)
             if it >= n_iterations:
                 break
         return hist

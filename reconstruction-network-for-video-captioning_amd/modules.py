@@ -38,7 +38,20 @@ def _gates(model_name, n_layers, what):
     return 4 if model_name == "LSTM" else 3
 
 
-class Decoder(nn.Module):
+class _Generation:
+    """The HIP optimiser updates parameters through raw device pointers, which does not bump torch's `_version`
+    counters; every path that does so (FusedAdam.step, TrainStep, GraphedStep, load_checkpoint) calls
+    `mark_weights_changed()` and the per-step / search engines re-pack their operand images when the generation moved."""
+    _weights_gen = 0
+
+    def mark_weights_changed(self):
+        self._weights_gen += 1
+
+    def weights_signature(self):
+        return (self._weights_gen, tuple(p._version for p in self.parameters()))
+
+
+class Decoder(nn.Module, _Generation):
     """models/decoder.py:6-70."""
 
     def __init__(self, model_name, n_layers, encoder_size, embedding_size, embedding_scale, hidden_size,
@@ -105,7 +118,7 @@ class Decoder(nn.Module):
         # (Uv, P) and the packed weights are refreshed only when the features or the parameters changed —
         # eval.py's search loops call forward 31 x beam times with the same encoder_outputs.
         enc = encoder_outputs.contiguous()
-        pver = tuple(p._version for p in self.parameters())
+        pver = self.weights_signature()
         sig = (enc.data_ptr(), enc._version, tuple(enc.shape), pver)
         fresh = getattr(eng, "_inv_sig", None) != sig
         if fresh:
@@ -122,16 +135,51 @@ class Decoder(nn.Module):
         return logits, (h2.unsqueeze(0) if gru else (h2.unsqueeze(0), c2.unsqueeze(0)))
 
 
-class _Reconstructor(nn.Module):
+class _Reconstructor(nn.Module, _Generation):
+    """Per-step API of the two reconstructors, the way the reference's own time loops call it (train.py:93-94,
+    122-123), served by the single-step kernels (recnet_reconstructor_step).  Forward only: training goes through
+    api.forward_global_reconstructor / forward_local_reconstructor / TrainStep, which differentiate whole sequences."""
     kind = None
+    dropout_seed = 42
 
     def named_tensors(self):
         return {k: v for k, v in self.named_parameters()}
 
-    def forward(self, *a, **k):
-        raise NotImplementedError(
-            "the per-step reconstructor API is only used inside the reference's own time loops "
-            "(train.py:93-94,122-123); use forward_global_reconstructor / forward_local_reconstructor")
+    def _step(self, inp, hidden, decoder_hiddens):
+        T, L, B, H = decoder_hiddens.shape
+        if L != 1:
+            raise NotImplementedError("n_layers must be 1")
+        if not hasattr(self, "_step_engines"):
+            self._step_engines, self._calls = {}, 0
+        dev = decoder_hiddens.device
+        key = (B, dev)
+        eng = self._step_engines.get(key)
+        if eng is None:
+            R = self.hidden_size
+            d = dict(B=B, F=2, D=R, E=4, H=H, A=4, V=8, R=R, RA=getattr(self, "attn_size", 0), rec_cell=self.model_name)
+            hy = dict(reconstructor_decoder_dropout=self.decoder_dropout_p,
+                      caption_max_len=getattr(self, "caption_max_len", 30))
+            eng = Engine(d, self.kind, self.precision, hy, device=dev)
+            eng.bind_reconstructor({k: v.data for k, v in self.named_tensors().items()})
+            self._step_engines[key] = eng
+        self._last_engine = eng
+        pver = self.weights_signature()
+        if getattr(eng, "_pver", None) != pver:
+            eng.pack_weights()
+            eng._pver = pver
+        # the reference recomputes the pooled states / U_r . hiddens on every call (global_reconstructor.py:33-37,
+        # local_reconstructor.py:42); here they are refreshed only when decoder_hiddens or the parameters changed
+        dh = decoder_hiddens.contiguous()
+        sig = (dh.data_ptr(), dh._version, tuple(dh.shape), pver)
+        fresh = getattr(eng, "_inv_sig", None) != sig
+        eng._inv_sig = sig
+        gru = self.model_name == "GRU"
+        h, c = (hidden, hidden) if gru else hidden
+        out, h2, c2 = eng.reconstructor_step(None if inp is None else inp[0].contiguous(), h[-1].contiguous(),
+                                             c[-1].contiguous(), dh if fresh else None, T, train=self.training,
+                                             seed=self.dropout_seed, t=self._calls)
+        self._calls += 1
+        return out, (h2.unsqueeze(0) if gru else (h2.unsqueeze(0), c2.unsqueeze(0)))
 
 
 class GlobalReconstructor(_Reconstructor):
@@ -152,6 +200,11 @@ class GlobalReconstructor(_Reconstructor):
         self.out = _Weights(weight=(R, R), bias=(R,))
         for p in self.parameters():
             _uniform(p, 1 / math.sqrt(R))
+
+    def forward(self, input, hidden, decoder_hiddens):
+        """global_reconstructor.py:30-46.  input [L,B,H] (= decoder_hiddens[t]), hidden = (hr, cr) each [L,B,R] (GRU: one
+        tensor), decoder_hiddens [T,L,B,H] -> (output [B,R], hidden')."""
+        return self._step(input, hidden, decoder_hiddens)
 
 
 class LocalReconstructor(_Reconstructor):
@@ -179,3 +232,8 @@ class LocalReconstructor(_Reconstructor):
         _uniform(self.attn_w.weight, 1 / math.sqrt(A))
         for p in list(self.rnn.parameters()) + list(self.out.parameters()):
             _uniform(p, 1 / math.sqrt(R))
+
+    def forward(self, hidden, decoder_hiddens):
+        """local_reconstructor.py:37-55.  hidden = (hr, cr) each [L,B,R] (GRU: one tensor), decoder_hiddens [T,L,B,H]
+        -> (output [B,R], hidden')."""
+        return self._step(None, hidden, decoder_hiddens)

@@ -18,10 +18,11 @@ def _engine(decoder, encoder_outputs):
         eng = Engine(decoder.dims(B, F), None, decoder.precision, decoder.hyper(), device=encoder_outputs.device)
         eng.bind_decoder({k: v.data for k, v in decoder.named_tensors().items()})
         decoder._step_engines[key] = eng
-    pver = tuple(p._version for p in decoder.parameters())
-    if getattr(eng, "_pver", None) != pver:
-        eng.pack_weights()
-        eng._pver = pver
+    # The HIP optimiser updates the parameters through raw pointers (no torch `_version` bump), so a cached "packed"
+    # flag can go stale between two evaluations of a training run.  Re-packing costs a few microseconds next to a
+    # 31-step search: always do it.
+    eng.pack_weights()
+    eng._pver = decoder.weights_signature()
     eng._inv_sig = None          # the search recomputes the invariants itself
     return eng
 

@@ -76,3 +76,87 @@ def test_validate_and_evaluate_shapes():
         assert set(s) == {"Bleu_1", "Bleu_2", "Bleu_3", "Bleu_4", "CIDEr", "ROUGE_L"}
     with pytest.raises(NotImplementedError):
         R.evaluate(C, [(vids, enc)], tr.decoder["model"], "sampling", idx2word, refs)
+
+
+def test_search_after_training_uses_the_current_weights():
+    """The HIP optimiser updates parameters through raw pointers (no torch `_version` bump): a search engine created
+    before further training must not keep decoding with the weights of its first call (periodic test scoring,
+    train.py:376-395)."""
+    C = R.make_config(use_recon=True, reconstructor_type="global", decoder_learning_rate=3e-2, **DIMS)
+    torch.manual_seed(3)
+    tr = R.Trainer(C, V, use_graphs=False)
+    dm = tr.decoder["model"]
+    enc = torch.from_numpy(_batches(1, 9)[0][0]).cuda()
+    B, H = 6, DIMS["decoder_hidden_size"]
+
+    def search(model):
+        model.eval()
+        inp = torch.full((1, B), 1, dtype=torch.long, device="cuda")
+        hid = (torch.zeros(1, B, H, device="cuda"), torch.zeros(1, B, H, device="cuda"))
+        out = (R.greedy_search(C, model, inp, hid, enc), R.beam_search(C, 3, None, model, inp, hid, enc))
+        lg, _ = model(inp, hid, enc)                      # the per-step API keeps a packed-weights cache of its own
+        model.train()
+        return out, lg.clone()
+
+    def fresh_copy():
+        m = R.Decoder(model_name=C.decoder_model, n_layers=1, encoder_size=C.encoder_output_size, embedding_size=C.embedding_size,
+                      embedding_scale=C.embedding_scale, hidden_size=C.decoder_hidden_size, attn_size=C.decoder_attn_size,
+                      output_size=V, embedding_dropout=C.embedding_dropout, dropout=C.decoder_dropout,
+                      out_dropout=C.decoder_out_dropout, precision="f32").cuda()
+        m.load_state_dict(dm.state_dict())
+        return m
+
+    (s0, lg0) = search(dm)
+    tr.fit(iter(_batches(6, 1)), 6)
+    (s1, lg1) = search(dm)
+    (s1_fresh, lg1_fresh) = search(fresh_copy())
+    assert s1 == s1_fresh and torch.equal(lg1, lg1_fresh)
+    assert not torch.equal(lg0, lg1)                       # the six steps at lr 3e-2 did move the logits
+    tr.fit(iter(_batches(4, 2)), 10)
+    (s2, lg2) = search(dm)
+    (s2_fresh, lg2_fresh) = search(fresh_copy())
+    assert s2 == s2_fresh and torch.equal(lg2, lg2_fresh)
+
+
+def test_trainer_resume_equals_uninterrupted_run(tmp_path):
+    """Trainer built FIRST, checkpoint loaded afterwards (its engines already hold packed images of the random
+    initial weights): the resumed run must equal the uninterrupted one."""
+    C = R.make_config(use_recon=True, reconstructor_type="local", **DIMS_CHAIN)
+    data = _batches(6)
+    torch.manual_seed(0)
+    a = R.Trainer(C, V)
+    a.fit(iter(data), 6, save_every=3, save_dpath=str(tmp_path))
+    torch.manual_seed(123)                                   # different initial weights
+    b = R.Trainer(C, V)
+    ck = b.resume(os.path.join(str(tmp_path), "3_checkpoint.tar"))
+    assert ck["iteration"] == 3 and b.iteration == 3 and b.decoder["_state"].step == 3
+    b.fit(iter(data[3:]), 6)
+    assert b.iteration == 6
+    for md_a, md_b in ((a.decoder, b.decoder), (a.reconstructor, b.reconstructor)):
+        for (k, x), (_, y) in zip(md_a["model"].state_dict().items(), md_b["model"].state_dict().items()):
+            assert torch.equal(x, y), k
+
+
+def test_chain_give_up_skips_the_update_and_is_reported():
+    """A persistent chain kernel that gives up a bounded wait (here: its sticky word is set by hand) must not corrupt
+    the run: the optimiser kernels skip the update, the loss is NaN, Trainer.check_health raises, and after the reset
+    the handle keeps training on the per-step kernels."""
+    C = R.make_config(use_recon=True, reconstructor_type="global", **DIMS_CHAIN)
+    torch.manual_seed(0)
+    tr = R.Trainer(C, V, use_graphs=False)
+    data = _batches(4)
+    tr.fit(iter(data[:1]), 1, log_every=1, log=lambda m: None)
+    eng = tr.dp.step_impl.engine
+    assert eng.chain_status() == 0
+    before = {k: v.clone() for k, v in tr.decoder["model"].state_dict().items()}
+    # sticky word of the reconstructor's forward chain: workspace word 64 (ctrl block) + 257
+    off = (eng._ws_ptr - eng.workspace.data_ptr()) + (64 + 257) * 4
+    eng.workspace[off:off + 4] = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError, match="gave up"):
+        tr.fit(iter(data[1:2]), 2, log_every=1, log=lambda m: None)
+    for k, v in tr.decoder["model"].state_dict().items():
+        assert torch.equal(v, before[k]), k                   # the poisoned step did not touch the parameters
+    assert eng.chain_status() == 0                          # check_health reset the words and disabled the chains
+    hist = tr.fit(iter(data[2:]), 4, log_every=1, log=lambda m: None)
+    assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist)
+    assert any(not torch.equal(v, before[k]) for k, v in tr.decoder["model"].state_dict().items())
