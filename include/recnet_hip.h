@@ -282,6 +282,18 @@ int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, c
 int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, int32_t b_col, int32_t ldb, float* C,
                      int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
                      int32_t splitk, float* splitk_ws, int32_t tag, void* stream);
+/* Dimensions a handle was created with (the torch.ops layer sizes its outputs from these). */
+#define RECNET_DIM_B 0
+#define RECNET_DIM_F 1
+#define RECNET_DIM_D 2
+#define RECNET_DIM_E 3
+#define RECNET_DIM_H 4
+#define RECNET_DIM_A 5
+#define RECNET_DIM_V 6
+#define RECNET_DIM_R 7
+#define RECNET_DIM_RA 8
+#define RECNET_DIM_TM 9      /* caption_max_len + 1: rows of `targets` */
+int32_t recnet_dim(const recnet_handle* h, int32_t which);
 /* One reconstructor step with the reference's per-step semantics — GlobalReconstructor.forward(input, hidden,
  * decoder_hiddens) (models/global_reconstructor.py:30-46, called at train.py:94) and LocalReconstructor.forward(hidden,
  * decoder_hiddens) (models/local_reconstructor.py:37-55, called at train.py:123).  input [B][H] (global only: the layer-0

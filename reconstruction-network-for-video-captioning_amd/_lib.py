@@ -140,3 +140,4 @@ EXPORTS["recnet_beam_search"] = (_i, [C.c_void_p, C.c_void_p, _i, C.c_void_p, C.
 EXPORTS["recnet_reconstructor_step"] = (_i, [C.c_void_p] * 5 + [_i] + [C.c_void_p] * 3 + [_i, C.c_uint32, _i, C.c_void_p])
 EXPORTS["recnet_chain_status"] = (_i, [C.c_void_p, C.POINTER(_i), C.c_void_p])
 EXPORTS["recnet_chain_reset"] = (_i, [C.c_void_p, _i, C.c_void_p])
+EXPORTS["recnet_dim"] = (_i, [C.c_void_p, _i])

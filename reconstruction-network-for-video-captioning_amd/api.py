@@ -17,7 +17,7 @@ import random
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, _ops
 from .config import TrainConfig
 from .engine import Engine, FlatState
 from .modules import Decoder, GlobalReconstructor, LocalReconstructor
@@ -271,20 +271,29 @@ def build_reconstructor(C=TrainConfig):
 
 
 # ----------------------------------------------------------------------------- autograd bridges
+def _h(eng):
+    return int(eng.handle.value)
+
+
 class _DecoderSeq(torch.autograd.Function):
+    """forward_decoder as a paired forward / backward custom op: torch.ops.recnet.forward_decoder / backward_decoder."""
+
     @staticmethod
     def forward(ctx, eng, ms, enc, targets, T, stepw, train, seed, *params):
-        hid = eng.forward_decoder(enc, targets, T, stepw, train=train, seed=seed)
+        ops = _ops.load()
+        eng._chk_step(enc, targets, T, stepw)
+        loss, hid, sc = ops.forward_decoder(_h(eng), enc, targets, T, stepw, bool(train), seed & 0xFFFFFFFF)
+        eng.scalars.copy_(sc)
+        eng.T = T
         ctx.eng, ctx.ms, ctx.enc, ctx.targets = eng, ms, enc, targets
-        loss = eng.scalars[2].clone()
         return loss, hid
 
     @staticmethod
     def backward(ctx, dloss, dhid):
-        eng = ctx.eng
+        ops, eng = _ops.load(), ctx.eng
         gs = float(dloss) if dloss is not None else 0.0
-        eng.backward_decoder(ctx.enc, ctx.targets, None if dhid is None else dhid.contiguous(), gs)
-        eng.add_reg_grad(0, gs)
+        ops.backward_decoder(_h(eng), ctx.enc, ctx.targets, None if dhid is None else dhid.contiguous(), gs)
+        ops.add_reg_grad(_h(eng), 0, gs)
         ctx.ms.publish_grads()
         return (None,) * 8 + (None,) * len(ctx.ms.params())
 
@@ -295,34 +304,44 @@ class _DecoderSeqFree(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng, ms, enc, targets, T, stepw, train, seed, *params):
-        hid, out = eng.forward_decoder_free(enc, targets, T, stepw, train=train, seed=seed)
+        ops = _ops.load()
+        eng._chk_step(enc, targets, T, stepw)
+        loss, hid, out, sc = ops.forward_decoder_free(_h(eng), enc, targets, T, stepw, bool(train), seed & 0xFFFFFFFF)
+        eng.scalars.copy_(sc)
+        eng.T = T
         ctx.eng, ctx.ms, ctx.enc, ctx.targets = eng, ms, enc, targets
         ctx.mark_non_differentiable(out)
-        return eng.scalars[2].clone(), hid, out
+        return loss, hid, out
 
     @staticmethod
     def backward(ctx, dloss, dhid, _dout):
-        eng = ctx.eng
+        ops, eng = _ops.load(), ctx.eng
         gs = float(dloss) if dloss is not None else 0.0
-        eng.backward_decoder(ctx.enc, ctx.targets, None if dhid is None else dhid.contiguous(), gs)
-        eng.add_reg_grad(0, gs)
+        ops.backward_decoder(_h(eng), ctx.enc, ctx.targets, None if dhid is None else dhid.contiguous(), gs)
+        ops.add_reg_grad(_h(eng), 0, gs)
         ctx.ms.publish_grads()
         return (None,) * 8 + (None,) * len(ctx.ms.params())
 
 
 class _ReconstructorSeq(torch.autograd.Function):
+    """forward_{global,local}_reconstructor: torch.ops.recnet.forward_reconstructor / backward_reconstructor."""
+
     @staticmethod
     def forward(ctx, eng, ms, hiddens, enc, T, train, seed, *params):
-        eng.forward_reconstructor(enc, hiddens, T, train=train, seed=seed)
-        ctx.eng, ctx.ms, ctx.enc = eng, ms, enc
-        return eng.scalars[5].clone()
+        ops = _ops.load()
+        eng._chk_rec(enc, hiddens, T)
+        loss, sc = ops.forward_reconstructor(_h(eng), enc, hiddens, T, bool(train), seed & 0xFFFFFFFF)
+        eng.scalars.copy_(sc)
+        eng.T = T
+        ctx.eng, ctx.ms, ctx.enc, ctx.T = eng, ms, enc, T
+        return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        eng = ctx.eng
+        ops, eng = _ops.load(), ctx.eng
         gs = float(dloss)
-        dh = eng.backward_reconstructor(ctx.enc, gs)
-        eng.add_reg_grad(1, gs)
+        dh = ops.backward_reconstructor(_h(eng), ctx.enc, ctx.T, gs)
+        ops.add_reg_grad(_h(eng), 1, gs)
         ctx.ms.publish_grads()
         return (None, None, dh, None, None, None, None) + (None,) * len(ctx.ms.params())
 

@@ -342,6 +342,13 @@ class Engine:
         _chk_tensor(targets, (self.hyper["caption_max_len"] + 1, d["B"]), torch.int64, "targets")
         _chk_tensor(step_weight, (int(T),), torch.float32, "step_weight")
 
+    def _chk_rec(self, enc, hiddens, T):
+        from ._lib import RecNetError  # noqa: F401
+        d = self.dims
+        _chk_tensor(enc, (d["B"], d["F"], d["D"]), torch.float32, "encoder_outputs")
+        if hiddens is not None:
+            _chk_tensor(hiddens, (int(T), 1, d["B"], d["H"]), torch.float32, "decoder_hiddens")
+
     def train_step_fwd_bwd(self, enc, targets, T, step_weight, seed):
         self._chk_step(enc, targets, T, step_weight)
         _lib.check(self.lib.recnet_train_step_fwd_bwd(self.handle, _ptr(enc), _ptr(targets), int(T),

@@ -11,6 +11,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import _ops
 from .engine import Engine
 
 
@@ -128,9 +129,9 @@ class Decoder(nn.Module, _Generation):
             eng._inv_sig = sig
         gru = self.model_name == "GRU"
         h, c = (hidden, hidden) if gru else hidden
-        logits, h2, c2 = eng.decoder_step(input.reshape(-1).contiguous(), h[-1].contiguous(), c[-1].contiguous(),
-                                          enc if fresh else None, train=self.training,
-                                          seed=self.dropout_seed, t=self._calls)
+        logits, h2, c2 = _ops.load().decoder_step(int(eng.handle.value), input.reshape(-1).contiguous(), h[-1].contiguous(),
+                                                  c[-1].contiguous(), enc if fresh else None, bool(self.training),
+                                                  self.dropout_seed & 0xFFFFFFFF, self._calls)
         self._calls += 1
         return logits, (h2.unsqueeze(0) if gru else (h2.unsqueeze(0), c2.unsqueeze(0)))
 
@@ -175,9 +176,9 @@ class _Reconstructor(nn.Module, _Generation):
         eng._inv_sig = sig
         gru = self.model_name == "GRU"
         h, c = (hidden, hidden) if gru else hidden
-        out, h2, c2 = eng.reconstructor_step(None if inp is None else inp[0].contiguous(), h[-1].contiguous(),
-                                             c[-1].contiguous(), dh if fresh else None, T, train=self.training,
-                                             seed=self.dropout_seed, t=self._calls)
+        out, h2, c2 = _ops.load().reconstructor_step(int(eng.handle.value), None if inp is None else inp[0].contiguous(),
+                                                     h[-1].contiguous(), c[-1].contiguous(), dh if fresh else None, T,
+                                                     bool(self.training), self.dropout_seed & 0xFFFFFFFF, self._calls)
         self._calls += 1
         return out, (h2.unsqueeze(0) if gru else (h2.unsqueeze(0), c2.unsqueeze(0)))
 

@@ -7,6 +7,7 @@ reference's own `evaluate()` builds (<SOS> tokens, zero hidden state, eval.py:13
 state the reference ever passes; beam_width <= 8."""
 import torch
 
+from . import _ops
 from .engine import Engine
 
 
@@ -40,7 +41,7 @@ def greedy_search(config, decoder, input, hidden, encoder_outputs):
     reference's list of lists of 0-d tensors."""
     _check_start(config, input, hidden)
     eng = _engine(decoder, encoder_outputs)
-    toks, n = eng.greedy_search(encoder_outputs.contiguous())
+    toks, n = _ops.load().greedy_search(int(eng.handle.value), encoder_outputs.contiguous())
     n = int(n.item())
     return toks[:n].cpu().tolist()
 
@@ -49,6 +50,6 @@ def beam_search(config, beam_width, vocab, decoder, input, hidden, encoder_outpu
     """eval.py:36-120.  Returns top1_output_list: one token list per caption."""
     _check_start(config, input, hidden)
     eng = _engine(decoder, encoder_outputs)
-    best, n = eng.beam_search(encoder_outputs.contiguous(), beam_width)
+    best, n = _ops.load().beam_search(int(eng.handle.value), encoder_outputs.contiguous(), int(beam_width))
     n = int(n.item())
     return best[:n].t().cpu().tolist()
