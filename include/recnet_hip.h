@@ -304,7 +304,7 @@ int recnet_reconstructor_step(recnet_handle* h, const float* input, const float*
                               const float* decoder_hiddens, int32_t T, float* out, float* hr_out, float* cr_out,
                               int32_t train, uint32_t seed, int32_t t, void* stream);
 /* Health of the persistent chain kernels (bounded waits): status bits 1/2 reconstructor fwd/bwd chain, 4/8 decoder
- * fwd/BPTT chain, 16/32 local reconstructor fwd/bwd chain gave up a wait; 256 the step's loss was poisoned (NaN) and the
+ * fwd/BPTT chain, 32/64 local reconstructor fwd/bwd chain gave up a wait; 256 the step's loss was poisoned (NaN) and the
  * optimiser kernels skip their updates.  Synchronises `stream`.  recnet_chain_reset clears the sticky words;
  * disable_persistent != 0 switches the handle to the per-step kernels for every later call. */
 int recnet_chain_status(recnet_handle* h, int32_t* status_out, void* stream);

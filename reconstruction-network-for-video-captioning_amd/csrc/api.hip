@@ -30,6 +30,7 @@
 #include "rec_step.hpp"
 #include "rec_chain.hpp"
 #include "dec_chain.hpp"
+#include "loc_chain.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
@@ -79,6 +80,8 @@ struct recnet_handle {
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void* Hr_pan = nullptr;
+  void *lc_panh = nullptr, *lc_panx = nullptr; float* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
+  int lc_ms = 1, lc_rb = 4, lc_ng = 0, lc_nc = 0;
   void* dG_pan = nullptr;   // exchange copies of the gate gradients, rec_chain_bwd_kernel
   void* WhhT = nullptr;     // [R][ld4R] transpose of Whh_w (K contiguous) for rec_chain_bwd_kernel
   int persist_rec_bwd = 0;
@@ -223,6 +226,9 @@ static size_t carve(recnet_handle* h, char* base) {
     h->dWhrs = takev(F * B * ldRA); h->Wr4_w = takev(RN_TCH * RA * ldR);
     h->Ur_w = takev(RA * ldH); h->Wr_w = takev(RA * ldR); h->Wihh_w = takev(4 * R * ldHR);
     h->slab2 = take(16 * B * R);
+    h->lc_panh = takev(F * rc_pan_elems((int)R) / 2 + 64);
+    h->lc_panx = takev(F * rc_pan_elems((int)H) / 2 + 64);
+    h->lc_pw = take(F * B * ((R + 15) / 16) * RA);
   }
   // optimiser tables (sizes are upper bounds; filled at bind time)
   for (int g = 0; g < 2; ++g) {
@@ -306,6 +312,16 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
                      (N & 15) == 0 && h->B <= RC_PAN_ROWS && (NA > h->B ? NA : h->B) + 1 <= ncu;
     const char* eb = getenv("RN_PERSIST_REC_BWD");
     h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
+  }
+  {
+    // loc_chain.hpp: the local reconstructor's forward chain as one launch (unit-owner + caption workgroups + relay)
+    const char* e = getenv("RN_PERSIST_LOC");
+    h->lc_ms = h->B > 64 ? 2 : 1; h->lc_rb = (h->B <= 32) ? 2 : 4;
+    h->lc_ng = h->R / 16; h->lc_nc = (h->B + LC_CPW - 1) / LC_CPW;
+    const int nwg = h->lc_ng * h->lc_ms + h->lc_nc + 1;
+    h->persist_loc = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && h->B <= RC_PAN_ROWS && (h->R & 31) == 0 &&
+                     h->R <= 2048 && (h->H & 31) == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 3) == 0 && h->Tm <= 32 &&
+                     nwg <= h->ncu && nwg - 1 <= 256;
   }
   {
     const char* e = getenv("RN_DEC_BWD_NT");

@@ -1,0 +1,432 @@
+// The local reconstructor's forward chain (local_reconstructor.py:37-55 inside train.py:122-123) as ONE launch:
+//   for s < F:  Whr = hr_{s-1} . W_r^T ;  beta[t] = w . tanh(Whr + Ud[t] + b) ;  x = drop((1/T) sum_t beta[t] h_t) ;
+//               gates = x . W_ih^T + hr_{s-1} . W_hh^T + bias ;  (hr_s, cr_s) = cell
+// The per-launch path runs four kernels per step (attention GEMM, attention, gate GEMM, cell: 33 us per step at
+// B = 100, R = 1536) and re-streams [W_ih | W_hh] (25 MB) every step.  Here the weights are read once and a step is two
+// hand-overs between two kinds of resident workgroups (one per CU, rec_chain.hpp's exchange discipline):
+//   U (unit owner): 16 hidden units x one row part.  Its 64 gate rows of W_hh stay in MFMA B-operand registers, its
+//      rows of W_ih as B fragments in LDS, its 16 columns of W_r in registers.  Per step: (x_s arrived) x_s . W_ih^T on top
+//      of the recurrent part, 4-wave K reduction, cell pointwise, publishes hr_s (k-group-major panel) AND its rank-16
+//      contribution hr_s[:, own units] . W_r[:, own units]^T to the next step's attention projection (so that no
+//      workgroup has to wait for all of hr_s and run a second GEMM before the attention can start); then, off the
+//      critical path, the recurrent product hr_s . W_hh^T for the next step.
+//   C (caption owner): two captions.  Their decoder states h_t (fp32) and projections Ud[t] stay in registers for all F
+//      steps.  Per step: sums the NG rank-16 contributions to Whr, scores beta over the T decoder steps (wavefront
+//      reductions), x_s = dropout(mean_t beta h_t), publishes x_s (panel) and the tensors the backward needs.
+//   One extra workgroup relays the two barriers per step (all U arrived -> C may read; all C arrived -> U may read).
+// Limits (host-checked): bf16 path, B <= 112, R % 32 == 0, R <= 2048, H % 32 == 0, H <= 512, A <= 128, T <= 32,
+// R/16 * row parts + ceil(B/2) + 1 workgroups resident at once (<= CU count, <= 256 flags).
+#pragma once
+#include "common.hpp"
+#include "rec_chain.hpp"
+
+struct LocChainArgs {
+  int F, T, B, R, H, A, gru;
+  int NU, NG, MS, NC;                 // unit-owner workgroups = NG unit groups x MS row parts; caption workgroups
+  const bf16_t* W; int ldw;           // [4R][ldw] packed [W_ih (H) | W_hh (R) | 0], gate-major rows
+  const bf16_t* Wr; int ldwr;         // [A][ldwr] W_r
+  const float* bias;                  // [4R] b_ih + b_hh in the 4-block layout
+  const float* Hs; const float* Ud;   // [T][B][H] decoder states, [T][B][A] their projections U_r h_t
+  const float* ab; const float* w;    // [A], [A]
+  float* Hr; float* Cr; float* acts;  // [F][B][R], [F][B][R], [F][B][4R]
+  bf16_t* Hlp; int ld_hlp;            // [F][B][ld_hlp] row-major operand copy of hr_s (zero padded)
+  bf16_t* Xcat; int ld_xcat;          // [F][B][ld_xcat]: x_s -> columns [0, H)
+  float* beta; float* Whr;            // [F][B][T], [F][B][A]
+  bf16_t* PanH; bf16_t* PanX;         // exchange: [F][rc_pan_elems(R)], [F][rc_pan_elems(H)]
+  float* Pw;                          // exchange: [F][B][NG][A] rank-16 contributions to Whr of step s (written at s-1)
+  unsigned* bar; unsigned* epoch; float* poison;
+  DropDesc dd;
+};
+
+#define LC_CPW 2              // captions per C workgroup
+__device__ __forceinline__ void lc_poll(const unsigned* flags, int n, unsigned target, unsigned* bar, unsigned& spin) {
+  // wave 0 of the relay workgroup: all n <= 256 flags have reached `target`
+  const int l = threadIdx.x;
+  const unsigned* f0 = flags + (l < n ? l : n - 1);
+  const unsigned* f1 = flags + (l + 64 < n ? l + 64 : n - 1);
+  const unsigned* f2 = flags + (l + 128 < n ? l + 128 : n - 1);
+  const unsigned* f3 = flags + (l + 192 < n ? l + 192 : n - 1);
+  for (;;) {
+    const unsigned a0 = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned a1 = __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned a2 = __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned a3 = __hip_atomic_load(f3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = (int)(a0 - target) >= 0 && (int)(a1 - target) >= 0 && (int)(a2 - target) >= 0 && (int)(a3 - target) >= 0;
+    if (__all(ok)) break;
+    if (rc_give_up(bar, spin)) break;
+  }
+}
+__device__ __forceinline__ void lc_release(unsigned* rel, unsigned v) {
+  if (threadIdx.x < 8) __hip_atomic_store(rel + threadIdx.x * 32, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// workers: wave 0 polls this workgroup's copy of a release word (one 128-byte line per group of workgroups)
+__device__ __forceinline__ void lc_wait(const unsigned* rel, unsigned target, unsigned* bar) {
+  if (threadIdx.x < 64) {
+    const unsigned* r = rel + (blockIdx.x & 7) * 32;
+    unsigned spin = 0;
+    while ((int)(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) { if (rc_give_up(bar, spin)) break; }
+    if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void lc_arrive(unsigned* flag, unsigned v) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lc_store16(bf16_t* dst, const bf16_t* src) {     // 16 bytes, written through
+  const uint64_t* s = reinterpret_cast<const uint64_t*>(src);
+  uint64_t* d = reinterpret_cast<uint64_t*>(dst);
+  __hip_atomic_store(d, s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(d + 1, s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+typedef short lc_s4 __attribute__((ext_vector_type(4)));
+
+// release words: relU (word 0 of each line) = "every U workgroup has finished step .", relC (word 16) = "every C ...".
+// Flag / release values are fb + phase, fb = launch epoch << 7 (rec_chain.hpp).  Phases: U arrives with s + 1 after
+// publishing hr_s, C arrives with s + 1 after publishing x_s; both arrive with F + 1 when they are done, after which the
+// relay bumps the launch epoch (every workgroup has read it by then).
+template <int STEPS, int PF, int RB>
+__global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
+  constexpr int CG = 4, UW = 16, ROWS = RB * 16, RED_LD = CG * 16 + 1, NP = STEPS / 2, KG = UW / 8, SX = 4;
+  extern __shared__ __attribute__((aligned(16))) float lc_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x, R = p.R, B = p.B, H = p.H, A = p.A, F = p.F, T = p.T;
+  const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
+  unsigned* relU = p.bar + 256; unsigned* relC = p.bar + 256 + 16;
+  const size_t pan_h = rc_pan_elems(R), pan_x = rc_pan_elems(H);
+
+  // ================================================================================== relay workgroup
+  if (wg == p.NU + p.NC) {
+    if (tid < 64) {
+      unsigned spin = 0;
+      for (int s = 0; s < F; ++s) {
+        if (s >= 1) { lc_poll(p.bar, p.NU, fb + (unsigned)s, p.bar, spin); lc_release(relU, fb + (unsigned)s); }
+        lc_poll(p.bar + p.NU, p.NC, fb + (unsigned)(s + 1), p.bar, spin); lc_release(relC, fb + (unsigned)(s + 1));
+      }
+      lc_poll(p.bar, p.NU + p.NC, fb + (unsigned)(F + 1), p.bar, spin);      // everybody is done (and has read the epoch)
+      if (tid == 0) {
+        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
+      }
+    }
+    return;
+  }
+
+  // ================================================================================== caption workgroups
+  if (wg >= p.NU) {
+    float* swh = lc_smem;                                   // [LC_CPW][128]
+    float* sbeta = swh + LC_CPW * 128;                      // [LC_CPW][32]
+    bf16_t* xl = reinterpret_cast<bf16_t*>(sbeta + LC_CPW * 32);   // [LC_CPW][512]
+    const int ci = wg - p.NU, c = tid >> 7, j = tid & 127, wv = (tid >> 6) & 1;
+    const int b = ci * LC_CPW + c;
+    const bool bok = b < B;
+    const int bb = bok ? b : 0;
+    // residents: this thread's four columns of h_t (t < T), this wave's Ud rows (t = wv, wv + 2, ..; k = lane, lane + 64)
+    float hv[4][32];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        const int h = j + 128 * q;
+        hv[q][t] = (bok && t < T && h < H) ? p.Hs[((size_t)t * B + bb) * H + h] : 0.f;
+      }
+    float udr[16][2], wk[2], bk[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = lane + 64 * q;
+      wk[q] = k < A ? p.w[k] : 0.f; bk[q] = k < A ? p.ab[k] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = wv + 2 * i;
+        udr[i][q] = (bok && t < T && k < A) ? p.Ud[((size_t)t * B + bb) * A + k] : 0.f;
+      }
+    }
+    const uint32_t key = drop_key(p.dd);
+    const float invT = 1.0f / (float)T;
+    for (int s = 0; s < F; ++s) {
+      // ---- Whr_s[b][j] = sum over the unit groups' rank-16 contributions (fixed order; zero at s = 0: hr_{-1} = 0)
+      float whr = 0.f;
+      if (s >= 1) {
+        lc_wait(relU, fb + (unsigned)s, p.bar);
+        if (bok && j < A) {
+          const float* pw = p.Pw + (((size_t)s * B + b) * p.NG) * A + j;
+          int g = 0;
+          for (; g + 8 <= p.NG; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = pw[(size_t)(g + q) * A];
+            whr += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+          }
+          for (; g < p.NG; ++g) whr += pw[(size_t)g * A];
+        }
+      }
+      swh[c * 128 + j] = whr;
+      if (bok && j < A) p.Whr[((size_t)s * B + b) * A + j] = whr;
+      __syncthreads();
+      {
+        float hk[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int k = lane + 64 * q; hk[q] = (k < A ? swh[c * 128 + k] : 0.f) + bk[q]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = wv + 2 * i;
+          if (t < T) {
+            float sc = wk[0] * rn_tanh(hk[0] + udr[i][0]);
+            if (A > 64) sc += wk[1] * rn_tanh(hk[1] + udr[i][1]);
+            sc = wave_sum(sc);
+            if (lane == 0) { sbeta[c * 32 + t] = sc; if (bok) p.beta[((size_t)s * B + b) * T + t] = sc; }
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int h = j + 128 * q;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 32; t += 2) {
+          if (t < T) a0 += sbeta[c * 32 + t] * hv[q][t];
+          if (t + 1 < T) a1 += sbeta[c * 32 + t + 1] * hv[q][t + 1];
+        }
+        if (h < H) xl[c * 512 + h] = (bf16_t)((a0 + a1) * invT * drop_at(p.dd, key, s, bb, H, h));
+      }
+      __syncthreads();
+      // publish x_s[b]: 16 bytes per k-group, written through; then the row-major copy for the deferred dW_ih GEMM
+      const int pc = tid >> 6, kg = tid & 63, pb = ci * LC_CPW + pc;
+      const bool pon = tid < LC_CPW * 64 && pb < B && kg < (H >> 3);
+      if (pon) lc_store16(p.PanX + (size_t)s * pan_x + ((size_t)kg * RC_PAN_ROWS + pb) * 8, xl + pc * 512 + kg * 8);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(s + 1));
+      if (pon) *reinterpret_cast<bf16x8*>(p.Xcat + ((size_t)s * B + pb) * p.ld_xcat + kg * 8) = *reinterpret_cast<const bf16x8*>(xl + pc * 512 + kg * 8);
+    }
+    __syncthreads();
+    lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(F + 1));
+    return;
+  }
+
+  // ================================================================================== unit-owner workgroups
+  float* red = lc_smem;                                                       // [4 waves][ROWS][RED_LD]; reused as the [ROWS][A + 4] Whr tile
+  bf16_t* hl = reinterpret_cast<bf16_t*>(lc_smem + 4 * ROWS * RED_LD);        // [ROWS][UW]
+  bf16x8* wih = reinterpret_cast<bf16x8*>(lc_smem + 4 * ROWS * RED_LD + ROWS * UW / 2);   // [4 waves][SX][CG][64] B fragments of W_ih
+  const int ug = wg % p.NG, part = wg / p.NG;
+  const int u0 = ug * UW;
+  const int own = RC_PAN_ROWS / p.MS, own_lo = part * own;
+  const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
+  const int kw0 = wave * (STEPS * 32);
+  const int kq = (lane >> 4) * 8;
+  const int rot = ug % NP;
+  auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
+
+  // ---- residents: W_hh (registers), W_ih (LDS, each lane keeps its own fragments), W_r columns of the own units
+  bf16x8 wb[STEPS][CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const int col = g * 16 + (lane & 15), gate = col / UW, ul = col % UW;
+    const bf16_t* wrow = p.W + (size_t)(gate * R + u0 + ul) * p.ldw;
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = k_of(pr, hh);
+        wb[pr * 2 + hh][g] = (k + kq < R) ? *reinterpret_cast<const bf16x8*>(wrow + H + k + kq) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#pragma unroll
+    for (int ks = 0; ks < SX; ++ks) {
+      const int k = (wave * SX + ks) * 32;
+      wih[((wave * SX + ks) * CG + g) * 64 + lane] = (k + kq < H) ? *reinterpret_cast<const bf16x8*>(wrow + k + kq) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  // W_r[a][u0 + (lane / 16) * 4 .. + 4] for a = (2 wave + q) * 16 + lane % 16: B operand of the 16x16x16 MFMA
+  bf16x4 wr[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int a = (2 * wave + q) * 16 + (lane & 15);
+    wr[q] = a < A ? *reinterpret_cast<const bf16x4*>(p.Wr + (size_t)a * p.ldwr + u0 + (lane >> 4) * 4) : bf16x4{0, 0, 0, 0};
+  }
+  constexpr int CPT = (ROWS * UW + 255) / 256;
+  float xb[CPT][4], cpv[CPT];
+  bool mine[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int cell = tid + c * 256, rg = r0 + cell / UW;
+    mine[c] = cell < ROWS * UW && rg >= own_lo && rg < own_lo + own && rg < B;
+    cpv[c] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xb[c][q] = p.bias[q * R + u0 + cell % UW];
+  }
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
+  f32x4 acc[RB][CG];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int g = 0; g < CG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int it_j = tid / own, it_rg = own_lo + tid % own;              // publish item = (k-group of this workgroup, owned row)
+  const bool it_on = tid < KG * own && it_rg < B && it_rg - r0 < ROWS;
+  const bf16_t* it_src = hl + (it_on ? it_rg - r0 : 0) * UW + (it_on ? it_j : 0) * 8;
+
+  for (int s = 0; s < F; ++s) {
+    // ---- x_s . W_ih^T on top of the recurrent part (this wave's K slice of both)
+    lc_wait(relC, fb + (unsigned)(s + 1), p.bar);
+    {
+      const bf16_t* Ax = p.PanX + (size_t)s * pan_x + lane_off;
+      bf16x8 fx[SX][RB];
+#pragma unroll
+      for (int ks = 0; ks < SX; ++ks) {
+        const int k = (wave * SX + ks) * 32;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) fx[ks][i] = *reinterpret_cast<const bf16x8*>(Ax + ((k < H ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+      }
+#pragma unroll
+      for (int ks = 0; ks < SX; ++ks)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+          const bf16x8 bw = wih[((wave * SX + ks) * CG + g) * 64 + lane];
+#pragma unroll
+          for (int i = 0; i < RB; ++i) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[ks][i], bw, acc[i][g], 0, 0, 0);
+        }
+    }
+    {
+      float* prt = red + wave * (ROWS * RED_LD);
+      const int rr = (lane >> 4) * 4, cc = lane & 15;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prt[(i * 16 + rr + r) * RED_LD + g * 16 + cc] = acc[i][g][r];
+          acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    // ---- cell pointwise for UW units x owned rows
+    float hv[CPT], av[CPT][4];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
+      float g4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = xb[c][q];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + row * RED_LD + q * UW + ul];
+        g4[q] = v;
+      }
+      if (p.gru) {
+        const GruOut r = gru_point(g4[0], g4[1], g4[2], g4[3], cpv[c]);
+        hv[c] = r.h; av[c][0] = r.r; av[c][1] = r.z; av[c][2] = r.n; av[c][3] = r.hn; cpv[c] = r.h;
+      } else {
+        const LstmOut r = lstm_point(g4[0], g4[1], g4[2], g4[3], cpv[c]);
+        hv[c] = r.h; av[c][0] = r.i; av[c][1] = r.f; av[c][2] = r.g; av[c][3] = r.o; cpv[c] = r.c;
+      }
+      if (cell < ROWS * UW) hl[cell] = (bf16_t)hv[c];
+    }
+    __syncthreads();
+    const bool more = s + 1 < F;
+    if (more) {
+      // publish hr_s (what the recurrent product of the next step reads)
+      if (it_on) lc_store16(p.PanH + (size_t)s * pan_h + ((size_t)(ug * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, it_src);
+      // this workgroup's rank-16 contribution to Whr_{s+1}: [ROWS x 16 units] . W_r[:, own units]^T, 16x16x16 MFMAs
+      // (wave -> attention columns [32 wave, 32 wave + 32)), staged through LDS so that a lane stores 16 bytes
+      float* tw = red;                                          // [ROWS][A + 4]; red was consumed above
+      const int tld = A + 4;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const bf16x4 fa = *reinterpret_cast<const bf16x4*>(hl + (i * 16 + (lane & 15)) * UW + (lane >> 4) * 4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int a0 = (2 * wave + q) * 16;
+          if (a0 < A) {
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(lc_s4, fa), __builtin_bit_cast(lc_s4, wr[q]),
+                                                                      f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (a0 + (lane & 15) < A) tw[(i * 16 + (lane >> 4) * 4 + r) * tld + a0 + (lane & 15)] = d[r];
+          }
+        }
+      }
+      __syncthreads();
+      {
+        const int nq = A >> 2;                                  // float4 items per row
+        float* Pn = p.Pw + ((size_t)(s + 1) * B * p.NG + ug) * A;
+        for (int idx = tid; idx < own * nq; idx += 256) {
+          const int rg = own_lo + idx / nq, qc = (idx % nq) * 4;
+          if (rg < B && rg - r0 < ROWS) {
+            const float* src = tw + (rg - r0) * tld + qc;
+            union { float f[2]; uint64_t u; } lo, hi;
+            lo.f[0] = src[0]; lo.f[1] = src[1]; hi.f[0] = src[2]; hi.f[1] = src[3];
+            uint64_t* dst = reinterpret_cast<uint64_t*>(Pn + (size_t)rg * p.NG * A + qc);
+            __hip_atomic_store(dst, lo.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, hi.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      lc_arrive(p.bar + wg, fb + (unsigned)(s + 1));
+    }
+    // ---- off the critical path: what the backward and the output layer read
+    float* Ht = p.Hr + (size_t)s * B * R;
+    float* Ct = p.Cr + (size_t)s * B * R;
+    float* At = p.acts + (size_t)s * B * 4 * R;
+    bf16_t* Lt = p.Hlp + (size_t)s * B * p.ld_hlp;
+    if (it_on) *reinterpret_cast<bf16x8*>(Lt + (size_t)it_rg * p.ld_hlp + u0 + it_j * 8) = *reinterpret_cast<const bf16x8*>(it_src);
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      if (mine[c]) {
+        const int row = r0 + cell / UW, u = u0 + cell % UW;
+        const size_t o = (size_t)row * R + u;
+        Ht[o] = hv[c];
+        if (!p.gru) Ct[o] = cpv[c];
+        float* a = At + (size_t)row * 4 * R + u;
+        a[0] = av[c][0]; a[R] = av[c][1]; a[2 * R] = av[c][2]; a[3 * R] = av[c][3];
+      }
+    }
+    if (wg == 0 && p.ld_hlp > R)
+      for (int jj = tid; jj < B * (p.ld_hlp - R); jj += 256) Lt[(size_t)(jj / (p.ld_hlp - R)) * p.ld_hlp + R + jj % (p.ld_hlp - R)] = (bf16_t)0.f;
+    if (more) {
+      // ---- the recurrent product of the NEXT step, hr_s . W_hh^T, as soon as every workgroup has published hr_s; the
+      // attention of step s + 1 runs in the caption workgroups meanwhile
+      lc_wait(relU, fb + (unsigned)(s + 1), p.bar);
+      const bf16_t* Ah = p.PanH + (size_t)s * pan_h + lane_off;
+      bf16x8 fa[PF][2][RB];
+      auto issue_pair = [&](int slot, int pr) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const int k = k_of(pr, hh);
+            fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(Ah + ((k < R ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+          }
+      };
+#pragma unroll
+      for (int pr = 0; pr < PF; ++pr)
+        if (pr < NP) issue_pair(pr, pr);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr) {
+        const int slot = pr % PF;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int ks = pr * 2 + hh;
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int g = 0; g < CG; ++g)
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], wb[ks][g], acc[i][g], 0, 0, 0);
+        }
+        if (pr + PF < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_pair(slot, pr + PF);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  lc_arrive(p.bar + wg, fb + (unsigned)(F + 1));
+}
+template <int RB> constexpr size_t lc_smem_bytes() {
+  return (size_t)4 * RB * 16 * 65 * 4 + (size_t)RB * 16 * 16 * 2 + (size_t)4 * 4 * 4 * 64 * 16;
+}

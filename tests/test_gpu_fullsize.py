@@ -113,19 +113,20 @@ def test_step_is_a_pure_function_of_its_inputs():
     assert torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("kind", ["global", "local"])
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
-def test_chain_kernels_over_changing_batches_match_per_step_kernels(cell, monkeypatch):
+def test_chain_kernels_over_changing_batches_match_per_step_kernels(cell, kind, monkeypatch):
     """The persistent chain kernels keep per-time-step exchange buffers in the workspace and do not invalidate caches at
     their barriers (csrc/rec_chain.hpp, RC_ACQUIRE_INV): run three DIFFERENT batches through one engine — every
     buffer then holds the previous batch's data when the next one starts — and hold each against an engine running the
     per-step kernels.  A stale line anywhere would show up as an O(1) error, not as rounding."""
     decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D, cell), 21)
-    recP = GU.formula_params(GU.rec_shapes("global", H, D, RA, cell), 22)
-    _, dec_a, rec_a = make_models(list(DIMS), "global", "bf16", decP, recP, cells=(cell, cell))
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA, cell), 22)
+    _, dec_a, rec_a = make_models(list(DIMS), kind, "bf16", decP, recP, cells=(cell, cell))
     step_a = R.TrainStep(dec_a, rec_a)
-    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC"):
+    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC", "RN_PERSIST_LOC", "RN_PERSIST_LOC_BWD"):
         monkeypatch.setenv(k, "0")
-    _, dec_b, rec_b = make_models(list(DIMS), "global", "bf16", decP, recP, cells=(cell, cell))
+    _, dec_b, rec_b = make_models(list(DIMS), kind, "bf16", decP, recP, cells=(cell, cell))
     step_b = R.TrainStep(dec_b, rec_b)
     for seed in (11, 12, 13):
         enc = synthetic_features(B, F, D, seed=seed).cuda()
