@@ -87,13 +87,15 @@ def roofline(eng, run_step, kind, precision, iters=5):
     # the dominant kernel is the longest of them.  Otherwise the per-step recurrent GEMM of the reconstructor / decoder.
     cands = [(9, 5, "dec_chain_kernel (decoder forward chain, T steps in one launch)"),
              (10, 6, "dec_chain_bwd_kernel (decoder BPTT chain, T steps in one launch)"),
-             (8, 4, "rec_chain_bwd_kernel<48, 3, 4, 1> (reconstructor backward chain, T steps in one launch)"),
-             (7, 3, "rec_chain_kernel<12, 2, 4, 4> (reconstructor forward chain, T steps in one launch)")]
+             (8, 4, "rec_chain_bwd_kernel<48, 3, 4, 1> (reconstructor backward chain, T steps in one launch)" if kind == "global" else
+                    "loc_chain_bwd_kernel (local reconstructor backward chain, F steps in one launch)"),
+             (7, 3, "rec_chain_kernel<12, 2, 4, 4> (reconstructor forward chain, T steps in one launch)" if kind == "global" else
+                    "loc_chain_kernel (local reconstructor forward chain, F steps in one launch)")]
     best = None
     chains = {}
     meas = []
     for s_id, wh, nm in cands:
-        if wh in (3, 4) and kind != "global":
+        if wh in (3, 4) and kind is None:
             continue
         n_, ms_ = run_step(s_id)
         if n_ > 0:

@@ -81,6 +81,8 @@ struct recnet_handle {
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void* Hr_pan = nullptr;
   void *lc_panh = nullptr, *lc_panx = nullptr; float* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
+  void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
+  int lcb_msx = 1, lcb_rbu = 4, lc_bwd_done = 0;
   int lc_ms = 1, lc_rb = 4, lc_ng = 0, lc_nc = 0;
   void* dG_pan = nullptr;   // exchange copies of the gate gradients, rec_chain_bwd_kernel
   void* WhhT = nullptr;     // [R][ld4R] transpose of Whh_w (K contiguous) for rec_chain_bwd_kernel
@@ -229,6 +231,10 @@ static size_t carve(recnet_handle* h, char* base) {
     h->lc_panh = takev(F * rc_pan_elems((int)R) / 2 + 64);
     h->lc_panx = takev(F * rc_pan_elems((int)H) / 2 + 64);
     h->lc_pw = take(F * B * ((R + 15) / 16) * RA);
+    h->lc_pang = takev(F * rc_pan_elems((int)(4 * R)) / 2 + 64);
+    h->lc_panw = takev(F * rc_pan_elems((int)RA) / 2 + 64);
+    h->lc_dx = take(F * B * H);
+    h->WihhT = takev((H + R) * (size_t)h->ld4R);
   }
   // optimiser tables (sizes are upper bounds; filled at bind time)
   for (int g = 0; g < 2; ++g) {
@@ -322,6 +328,12 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     h->persist_loc = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && h->B <= RC_PAN_ROWS && (h->R & 31) == 0 &&
                      h->R <= 2048 && (h->H & 31) == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 3) == 0 && h->Tm <= 32 &&
                      nwg <= h->ncu && nwg - 1 <= 256;
+    // ... and its backward chain: U' all rows (RB 7) + X' two row parts above 64 captions, one part of 64 rows below
+    const char* eb = getenv("RN_PERSIST_LOC_BWD");
+    h->lcb_msx = h->B > 64 ? 2 : 1; h->lcb_rbu = h->B > 64 ? 7 : 4;
+    const int nwb = h->lc_ng + (h->H / 16) * h->lcb_msx + h->lc_nc + 1;
+    h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && (h->H & 15) == 0 && !(h->B > 64 && h->R > 1536) &&
+                         nwb <= h->ncu && nwb - 1 <= 256;
   }
   {
     const char* e = getenv("RN_DEC_BWD_NT");

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     float* swh = lc_smem;                                   // [LC_CPW][128]
     float* sbeta = swh + LC_CPW * 128;                      // [LC_CPW][32]
     bf16_t* xl = reinterpret_cast<bf16_t*>(sbeta + LC_CPW * 32);   // [LC_CPW][512]
+    float* spw = sbeta + LC_CPW * 32 + LC_CPW * 256;               // [LC_CPW][4][128] partial sums of the Whr contributions
     const int ci = wg - p.NU, c = tid >> 7, j = tid & 127, wv = (tid >> 6) & 1;
     const int b = ci * LC_CPW + c;
     const bool bok = b < B;
@@ -147,17 +148,22 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       float whr = 0.f;
       if (s >= 1) {
         lc_wait(relU, fb + (unsigned)s, p.bar);
-        if (bok && j < A) {
-          const float* pw = p.Pw + (((size_t)s * B + b) * p.NG) * A + j;
-          int g = 0;
-          for (; g + 8 <= p.NG; g += 8) {
-            float v[8];
+        // thread = (attention columns 4 aq .. 4 aq + 3, unit groups gg, gg + 4, ..): every load of the step is issued before
+        // the first use (one memory round trip; the blocks were written by other XCDs a moment ago and come from memory)
+        const int aq = j & 31, gg = j >> 5;
+        f32x4 v[32];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = pw[(size_t)(g + q) * A];
-            whr += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-          }
-          for (; g < p.NG; ++g) whr += pw[(size_t)g * A];
+        for (int q = 0; q < 32; ++q) {
+          const int g = gg + 4 * q;
+          v[q] = (bok && 4 * aq < A && g < p.NG) ? *reinterpret_cast<const f32x4*>(p.Pw + (((size_t)s * B + b) * p.NG + g) * A + 4 * aq)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 32; q += 4) a4 += (v[q] + v[q + 1]) + (v[q + 2] + v[q + 3]);
+        *reinterpret_cast<f32x4*>(spw + ((c * 4 + gg) * 128 + 4 * aq)) = a4;
+        __syncthreads();
+        whr = (spw[(c * 4 + 0) * 128 + j] + spw[(c * 4 + 1) * 128 + j]) + (spw[(c * 4 + 2) * 128 + j] + spw[(c * 4 + 3) * 128 + j]);
       }
       swh[c * 128 + j] = whr;
       if (bok && j < A) p.Whr[((size_t)s * B + b) * A + j] = whr;
@@ -429,4 +435,390 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
 }
 template <int RB> constexpr size_t lc_smem_bytes() {
   return (size_t)4 * RB * 16 * 65 * 4 + (size_t)RB * 16 * 16 * 2 + (size_t)4 * 4 * 4 * 64 * 16;
+}
+
+// =============================================================================================
+// The backward chain of the local reconstructor, one launch (the mirror of loc_chain_kernel; chain step q <-> s = F-1-q):
+//   dhr_s = dHr[s] + dG_{s+1} . W_hh + dWhr_{s+1} . W_r ;  (dG_s, dc) = cell backward
+//   dx_s  = dropmask(s) * (dG_s . W_ih) ;  attention backward of step s: dbeta, dHs +=, dUd +=, dw +=, dWhr_s
+// Three kinds of resident workgroups and three relayed hand-overs per step:
+//   U' (16 output units of dhr, all rows or one row part): its rows of [W_ih | W_hh]^T (K = 4R contiguous, image WT) in
+//      registers; per step the recurrent product over the gate-gradient panel of the step before (off the critical path:
+//      it runs while X' and C' work), then the small product with dWhr (K = A), cell backward, publishes dG_s;
+//   X' (16 columns of dx x one row part): the same product with the W_ih rows of WT; publishes dx_s (fp32, masked);
+//   C' (two captions): h_t, Ud[t] and the dHs / dUd / dw accumulators live in registers for all F steps; publishes dWhr_s.
+// The panels are indexed by chain step (fresh addresses every step, rec_chain.hpp).
+struct LocChainBwdArgs {
+  int F, T, B, R, H, A, gru;
+  int NGU, MSU, NGX, MSX, NC;        // U' = NGU unit groups x MSU row parts, X' = NGX column groups x MSX row parts, C'
+  const bf16_t* WT; int ldwt;        // [H + R][ldwt]: rows [0,H) = W_ih^T (x columns), rows [H, H+R) = W_hh^T; K = 4R contiguous
+  const bf16_t* Wr; int ldwr;        // [A][ldwr]
+  const float* dHr;                  // [F][B][R] d loss / d hr_s through the output layer
+  const float* acts; const float* Cr; const float* Hr;     // saved by the forward
+  const float* Hs; const float* Ud; const float* ab; const float* w;
+  const float* Whr; const float* beta;                       // [F][B][A], [F][B][T]
+  bf16_t* dG; int ld_dg;             // [F][B][ld_dg] row-major gate gradients (deferred weight-gradient GEMMs)
+  bf16_t* dWhrs; int ld_dwhr;        // [F][B][ld_dwhr] row-major dWhr_s (deferred attn_W / attn_b gradients)
+  float* dHs;                        // [T][B][H] out: d loss / d decoder states (attention path)
+  float* dUd; bf16_t* dUd_lp; int ld_dUd;   // [T][B][A] (+ operand copy, zero padded)
+  float* dwacc;                      // [nch][B][A]: chunk 0 = sum_t dbeta tanh(.), other chunks zero
+  int nch;
+  bf16_t* PanG; bf16_t* PanW; float* Dx;    // exchange: [F][rc_pan_elems(4R)], [F][rc_pan_elems(A)], [F][B][H]
+  unsigned* bar; unsigned* epoch; float* poison;
+  DropDesc dd;
+};
+
+// acc[i] += rows [r0 + 16 i, +16) of the panel (K-group-major, all of K) . this lane's resident weight fragments
+template <int STEPS, int PF, int RB>
+__device__ __forceinline__ void lcb_product(f32x4 (&acc)[RB], const bf16x8 (&wb)[STEPS], const bf16_t* A, int K, int kw0, int rot) {
+  constexpr int NP = STEPS / 2;
+  auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
+  bf16x8 fa[PF][2][RB];
+  auto issue_pair = [&](int slot, int pr) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int k = k_of(pr, hh);
+        fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(A + ((k < K ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+      }
+  };
+#pragma unroll
+  for (int pr = 0; pr < PF; ++pr)
+    if (pr < NP) issue_pair(pr, pr);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
+    const int slot = pr % PF;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], wb[pr * 2 + hh], acc[i], 0, 0, 0);
+    if (pr + PF < NP) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_pair(slot, pr + PF);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+template <int STEPS>
+__device__ __forceinline__ void lcb_load_weights(bf16x8 (&wb)[STEPS], const bf16_t* wrow, int K, int kw0, int rot, int kq) {
+  constexpr int NP = STEPS / 2;
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      int prr = pr + rot; prr = prr >= NP ? prr - NP : prr;
+      const int k = kw0 + (prr * 2 + hh) * 32;
+      wb[pr * 2 + hh] = (k + kq < K) ? *reinterpret_cast<const bf16x8*>(wrow + k + kq) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+template <int STEPS, int PF, int RBU, int RBX>
+__global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArgs p) {
+  constexpr int UW = 16, RED_LD = UW + 1, KG = UW / 8;
+  extern __shared__ __attribute__((aligned(16))) float lc_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x, R = p.R, B = p.B, H = p.H, A = p.A, F = p.F, T = p.T, K = 4 * R;
+  const int NU = p.NGU * p.MSU, NX = p.NGX * p.MSX;
+  const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
+  unsigned* relG = p.bar + 256; unsigned* relX = p.bar + 256 + 8; unsigned* relW = p.bar + 256 + 16;
+  const size_t pan_g = rc_pan_elems(K), pan_w = rc_pan_elems(A);
+  const int kq = (lane >> 4) * 8, kw0 = wave * (STEPS * 32);
+
+  // ================================================================================== relay workgroup
+  if (wg == NU + NX + p.NC) {
+    if (tid < 64) {
+      unsigned spin = 0;
+      for (int q = 0; q < F; ++q) {
+        lc_poll(p.bar, NU, fb + (unsigned)(q + 1), p.bar, spin); lc_release(relG, fb + (unsigned)(q + 1));
+        lc_poll(p.bar + NU, NX, fb + (unsigned)(q + 1), p.bar, spin); lc_release(relX, fb + (unsigned)(q + 1));
+        lc_poll(p.bar + NU + NX, p.NC, fb + (unsigned)(q + 1), p.bar, spin); lc_release(relW, fb + (unsigned)(q + 1));
+      }
+      lc_poll(p.bar, NU + NX + p.NC, fb + (unsigned)(F + 1), p.bar, spin);
+      if (tid == 0) {
+        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
+      }
+    }
+    return;
+  }
+
+  // ================================================================================== caption workgroups
+  if (wg >= NU + NX) {
+    float* sdb = lc_smem;                                   // [LC_CPW][2 waves][32] partial dbeta
+    float* sbt = sdb + LC_CPW * 64;                         // [LC_CPW][32] beta_s / T
+    float* sdbt = sbt + LC_CPW * 32;                        // [LC_CPW][32] dbeta
+    bf16_t* swl = reinterpret_cast<bf16_t*>(sdbt + LC_CPW * 32);    // [LC_CPW][128] dWhr_s (bf16)
+    const int ci = wg - NU - NX, c = tid >> 7, j = tid & 127, wv = (tid >> 6) & 1;
+    const int b = ci * LC_CPW + c;
+    const bool bok = b < B;
+    const int bb = bok ? b : 0;
+    const bool kon = bok && j < A;
+    float hv[4][32], dhs[4][32], ud[32], dud[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int h = j + 128 * q;
+        hv[q][t] = (bok && t < T && h < H) ? p.Hs[((size_t)t * B + bb) * H + h] : 0.f;
+        dhs[q][t] = 0.f;
+      }
+      ud[t] = (kon && t < T) ? p.Ud[((size_t)t * B + bb) * A + j] : 0.f;
+      dud[t] = 0.f;
+    }
+    const float wk = kon ? p.w[j] : 0.f, abk = kon ? p.ab[j] : 0.f;
+    float dwa = 0.f;
+    const uint32_t key = drop_key(p.dd);
+    const float invT = 1.0f / (float)T;
+    for (int q = 0; q < F; ++q) {
+      const int s = F - 1 - q;
+      // saved tensors of step s: independent of the chain, requested before waiting
+      const float whk = (kon ? p.Whr[((size_t)s * B + b) * A + j] : 0.f) + abk;
+      const float bet = (bok && j < T) ? p.beta[((size_t)s * B + b) * T + j] : 0.f;
+      if (j < 32) sbt[c * 32 + j] = bet * invT;
+      lc_wait(relX, fb + (unsigned)(q + 1), p.bar);
+      float dx[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int h = j + 128 * qq;
+        dx[qq] = (bok && h < H) ? p.Dx[((size_t)q * B + b) * H + h] : 0.f;
+      }
+      // dbeta[t] = (1/T) dx . h_t : per-thread partial over its four columns, wave sum, two waves per caption
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        if (t < T) {
+          float v = (dx[0] * hv[0][t] + dx[1] * hv[1][t]) + (dx[2] * hv[2][t] + dx[3] * hv[3][t]);
+          v = wave_sum(v);
+          if (lane == 0) sdb[(c * 2 + wv) * 32 + t] = v;
+        }
+      }
+      __syncthreads();
+      if (j < 32) sdbt[c * 32 + j] = (sdb[(c * 2) * 32 + j] + sdb[(c * 2 + 1) * 32 + j]) * invT;
+      // dHs[t] += (beta_s[t] / T) dx
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        if (t < T) {
+          const float bt = sbt[c * 32 + t];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) dhs[qq][t] += bt * dx[qq];
+        }
+      }
+      __syncthreads();
+      // (t, k) plane, thread = k: dz = dbeta[t] w_k (1 - tanh^2), dUd[t] += dz, dWhr_s = sum_t dz, dw += sum_t dbeta[t] tanh
+      float dwh = 0.f;
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        if (t < T) {
+          const float tz = rn_tanh(whk + ud[t]);
+          const float db = sdbt[c * 32 + t];
+          const float dz = db * wk * (1.f - tz * tz);
+          dwa += db * tz;
+          dwh += dz;
+          dud[t] += dz;
+        }
+      }
+      swl[c * 128 + j] = (bf16_t)(kon ? dwh : 0.f);
+      __syncthreads();
+      // publish dWhr_s[b]: 16 bytes per k-group, written through; then the row-major copy (zero padded)
+      const int pc = tid >> 6, kg = tid & 63, pb = ci * LC_CPW + pc;
+      const bool pon = tid < LC_CPW * 64 && pb < B;
+      // (k-groups up to the next multiple of 32 columns: the consumer's k-step reads them; swl holds zeros beyond A)
+      if (pon && kg < (((A + 31) >> 5) << 2)) lc_store16(p.PanW + (size_t)q * pan_w + ((size_t)kg * RC_PAN_ROWS + pb) * 8, swl + pc * 128 + kg * 8);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      lc_arrive(p.bar + NU + NX + ci, fb + (unsigned)(q + 1));
+      if (pon && kg < (p.ld_dwhr >> 3) && kg < 16)
+        *reinterpret_cast<bf16x8*>(p.dWhrs + ((size_t)s * B + pb) * p.ld_dwhr + kg * 8) = *reinterpret_cast<const bf16x8*>(swl + pc * 128 + kg * 8);
+    }
+    // ---- the accumulators
+    if (bok) {
+#pragma unroll
+      for (int t = 0; t < 32; ++t) {
+        if (t < T) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) { const int h = j + 128 * qq; if (h < H) p.dHs[((size_t)t * B + b) * H + h] = dhs[qq][t]; }
+          if (j < A) { p.dUd[((size_t)t * B + b) * A + j] = dud[t]; p.dUd_lp[((size_t)t * B + b) * p.ld_dUd + j] = (bf16_t)dud[t]; }
+          else if (j < p.ld_dUd) p.dUd_lp[((size_t)t * B + b) * p.ld_dUd + j] = (bf16_t)0.f;
+        }
+      }
+      if (j < A) {
+        p.dwacc[(size_t)b * A + j] = dwa;
+        for (int ch = 1; ch < p.nch; ++ch) p.dwacc[((size_t)ch * B + b) * A + j] = 0.f;
+      }
+    }
+    __syncthreads();
+    lc_arrive(p.bar + NU + NX + ci, fb + (unsigned)(F + 1));
+    return;
+  }
+
+  // ================================================================================== X': dx_s = mask * dG_s . W_ih
+  if (wg >= NU) {
+    constexpr int ROWS = RBX * 16;
+    float* red = lc_smem;                                   // [4 waves][ROWS][RED_LD]
+    const int xi = wg - NU, xg = xi % p.NGX, part = xi / p.NGX;
+    const int j0 = xg * UW;
+    const int own = RC_PAN_ROWS / p.MSX, own_lo = part * own;
+    const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
+    const int rot = xg % (STEPS / 2);
+    bf16x8 wb[STEPS];
+    {
+      const int jr = j0 + (lane & 15);
+      lcb_load_weights<STEPS>(wb, p.WT + (size_t)(jr < H ? jr : 0) * p.ldwt, jr < H ? K : 0, kw0, rot, kq);
+    }
+    const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
+    const uint32_t key = drop_key(p.dd);
+    for (int q = 0; q < F; ++q) {
+      const int s = F - 1 - q;
+      lc_wait(relG, fb + (unsigned)(q + 1), p.bar);
+      f32x4 acc[RBX];
+#pragma unroll
+      for (int i = 0; i < RBX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lcb_product<STEPS, PF, RBX>(acc, wb, p.PanG + (size_t)q * pan_g + lane_off, K, kw0, rot);
+      float* prt = red + wave * (ROWS * RED_LD);
+#pragma unroll
+      for (int i = 0; i < RBX; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + (lane & 15)] = acc[i][r];
+      __syncthreads();
+      for (int idx = tid; idx < own * (UW / 2); idx += 256) {
+        const int rg = own_lo + idx / (UW / 2), pc = (idx % (UW / 2)) * 2, rl = rg - r0;
+        if (rg < B && rl < ROWS && j0 + pc < H) {
+          float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { v0 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc]; v1 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc + 1]; }
+          union { float f[2]; uint64_t u; } pk;
+          pk.f[0] = v0 * drop_at(p.dd, key, s, rg, H, j0 + pc); pk.f[1] = v1 * drop_at(p.dd, key, s, rg, H, j0 + pc + 1);
+          __hip_atomic_store(reinterpret_cast<uint64_t*>(p.Dx + ((size_t)q * B + rg) * H + j0 + pc), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      lc_arrive(p.bar + wg, fb + (unsigned)(q + 1));
+    }
+    __syncthreads();
+    lc_arrive(p.bar + wg, fb + (unsigned)(F + 1));
+    return;
+  }
+
+  // ================================================================================== U': dhr, cell backward, dG_s
+  constexpr int ROWS = RBU * 16;
+  float* red = lc_smem;                                                           // [4 waves][ROWS][RED_LD]
+  bf16_t* hl = reinterpret_cast<bf16_t*>(lc_smem + ((4 * ROWS * RED_LD + 3) / 4) * 4);   // [ROWS][4][UW]
+  const int ug = wg % p.NGU, part = wg / p.NGU;
+  const int u0 = ug * UW;
+  const int own = RC_PAN_ROWS / p.MSU, own_lo = part * own;
+  const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
+  const int rot = ug % (STEPS / 2);
+  bf16x8 wb[STEPS];
+  lcb_load_weights<STEPS>(wb, p.WT + (size_t)(H + u0 + (lane & 15)) * p.ldwt, K, kw0, rot, kq);
+  // W_r^T fragment of the small product (K = A <= 128: one k-step per wave): B[k = a][n = unit]
+  bf16x8 wrt;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int a = wave * 32 + kq + e;
+    wrt[e] = a < A ? p.Wr[(size_t)a * p.ldwr + u0 + (lane & 15)] : (bf16_t)0.f;
+  }
+  constexpr int CPT = (ROWS * UW + 255) / 256;
+  bool mine[CPT];
+  float direct[CPT], carry[CPT], av[CPT][4], cc[CPT], cp[CPT];
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int cell = tid + c * 256, rg = r0 + cell / UW;
+    mine[c] = cell < ROWS * UW && rg >= own_lo && rg < own_lo + own && rg < B;
+    carry[c] = 0.f;
+  }
+  auto prefetch = [&](int s) {                            // saved activations, states and the direct gradient of step s
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const size_t row = mine[c] ? r0 + cell / UW : 0;
+      const int u = u0 + cell % UW;
+      const float* a = p.acts + ((size_t)s * B + row) * 4 * R + u;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) av[c][qq] = a[(size_t)qq * R];
+      cc[c] = p.gru ? 0.f : p.Cr[((size_t)s * B + row) * R + u];
+      cp[c] = s > 0 ? (p.gru ? p.Hr : p.Cr)[((size_t)(s - 1) * B + row) * R + u] : 0.f;
+      direct[c] = mine[c] ? p.dHr[((size_t)s * B + row) * R + u] : 0.f;
+    }
+  };
+  prefetch(F - 1);
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
+  constexpr int IPT = (4 * KG * RC_PAN_ROWS + 255) / 256;            // upper bound: own <= 112
+  const bf16_t* it_src[IPT]; int it_rg[IPT], it_col[IPT]; bool it_on[IPT];
+#pragma unroll
+  for (int jj = 0; jj < IPT; ++jj) {
+    const int idx = tid + jj * 256;
+    const int gq = idx / (KG * own), rem = idx - gq * (KG * own), kgi = rem / own, rg = own_lo + rem % own;
+    it_on[jj] = idx < 4 * KG * own && rg < B && rg - r0 < ROWS;
+    it_rg[jj] = rg; it_col[jj] = gq * R + u0 + kgi * 8;
+    it_src[jj] = hl + ((size_t)(it_on[jj] ? rg - r0 : 0) * 4 + (it_on[jj] ? gq : 0)) * UW + kgi * 8;
+  }
+
+  for (int q = 0; q < F; ++q) {
+    const int s = F - 1 - q;
+    if (q > 0) {
+      f32x4 acc[RBU];
+#pragma unroll
+      for (int i = 0; i < RBU; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      lc_wait(relG, fb + (unsigned)q, p.bar);                        // dG_{s+1} is complete
+      lcb_product<STEPS, PF, RBU>(acc, wb, p.PanG + (size_t)(q - 1) * pan_g + lane_off, K, kw0, rot);
+      lc_wait(relW, fb + (unsigned)q, p.bar);                        // dWhr_{s+1} is complete
+      {
+        const int k = wave * 32;
+        const bf16_t* Aw = p.PanW + (size_t)(q - 1) * pan_w + lane_off;
+        if (k < A) {
+#pragma unroll
+          for (int i = 0; i < RBU; ++i) {
+            const bf16x8 fw = *reinterpret_cast<const bf16x8*>(Aw + ((k >> 3) * RC_PAN_ROWS + i * 16) * 8);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, wrt, acc[i], 0, 0, 0);
+          }
+        }
+      }
+      float* prt = red + wave * (ROWS * RED_LD);
+#pragma unroll
+      for (int i = 0; i < RBU; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + (lane & 15)] = acc[i][r];
+      __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
+      float dh = direct[c];
+      if (q > 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) dh += red[w * (ROWS * RED_LD) + row * RED_LD + ul];
+      }
+      const LstmGrad g = p.gru ? gru_point_bwd(dh + carry[c], av[c][0], av[c][1], av[c][2], av[c][3], cp[c])
+                               : lstm_point_bwd(dh, carry[c], av[c][0], av[c][1], av[c][2], av[c][3], cc[c], cp[c]);
+      carry[c] = g.dc_prev;
+      if (cell < ROWS * UW) {
+        bf16_t* d = hl + (size_t)row * 4 * UW + ul;
+        d[0] = (bf16_t)g.di; d[UW] = (bf16_t)g.df; d[2 * UW] = (bf16_t)g.dg; d[3 * UW] = (bf16_t)g.d_o;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < IPT; ++jj)
+      if (it_on[jj]) lc_store16(p.PanG + (size_t)q * pan_g + ((size_t)(it_col[jj] >> 3) * RC_PAN_ROWS + it_rg[jj]) * 8, it_src[jj]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lc_arrive(p.bar + wg, fb + (unsigned)(q + 1));
+    // ---- off the critical path: the row-major copy for the deferred weight-gradient GEMMs
+    bf16_t* Gt = p.dG + (size_t)s * B * p.ld_dg;
+#pragma unroll
+    for (int jj = 0; jj < IPT; ++jj)
+      if (it_on[jj]) *reinterpret_cast<bf16x8*>(Gt + (size_t)it_rg[jj] * p.ld_dg + it_col[jj]) = *reinterpret_cast<const bf16x8*>(it_src[jj]);
+    if (wg == 0 && p.ld_dg > K)
+      for (int jj = tid; jj < B * (p.ld_dg - K); jj += 256) Gt[(size_t)(jj / (p.ld_dg - K)) * p.ld_dg + K + jj % (p.ld_dg - K)] = (bf16_t)0.f;
+    if (q + 1 < F) prefetch(s - 1);
+  }
+  __syncthreads();
+  lc_arrive(p.bar + wg, fb + (unsigned)(F + 1));
+}
+template <int RBU, int RBX> constexpr size_t lcb_smem_bytes() {
+  constexpr int RB = RBU > RBX ? RBU : RBX;
+  return ((size_t)4 * RB * 16 * 17 + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * 2 + 1024;
 }
