@@ -282,6 +282,9 @@ int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, c
 int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, int32_t b_col, int32_t ldb, float* C,
                      int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
                      int32_t splitk, float* splitk_ws, int32_t tag, void* stream);
+/* Probe builds only (csrc: make PROBE=1): in-kernel wall-clock stamps of the local chain kernels' last launch,
+ * [role][step][8] uint64 ticks; RECNET_ESTATE in the product build. */
+int recnet_probe_read(recnet_handle* h, uint64_t* out, int32_t n);
 /* Dimensions a handle was created with (the torch.ops layer sizes its outputs from these). */
 #define RECNET_DIM_B 0
 #define RECNET_DIM_F 1

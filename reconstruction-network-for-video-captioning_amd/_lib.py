@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip.so")
+LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip_probe.so" if os.environ.get("RN_LIB_PROBE") == "1" else "librecnet_hip.so")
 ABI_VERSION = 3
 
 REC_NONE, REC_GLOBAL, REC_LOCAL = 0, 1, 2
@@ -141,3 +141,4 @@ EXPORTS["recnet_reconstructor_step"] = (_i, [C.c_void_p] * 5 + [_i] + [C.c_void_
 EXPORTS["recnet_chain_status"] = (_i, [C.c_void_p, C.POINTER(_i), C.c_void_p])
 EXPORTS["recnet_chain_reset"] = (_i, [C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_dim"] = (_i, [C.c_void_p, _i])
+EXPORTS["recnet_probe_read"] = (_i, [C.c_void_p, C.c_void_p, _i])

@@ -83,6 +83,7 @@ struct recnet_handle {
   void *lc_panh = nullptr, *lc_panx = nullptr; float* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
   void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
   int lcb_msx = 1, lcb_rbu = 4, lc_bwd_done = 0;
+  unsigned long long* lc_ts = nullptr;   // probe builds (make PROBE=1): wall-clock stamps of the local chain kernels
   int lc_ms = 1, lc_rb = 4, lc_ng = 0, lc_nc = 0;
   void* dG_pan = nullptr;   // exchange copies of the gate gradients, rec_chain_bwd_kernel
   void* WhhT = nullptr;     // [R][ld4R] transpose of Whh_w (K contiguous) for rec_chain_bwd_kernel
@@ -146,6 +147,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
   h->dc_G2 = take(2 * Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
   h->scal = take(64);
+  h->lc_ts = (unsigned long long*)take(2 * 8 * 64 * 8);
   h->stepw = take(Tm);
   h->msep = take(1024);
   h->bsum_d = take(4 * H);

@@ -36,8 +36,14 @@ struct LocChainArgs {
   float* Pw;                          // exchange: [F][B][NG][A] rank-16 contributions to Whr of step s (written at s-1)
   unsigned* bar; unsigned* epoch; float* poison;
   DropDesc dd;
+  unsigned long long* ts;             // probe builds only (LC_PROBE): [role][step][8] wall-clock stamps of one workgroup per role
 };
 
+#ifdef LC_PROBE
+#define LC_TS(role, step, i) do { if (tid == 0) p.ts[((size_t)(role) * 64 + (step)) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define LC_TS(role, step, i) do { } while (0)
+#endif
 #define LC_CPW 2              // captions per C workgroup
 __device__ __forceinline__ void lc_poll(const unsigned* flags, int n, unsigned target, unsigned* bar, unsigned& spin) {
   // wave 0 of the relay workgroup: all n <= 256 flags have reached `target`
@@ -100,7 +106,9 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       unsigned spin = 0;
       for (int s = 0; s < F; ++s) {
         if (s >= 1) { lc_poll(p.bar, p.NU, fb + (unsigned)s, p.bar, spin); lc_release(relU, fb + (unsigned)s); }
+        LC_TS(2, s, 0);
         lc_poll(p.bar + p.NU, p.NC, fb + (unsigned)(s + 1), p.bar, spin); lc_release(relC, fb + (unsigned)(s + 1));
+        LC_TS(2, s, 1);
       }
       lc_poll(p.bar, p.NU + p.NC, fb + (unsigned)(F + 1), p.bar, spin);      // everybody is done (and has read the epoch)
       if (tid == 0) {
@@ -117,7 +125,9 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     float* sbeta = swh + LC_CPW * 128;                      // [LC_CPW][32]
     bf16_t* xl = reinterpret_cast<bf16_t*>(sbeta + LC_CPW * 32);   // [LC_CPW][512]
     float* spw = sbeta + LC_CPW * 32 + LC_CPW * 256;               // [LC_CPW][4][128] partial sums of the Whr contributions
-    const int ci = wg - p.NU, c = tid >> 7, j = tid & 127, wv = (tid >> 6) & 1;
+    float* swab = spw + LC_CPW * 4 * 128;                          // [128][2] (w_k, b_k)
+    float* spb = swab + 256;                                       // [LC_CPW][4][32] partial scores
+    const int ci = wg - p.NU, c = tid >> 7, j = tid & 127;
     const int b = ci * LC_CPW + c;
     const bool bok = b < B;
     const int bb = bok ? b : 0;
@@ -130,17 +140,16 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
         const int h = j + 128 * q;
         hv[q][t] = (bok && t < T && h < H) ? p.Hs[((size_t)t * B + bb) * H + h] : 0.f;
       }
-    float udr[16][2], wk[2], bk[2];
+    // scores: thread = (decoder step tt = j % 32, attention columns [32 kq4, 32 kq4 + 32)): the sum over k is mostly inside a
+    // thread (32 independent tanh), the four column quarters are added through LDS — no wavefront reductions
+    const int tt = j & 31, kq4 = j >> 5;
+    float udr[32];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int k = lane + 64 * q;
-      wk[q] = k < A ? p.w[k] : 0.f; bk[q] = k < A ? p.ab[k] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int t = wv + 2 * i;
-        udr[i][q] = (bok && t < T && k < A) ? p.Ud[((size_t)t * B + bb) * A + k] : 0.f;
-      }
+    for (int i = 0; i < 32; ++i) {
+      const int k = 32 * kq4 + i;
+      udr[i] = (bok && tt < T && k < A) ? p.Ud[((size_t)tt * B + bb) * A + k] : 0.f;
     }
+    if (tid < 128) { swab[2 * tid] = tid < A ? p.w[tid] : 0.f; swab[2 * tid + 1] = tid < A ? p.ab[tid] : 0.f; }
     const uint32_t key = drop_key(p.dd);
     const float invT = 1.0f / (float)T;
     for (int s = 0; s < F; ++s) {
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       float whr = 0.f;
       if (s >= 1) {
         lc_wait(relU, fb + (unsigned)s, p.bar);
+        if (ci == 0) LC_TS(1, s, 0);
         // thread = (attention columns 4 aq .. 4 aq + 3, unit groups gg, gg + 4, ..): every load of the step is issued before
         // the first use (one memory round trip; the blocks were written by other XCDs a moment ago and come from memory)
         const int aq = j & 31, gg = j >> 5;
@@ -168,20 +178,24 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       swh[c * 128 + j] = whr;
       if (bok && j < A) p.Whr[((size_t)s * B + b) * A + j] = whr;
       __syncthreads();
+      if (ci == 0) LC_TS(1, s, 1);
       {
-        float hk[2];
+        float sc0 = 0.f, sc1 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { const int k = lane + 64 * q; hk[q] = (k < A ? swh[c * 128 + k] : 0.f) + bk[q]; }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int t = wv + 2 * i;
-          if (t < T) {
-            float sc = wk[0] * rn_tanh(hk[0] + udr[i][0]);
-            if (A > 64) sc += wk[1] * rn_tanh(hk[1] + udr[i][1]);
-            sc = wave_sum(sc);
-            if (lane == 0) { sbeta[c * 32 + t] = sc; if (bok) p.beta[((size_t)s * B + b) * T + t] = sc; }
-          }
+        for (int i = 0; i < 32; i += 2) {
+          const int k = 32 * kq4 + i;
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(swab + 2 * k);          // (w_k, b_k, w_k+1, b_k+1)
+          const float h0 = swh[c * 128 + k], h1 = swh[c * 128 + k + 1];
+          sc0 += wa[0] * rn_tanh(h0 + wa[1] + udr[i]);
+          sc1 += wa[2] * rn_tanh(h1 + wa[3] + udr[i + 1]);
         }
+        spb[(c * 4 + kq4) * 32 + tt] = sc0 + sc1;
+      }
+      __syncthreads();
+      if (kq4 == 0) {
+        const float sc = (spb[(c * 4) * 32 + tt] + spb[(c * 4 + 1) * 32 + tt]) + (spb[(c * 4 + 2) * 32 + tt] + spb[(c * 4 + 3) * 32 + tt]);
+        sbeta[c * 32 + tt] = sc;
+        if (bok && tt < T) p.beta[((size_t)s * B + b) * T + tt] = sc;
       }
       __syncthreads();
 #pragma unroll
@@ -189,13 +203,14 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
         const int h = j + 128 * q;
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-        for (int t = 0; t < 32; t += 2) {
-          if (t < T) a0 += sbeta[c * 32 + t] * hv[q][t];
-          if (t + 1 < T) a1 += sbeta[c * 32 + t + 1] * hv[q][t + 1];
+        for (int t = 0; t < 32; t += 2) {       // (h_t is held as zero for t >= T)
+          a0 += sbeta[c * 32 + t] * hv[q][t];
+          a1 += sbeta[c * 32 + t + 1] * hv[q][t + 1];
         }
         if (h < H) xl[c * 512 + h] = (bf16_t)((a0 + a1) * invT * drop_at(p.dd, key, s, bb, H, h));
       }
       __syncthreads();
+      if (ci == 0) LC_TS(1, s, 2);
       // publish x_s[b]: 16 bytes per k-group, written through; then the row-major copy for the deferred dW_ih GEMM
       const int pc = tid >> 6, kg = tid & 63, pb = ci * LC_CPW + pc;
       const bool pon = tid < LC_CPW * 64 && pb < B && kg < (H >> 3);
@@ -203,6 +218,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(s + 1));
+      if (ci == 0) LC_TS(1, s, 3);
       if (pon) *reinterpret_cast<bf16x8*>(p.Xcat + ((size_t)s * B + pb) * p.ld_xcat + kg * 8) = *reinterpret_cast<const bf16x8*>(xl + pc * 512 + kg * 8);
     }
     __syncthreads();
@@ -273,6 +289,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
   for (int s = 0; s < F; ++s) {
     // ---- x_s . W_ih^T on top of the recurrent part (this wave's K slice of both)
     lc_wait(relC, fb + (unsigned)(s + 1), p.bar);
+    if (wg == 0) LC_TS(0, s, 0);
     {
       const bf16_t* Ax = p.PanX + (size_t)s * pan_x + lane_off;
       bf16x8 fx[SX][RB];
@@ -304,6 +321,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
         }
     }
     __syncthreads();
+    if (wg == 0) LC_TS(0, s, 1);
     // ---- cell pointwise for UW units x owned rows
     float hv[CPT], av[CPT][4];
 #pragma unroll
@@ -328,6 +346,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       if (cell < ROWS * UW) hl[cell] = (bf16_t)hv[c];
     }
     __syncthreads();
+    if (wg == 0) LC_TS(0, s, 2);
     const bool more = s + 1 < F;
     if (more) {
       // publish hr_s (what the recurrent product of the next step reads)
@@ -367,9 +386,11 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
           }
         }
       }
+      if (wg == 0) LC_TS(0, s, 3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       lc_arrive(p.bar + wg, fb + (unsigned)(s + 1));
+      if (wg == 0) LC_TS(0, s, 4);
     }
     // ---- off the critical path: what the backward and the output layer read
     float* Ht = p.Hr + (size_t)s * B * R;
@@ -395,6 +416,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       // ---- the recurrent product of the NEXT step, hr_s . W_hh^T, as soon as every workgroup has published hr_s; the
       // attention of step s + 1 runs in the caption workgroups meanwhile
       lc_wait(relU, fb + (unsigned)(s + 1), p.bar);
+      if (wg == 0) LC_TS(0, s, 5);
       const bf16_t* Ah = p.PanH + (size_t)s * pan_h + lane_off;
       bf16x8 fa[PF][2][RB];
       auto issue_pair = [&](int slot, int pr) {
@@ -428,6 +450,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (wg == 0) LC_TS(0, s, 6);
     }
   }
   __syncthreads();
@@ -466,6 +489,7 @@ struct LocChainBwdArgs {
   bf16_t* PanG; bf16_t* PanW; float* Dx;    // exchange: [F][rc_pan_elems(4R)], [F][rc_pan_elems(A)], [F][B][H]
   unsigned* bar; unsigned* epoch; float* poison;
   DropDesc dd;
+  unsigned long long* ts;            // probe builds only
 };
 
 // acc[i] += rows [r0 + 16 i, +16) of the panel (K-group-major, all of K) . this lane's resident weight fragments
@@ -532,8 +556,11 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       unsigned spin = 0;
       for (int q = 0; q < F; ++q) {
         lc_poll(p.bar, NU, fb + (unsigned)(q + 1), p.bar, spin); lc_release(relG, fb + (unsigned)(q + 1));
+        LC_TS(3, q, 0);
         lc_poll(p.bar + NU, NX, fb + (unsigned)(q + 1), p.bar, spin); lc_release(relX, fb + (unsigned)(q + 1));
+        LC_TS(3, q, 1);
         lc_poll(p.bar + NU + NX, p.NC, fb + (unsigned)(q + 1), p.bar, spin); lc_release(relW, fb + (unsigned)(q + 1));
+        LC_TS(3, q, 2);
       }
       lc_poll(p.bar, NU + NX + p.NC, fb + (unsigned)(F + 1), p.bar, spin);
       if (tid == 0) {
@@ -546,64 +573,60 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 
   // ================================================================================== caption workgroups
   if (wg >= NU + NX) {
-    float* sdb = lc_smem;                                   // [LC_CPW][2 waves][32] partial dbeta
-    float* sbt = sdb + LC_CPW * 64;                         // [LC_CPW][32] beta_s / T
-    float* sdbt = sbt + LC_CPW * 32;                        // [LC_CPW][32] dbeta
+    float* sdx = lc_smem;                                   // [LC_CPW][512] dx_s
+    float* spd = sdx + LC_CPW * 512;                        // [LC_CPW][4][32] partial dbeta
+    float* sdbt = spd + LC_CPW * 128;                       // [LC_CPW][32] dbeta
     bf16_t* swl = reinterpret_cast<bf16_t*>(sdbt + LC_CPW * 32);    // [LC_CPW][128] dWhr_s (bf16)
-    const int ci = wg - NU - NX, c = tid >> 7, j = tid & 127, wv = (tid >> 6) & 1;
+    const int ci = wg - NU - NX, c = tid >> 7, j = tid & 127;
     const int b = ci * LC_CPW + c;
     const bool bok = b < B;
     const int bb = bok ? b : 0;
     const bool kon = bok && j < A;
-    float hv[4][32], dhs[4][32], ud[32], dud[32];
+    // thread = (decoder step tt, quarter hq of the hidden columns): its 128 values of h_tt and of the dHs accumulator;
+    // thread = attention column k = j for the (t, k) plane: Ud[t][k] and the dUd accumulator for every t
+    const int tt = j & 31, hq = j >> 5;
+    float hv[128], dhs[128], ud[32], dud[32];
+#pragma unroll
+    for (int i = 0; i < 128; ++i) {
+      const int h = 128 * hq + i;
+      hv[i] = (bok && tt < T && h < H) ? p.Hs[((size_t)tt * B + bb) * H + h] : 0.f;
+      dhs[i] = 0.f;
+    }
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int h = j + 128 * q;
-        hv[q][t] = (bok && t < T && h < H) ? p.Hs[((size_t)t * B + bb) * H + h] : 0.f;
-        dhs[q][t] = 0.f;
-      }
       ud[t] = (kon && t < T) ? p.Ud[((size_t)t * B + bb) * A + j] : 0.f;
       dud[t] = 0.f;
     }
     const float wk = kon ? p.w[j] : 0.f, abk = kon ? p.ab[j] : 0.f;
     float dwa = 0.f;
-    const uint32_t key = drop_key(p.dd);
     const float invT = 1.0f / (float)T;
     for (int q = 0; q < F; ++q) {
       const int s = F - 1 - q;
       // saved tensors of step s: independent of the chain, requested before waiting
       const float whk = (kon ? p.Whr[((size_t)s * B + b) * A + j] : 0.f) + abk;
-      const float bet = (bok && j < T) ? p.beta[((size_t)s * B + b) * T + j] : 0.f;
-      if (j < 32) sbt[c * 32 + j] = bet * invT;
+      const float bt = (bok && tt < T) ? p.beta[((size_t)s * B + b) * T + tt] * invT : 0.f;
       lc_wait(relX, fb + (unsigned)(q + 1), p.bar);
-      float dx[4];
+      if (ci == 0) LC_TS(6, q, 0);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int h = j + 128 * qq;
-        dx[qq] = (bok && h < H) ? p.Dx[((size_t)q * B + b) * H + h] : 0.f;
-      }
-      // dbeta[t] = (1/T) dx . h_t : per-thread partial over its four columns, wave sum, two waves per caption
-#pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        if (t < T) {
-          float v = (dx[0] * hv[0][t] + dx[1] * hv[1][t]) + (dx[2] * hv[2][t] + dx[3] * hv[3][t]);
-          v = wave_sum(v);
-          if (lane == 0) sdb[(c * 2 + wv) * 32 + t] = v;
-        }
+        sdx[c * 512 + h] = (bok && h < H) ? p.Dx[((size_t)q * B + b) * H + h] : 0.f;
       }
       __syncthreads();
-      if (j < 32) sdbt[c * 32 + j] = (sdb[(c * 2) * 32 + j] + sdb[(c * 2 + 1) * 32 + j]) * invT;
-      // dHs[t] += (beta_s[t] / T) dx
+      // dbeta[tt] = (1/T) dx . h_tt (this thread's quarter) and dHs[tt] += (beta_s[tt] / T) dx
+      {
+        float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-      for (int t = 0; t < 32; ++t) {
-        if (t < T) {
-          const float bt = sbt[c * 32 + t];
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) dhs[qq][t] += bt * dx[qq];
+        for (int i = 0; i < 128; i += 4) {
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sdx + c * 512 + 128 * hq + i);
+          v0 += d4[0] * hv[i] + d4[2] * hv[i + 2];
+          v1 += d4[1] * hv[i + 1] + d4[3] * hv[i + 3];
+          dhs[i] += bt * d4[0]; dhs[i + 1] += bt * d4[1]; dhs[i + 2] += bt * d4[2]; dhs[i + 3] += bt * d4[3];
         }
+        spd[(c * 4 + hq) * 32 + tt] = v0 + v1;
       }
+      __syncthreads();
+      if (hq == 0) sdbt[c * 32 + tt] = ((spd[(c * 4) * 32 + tt] + spd[(c * 4 + 1) * 32 + tt]) + (spd[(c * 4 + 2) * 32 + tt] + spd[(c * 4 + 3) * 32 + tt])) * invT;
       __syncthreads();
       // (t, k) plane, thread = k: dz = dbeta[t] w_k (1 - tanh^2), dUd[t] += dz, dWhr_s = sum_t dz, dw += sum_t dbeta[t] tanh
       float dwh = 0.f;
@@ -620,6 +643,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       }
       swl[c * 128 + j] = (bf16_t)(kon ? dwh : 0.f);
       __syncthreads();
+      if (ci == 0) LC_TS(6, q, 1);
       // publish dWhr_s[b]: 16 bytes per k-group, written through; then the row-major copy (zero padded)
       const int pc = tid >> 6, kg = tid & 63, pb = ci * LC_CPW + pc;
       const bool pon = tid < LC_CPW * 64 && pb < B;
@@ -628,16 +652,22 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       lc_arrive(p.bar + NU + NX + ci, fb + (unsigned)(q + 1));
+      if (ci == 0) LC_TS(6, q, 2);
       if (pon && kg < (p.ld_dwhr >> 3) && kg < 16)
         *reinterpret_cast<bf16x8*>(p.dWhrs + ((size_t)s * B + pb) * p.ld_dwhr + kg * 8) = *reinterpret_cast<const bf16x8*>(swl + pc * 128 + kg * 8);
     }
     // ---- the accumulators
     if (bok) {
+      if (tt < T) {
+#pragma unroll
+        for (int i = 0; i < 128; i += 4) {
+          const int h = 128 * hq + i;
+          if (h < H) *reinterpret_cast<f32x4*>(p.dHs + ((size_t)tt * B + b) * H + h) = f32x4{dhs[i], dhs[i + 1], dhs[i + 2], dhs[i + 3]};
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
         if (t < T) {
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) { const int h = j + 128 * qq; if (h < H) p.dHs[((size_t)t * B + b) * H + h] = dhs[qq][t]; }
           if (j < A) { p.dUd[((size_t)t * B + b) * A + j] = dud[t]; p.dUd_lp[((size_t)t * B + b) * p.ld_dUd + j] = (bf16_t)dud[t]; }
           else if (j < p.ld_dUd) p.dUd_lp[((size_t)t * B + b) * p.ld_dUd + j] = (bf16_t)0.f;
         }
@@ -671,6 +701,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
     for (int q = 0; q < F; ++q) {
       const int s = F - 1 - q;
       lc_wait(relG, fb + (unsigned)(q + 1), p.bar);
+      if (xi == 0) LC_TS(5, q, 0);
       f32x4 acc[RBX];
 #pragma unroll
       for (int i = 0; i < RBX; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -681,6 +712,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + (lane & 15)] = acc[i][r];
       __syncthreads();
+      if (xi == 0) LC_TS(5, q, 1);
       for (int idx = tid; idx < own * (UW / 2); idx += 256) {
         const int rg = own_lo + idx / (UW / 2), pc = (idx % (UW / 2)) * 2, rl = rg - r0;
         if (rg < B && rl < ROWS && j0 + pc < H) {
@@ -695,6 +727,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       lc_arrive(p.bar + wg, fb + (unsigned)(q + 1));
+      if (xi == 0) LC_TS(5, q, 2);
     }
     __syncthreads();
     lc_arrive(p.bar + wg, fb + (unsigned)(F + 1));
@@ -762,8 +795,11 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 #pragma unroll
       for (int i = 0; i < RBU; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       lc_wait(relG, fb + (unsigned)q, p.bar);                        // dG_{s+1} is complete
+      if (wg == 0) LC_TS(4, q, 0);
       lcb_product<STEPS, PF, RBU>(acc, wb, p.PanG + (size_t)(q - 1) * pan_g + lane_off, K, kw0, rot);
+      if (wg == 0) LC_TS(4, q, 1);
       lc_wait(relW, fb + (unsigned)q, p.bar);                        // dWhr_{s+1} is complete
+      if (wg == 0) LC_TS(4, q, 2);
       {
         const int k = wave * 32;
         const bf16_t* Aw = p.PanW + (size_t)(q - 1) * pan_w + lane_off;
@@ -800,12 +836,14 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       }
     }
     __syncthreads();
+    if (wg == 0) LC_TS(4, q, 3);
 #pragma unroll
     for (int jj = 0; jj < IPT; ++jj)
       if (it_on[jj]) lc_store16(p.PanG + (size_t)q * pan_g + ((size_t)(it_col[jj] >> 3) * RC_PAN_ROWS + it_rg[jj]) * 8, it_src[jj]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     lc_arrive(p.bar + wg, fb + (unsigned)(q + 1));
+    if (wg == 0) LC_TS(4, q, 4);
     // ---- off the critical path: the row-major copy for the deferred weight-gradient GEMMs
     bf16_t* Gt = p.dG + (size_t)s * B * p.ld_dg;
 #pragma unroll

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Where a step of the local reconstructor's chain kernels goes: in-kernel wall-clock stamps (probe build of the library:
+`make -C reconstruction-network-for-video-captioning_amd/csrc probe`, loaded with RN_LIB_PROBE=1).
+
+   RN_LIB_PROBE=1 python tools/loc_chain_probe.py [B F D]
+Prints, per role, the median over the steps of the intervals between consecutive stamps (us) and the step period."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+os.environ["RN_LIB_PROBE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import recnet_amd as R  # noqa: E402
+from recnet_amd.synthetic import synthetic_features, synthetic_targets  # noqa: E402
+
+B, F, D = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (100, 28, 1536)
+V = 4188
+Cc = R.make_config(batch_size=B, use_recon=True, reconstructor_type="local", encoder_output_len=F, encoder_output_size=D,
+                   reconstructor_hidden_size=D, precision="bf16", device="cuda")
+torch.manual_seed(0)
+dec, rec = R.build_decoder(V, Cc), R.build_reconstructor(Cc)
+step = R.TrainStep(dec, rec)
+enc = synthetic_features(B, F, D).cuda()
+tg = synthetic_targets(B, V)
+T, w = step.prepare(tg.numpy())
+for _ in range(3):
+    step.fwd_bwd(enc, tg.cuda(), T, w, seed=1)
+torch.cuda.synchronize()
+eng = step.engine
+n = 7 * 64 * 8
+buf = (C.c_uint64 * n)()
+R._lib.check(eng.lib.recnet_probe_read(eng.handle, buf, n), "recnet_probe_read")
+ts = np.frombuffer(buf, dtype=np.uint64).reshape(7, 64, 8).astype(np.float64) / 100.0   # 100 MHz -> us
+names = {0: ("fwd U", ["x arrived", "x GEMM + red", "cell", "stores issued", "ack + arrive", "hr released", "hh GEMM"]),
+         1: ("fwd C", ["Pw released", "Whr summed", "beta + x", "ack + arrive"]),
+         2: ("fwd relay", ["U all arrived", "C all arrived"]),
+         3: ("bwd relay", ["U' arrived", "X' arrived", "C' arrived"]),
+         4: ("bwd U'", ["dG released", "big GEMM", "dWhr released", "small GEMM + cell", "ack + arrive"]),
+         5: ("bwd X'", ["dG released", "GEMM + red", "ack + arrive"]),
+         6: ("bwd C'", ["dx released", "attention bwd", "ack + arrive"])}
+for role, (nm, pts) in names.items():
+    t = ts[role, 2:F - 2, :len(pts)]
+    period = np.median(np.diff(ts[role, 2:F - 2, 0]))
+    print("%-10s period %.2f us" % (nm, period))
+    for i in range(1, len(pts)):
+        print("    %-22s +%.2f" % (pts[i], np.median(t[:, i] - t[:, i - 1])))
+    print("    %-22s +%.2f (to the next step's first stamp)" % ("...", np.median(ts[role, 3:F - 1, 0] - t[:, len(pts) - 1])))
+# cross-role offsets inside a step (forward): relay 'C all arrived' -> U 'x arrived', U 'ack + arrive' -> relay 'U all arrived'
+s = slice(3, F - 2)
+print("fwd: relay C-arrived -> U sees x      %.2f" % np.median(ts[0, s, 0] - ts[2, s, 1]))
+print("fwd: U arrive -> relay sees all U     %.2f" % np.median(ts[2, 4:F - 1, 0] - ts[0, s, 4]))
+print("fwd: relay U-arrived -> C released    %.2f" % np.median(ts[1, 4:F - 1, 0] - ts[2, 4:F - 1, 0]))
+print("fwd: C arrive -> relay sees all C     %.2f" % np.median(ts[2, s, 1] - ts[1, s, 3]))
+print("bwd: U' arrive -> relay               %.2f" % np.median(ts[3, s, 0] - ts[4, s, 4]))
+print("bwd: relay dG -> X' released          %.2f" % np.median(ts[5, s, 0] - ts[3, s, 0]))
+print("bwd: X' arrive -> relay               %.2f" % np.median(ts[3, s, 1] - ts[5, s, 2]))
+print("bwd: relay dx -> C' released          %.2f" % np.median(ts[6, s, 0] - ts[3, s, 1]))
+print("bwd: C' arrive -> relay               %.2f" % np.median(ts[3, s, 2] - ts[6, s, 2]))
+print("bwd: relay dWhr -> U' released (next) %.2f" % np.median(ts[4, 4:F - 1, 2] - ts[3, s, 2]))
