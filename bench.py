@@ -32,6 +32,7 @@ def cpu_baseline(kind, B, F, D, V, steps, warmup, cell="LSTM"):
     """The oracle (CPU port of the reference algorithm, oracle/recnet_oracle.py) timed on this host."""
     import torch
     from oracle import recnet_oracle as O
+    O.RNN_IMPL = "aten"       # the fused one-step RNN op nn.LSTM dispatches to: the reference's own CPU cost structure
     # small per-step ops: more than ~32 threads only adds synchronisation cost to the CPU port
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     torch.manual_seed(0)
@@ -126,20 +127,25 @@ def roofline(eng, run_step, kind, precision, iters=5):
     ms_null = max(b1 - f_empty, 0.0)
     ms = max(ms_raw - ms_null, 1e-6)
     bytes_launch = eng.recurrent_step_bytes(which)
+    exchange = eng.chain_exchange_bytes(which) if which >= 3 else 0.0
     achieved = bytes_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     peak = 8000.0
     # HBM-side bytes per launch from the PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs,
     # FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py) — only valid for the configuration it was
     # collected on (global reconstructor, bf16, B=100, 28x1536)
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", {1: "r01_pmc_traffic_rec_fwd_gemm.json", 4: "r01_pmc_traffic_rec_chain_bwd.json",
-                                         6: "r01_pmc_traffic_dec_chain_bwd.json", 5: "r01_pmc_traffic_dec_chain_fwd.json",
-                                         3: "r01_pmc_traffic_rec_chain_fwd.json"}.get(which, "-"))
-    if which in (1, 3, 4, 5, 6) and kind == "global" and precision == "bf16" and eng.dims["B"] == 100 and eng.dims["D"] == 1536 and os.path.exists(tf):
-        traffic = int(json.load(open(tf))["traffic_bytes_per_launch"])
+    # traffic: HBM-side bytes per launch from rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py), stored
+    # under profiles/ — counters cannot be read from inside the timed process.  Only reported for the exact workload and
+    # kernel the stored file was collected on; `traffic_source` names the file.
+    traffic, traffic_src = None, None
+    short = kname.split(" ")[0].split("<")[0]
+    tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s_%s.json" % (kind or "none", short))
+    if precision == "bf16" and os.path.exists(tf):
+        meta = json.load(open(tf))
+        if meta.get("B") == eng.dims["B"] and meta.get("D") == eng.dims["D"] and meta.get("F") == eng.dims["F"]:
+            traffic, traffic_src = int(meta["traffic_bytes_per_launch"]), "stored: profiles/" + os.path.basename(tf)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic,
-            "kernel": kname,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kname, "exchange_bytes_per_launch": int(exchange),
             "launches_timed": n, "avg_launch_us": round(ms * 1e3, 3), "bracket_us": round(ms_raw * 1e3, 3),
             "event_pair_overhead_us": round(ms_null * 1e3, 3), "empty_kernel_us": round(f_empty * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch),
             "chain_kernel_brackets_us": chains}
@@ -164,6 +170,8 @@ def main():
                     "U{4..30} with one full-length caption (T = 31), or MSVD-like 3 + Poisson(5) (the loop exits early)")
     ap.add_argument("--force-allreduce", action="store_true", help="keep the gradient all-reduce (and the three-graph step "
                     "built around it) with a single rank too: exercises the RCCL path on one GPU")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many captions in total, sharded over the "
+                    "ranks (BASELINE configs[3]: 256 over 8, configs[4]: 512 over 8); default 0 = weak scaling, --batch per rank")
     ap.add_argument("--feed", type=int, default=0, help="1: every step takes a fresh HOST batch through feed.DeviceFeeder "
                     "(pinned staging + H2D on a side stream); reports the PCIe-inclusive rate, not the headline value")
     args = ap.parse_args()
@@ -187,12 +195,14 @@ def main():
         dist.init_process_group(os.environ.get("RN_DIST_BACKEND", "nccl"), rank=rank, world_size=world, device_id=dev)
 
     B, F, D, V = args.batch, args.frames, args.feat, 4188
+    if args.global_batch:
+        B = R.shard_bounds(args.global_batch, world, 0)[1]          # the largest shard sizes the engines
     kind = None if args.rec == "none" else args.rec
     C, dec, rec = build_models(R, dict(batch_size=B, use_recon=kind is not None, reconstructor_type=kind or "global",
                                        encoder_output_len=F, encoder_output_size=D, reconstructor_hidden_size=D,
                                        precision=args.precision, device=str(dev), decoder_model=args.cell,
                                        reconstructor_model=args.cell), V)
-    Bg = B * world
+    Bg = args.global_batch if args.global_batch else B * world
     targets_g = synthetic_targets(Bg, V, seed=1234, lengths=args.lengths)
     lo, hi = R.shard_bounds(Bg, world, rank)
     enc = synthetic_features(hi - lo, F, D, seed=1234 + rank).to(dev)
@@ -264,22 +274,37 @@ def main():
             # (never the data-parallel step itself: this runs on rank 0 only, a collective here would wait for ever)
             return eng.profile_site(s_id, one, 5)
         prof = roofline(eng, prof_pass, kind, args.precision)
+        # whole-step roofline fractions: algorithmic FLOPs against the dense bf16 MFMA peak and
+        # algorithmic HBM bytes (optimiser + inputs) against 8 TB/s; per GPU (every rank does the same work)
+        Bl = hi - lo
+        flops = algorithmic_flops(kind, Bl, F, D, T)
+        hbm = algorithmic_hbm_bytes(kind, Bl, F, D)
+        mfma_peak = 2.5e15 if args.precision == "bf16" else 157.3e12
+        whole = {"algorithmic_gflop_per_step": round(flops / 1e9, 1), "mfma_frac": round(flops / (ms * 1e-3) / mfma_peak, 4),
+                 "mfma_peak_tflops": mfma_peak / 1e12, "algorithmic_hbm_mb_per_step": round(hbm / 1e6, 1),
+                 "hbm_frac": round(hbm / (ms * 1e-3) / 8e12, 4), "binding_floor_us": round(max(flops / mfma_peak, hbm / 8e12) * 1e6, 1)}
         out = {
             "metric": "captions/sec (train step) MSVD bs=100 28x1536 feats", "value": round(Bg * 1e3 / ms, 1),
             "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "ms_per_step_hipevent": round(ms_ev, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4), "ms_per_step_hipevent": round(ms_ev, 4), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
-                                   "D=R=%d, V=4188, E=468, H=512, A=128, T=%d, dropout 0.5, %s cells" % (args.rec, B, F, D, T, args.cell),
+                                   "D=R=%d, V=4188, E=468, H=512, A=128, T=%d, dropout 0.5, %s cells" % (args.rec, hi - lo, F, D, T, args.cell),
                        "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
                        "loss": round(sc["total_loss"], 5)},
-            "roofline": prof,
+            "roofline": prof, "whole_step": whole,
         }
         if not args.no_cpu_baseline and world == 1:
             v, cores, med = cpu_baseline(kind, B, F, D, V, args.cpu_steps, 1, args.cell)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "captions/s", "cores": cores, "kind": "port",
                                    "sample": "1 warm-up + %d timed train steps of the same workload (B=%d, T=31) by "
                                              "oracle/recnet_oracle.py on torch-CPU; median %.2f s/step" % (args.cpu_steps, B, med)}
+            # BASELINE.json configs[0] (mandatory): decoder only, B=8, the reference's CPU-runnable case
+            v1, c1, m1 = cpu_baseline(None, 8, 28, 1536, V, 5, 2, args.cell)
+            out["cpu_baseline_c1"] = {"value": round(v1, 2), "unit": "captions/s", "cores": c1, "kind": "port",
+                                      "sample": "configs[0]: decoder only, B=8, 28x1536, T=31; 2 warm-up + 5 timed train steps by "
+                                                "oracle/recnet_oracle.py on torch-CPU; median %.3f s/step (tools/c1_reference_vs_oracle.py: "
+                                                "the oracle times within noise of the imported reference)" % m1}
         print(json.dumps(out), flush=True)
     if world > 1 or under_launcher:
         dist.barrier()

@@ -71,8 +71,18 @@ def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
     return (1.0 - z) * n + z * h
 
 
+RNN_IMPL = "explicit"     # "aten": the fused single-step op nn.LSTM / nn.GRU dispatch to (what the reference executes on
+#                           the CPU: mkldnn_rnn_layer) — same arithmetic, used when the oracle is TIMED as the CPU baseline
+
+
 def _rnn(P, prefix, cell, x, hidden):
     w = [P[prefix + k] for k in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0")]
+    if RNN_IMPL == "aten":
+        if cell == "LSTM":
+            out, h2, c2 = torch._VF.lstm(x.unsqueeze(0), hidden, w, True, 1, 0.0, False, False, False)
+            return out[0], (h2, c2)
+        out, h2 = torch._VF.gru(x.unsqueeze(0), hidden, w, True, 1, 0.0, False, False, False)
+        return out[0], h2
     if cell == "LSTM":
         h, c = hidden
         h2, c2 = lstm_cell(x, h[0], c[0], *w)

@@ -332,7 +332,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
                      nwg <= h->ncu && nwg - 1 <= 256;
     // ... and its backward chain: U' all rows (RB 7) + X' two row parts above 64 captions, one part of 64 rows below
     const char* eb = getenv("RN_PERSIST_LOC_BWD");
-    h->lcb_msx = h->B > 64 ? 2 : 1; h->lcb_rbu = h->B > 64 ? 7 : 4;
+    h->lcb_msx = h->B > 64 ? 2 : 1; h->lcb_rbu = h->B > 64 ? 7 : (h->B > 32 ? 4 : 2);
     const int nwb = h->lc_ng + (h->H / 16) * h->lcb_msx + h->lc_nc + 1;
     h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && (h->H & 15) == 0 && !(h->B > 64 && h->R > 1536) &&
                          nwb <= h->ncu && nwb - 1 <= 256;
