@@ -172,6 +172,7 @@ def main():
                     "built around it) with a single rank too: exercises the RCCL path on one GPU")
     ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: this many captions in total, sharded over the "
                     "ranks (BASELINE configs[3]: 256 over 8, configs[4]: 512 over 8); default 0 = weak scaling, --batch per rank")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="gradient transport of the all-reduce")
     ap.add_argument("--feed", type=int, default=0, help="1: every step takes a fresh HOST batch through feed.DeviceFeeder "
                     "(pinned staging + H2D on a side stream); reports the PCIe-inclusive rate, not the headline value")
     args = ap.parse_args()
@@ -207,7 +208,8 @@ def main():
     lo, hi = R.shard_bounds(Bg, world, rank)
     enc = synthetic_features(hi - lo, F, D, seed=1234 + rank).to(dev)
     targets = targets_g[:, lo:hi].contiguous().to(dev)
-    step = R.DataParallelTrainStep(dec, rec, Bg, rank, world, n_frames=F, always_reduce=args.force_allreduce and under_launcher)
+    step = R.DataParallelTrainStep(dec, rec, Bg, rank, world, n_frames=F, always_reduce=args.force_allreduce and under_launcher,
+                                   grad_dtype=args.grad_dtype)
     T, w = step.prepare(targets_g.numpy())
 
     def sync_all():

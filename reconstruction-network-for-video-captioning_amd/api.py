@@ -491,10 +491,10 @@ class GraphedStep:
 
     One rank: a single graph (fwd + bwd + optimiser).  Data parallel: three graphs with the two gradient
     all-reduces in between,
-        graph A (fwd, reconstructor bwd)  ->  all-reduce(reconstructor bucket, async, RCCL stream)
-        graph B (decoder bwd)  [runs while the reconstructor bucket is on the wire]
-        all-reduce(decoder bucket)  ->  wait both  ->  graph C (regulariser, clip, Adam, re-pack)
-    so only the decoder bucket's all-reduce is exposed."""
+        graph A (fwd, reconstructor bwd)  ->  all-reduce(reconstructor bucket + decoder out.*, async, RCCL stream)
+        graph B (decoder bwd)  [runs while those are on the wire]
+        all-reduce(rest of the decoder bucket)  ->  wait all  ->  graph C (regulariser, clip, Adam, re-pack)
+    so only the all-reduce of the decoder's recurrent / attention / embedding gradients is exposed."""
 
     def __init__(self, dp_step, enc, targets, T, step_weight, warmup=2):
         self.dp = dp_step
@@ -535,9 +535,8 @@ class GraphedStep:
                 eng.optimizer_step_dev(self.flags)
             self.graphs.append(g)
 
-    def _reduce_async(self, buf):
-        import torch.distributed as dist
-        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.dp.group, async_op=True)
+    def _reduce_async(self, bufs):
+        return [self.dp.transport.start(b) for b in bufs]
 
     def _eager(self):
         if not self.split:
@@ -546,11 +545,11 @@ class GraphedStep:
             return
         else:
             self.eng.train_step_part_dev(1, self.enc, self.targets, self.T, self.w, self.seed_base)
-            works = [self._reduce_async(self.rs.flat()["grad"].flat)] if self.rs else []
+            works = self._reduce_async(self.dp.early_buffers())
             self.eng.train_step_part_dev(2, self.enc, self.targets, self.T, self.w, self.seed_base)
-            works.append(self._reduce_async(self.ms.flat()["grad"].flat))
+            works += self._reduce_async(self.dp.late_buffers())
             for w in works:
-                w.wait()
+                self.dp.transport.finish(w)
         self.eng.optimizer_step_dev(self.flags)
         self._bump()
 
@@ -567,11 +566,11 @@ class GraphedStep:
         else:
             ga, gb, gc = self.graphs
             ga.replay()
-            works = [self._reduce_async(self.rs.flat()["grad"].flat)] if self.rs else []
-            gb.replay()
-            works.append(self._reduce_async(self.ms.flat()["grad"].flat))
+            works = self._reduce_async(self.dp.early_buffers())      # reconstructor bucket + the decoder's output layer
+            gb.replay()                                              # decoder BPTT while they are on the wire
+            works += self._reduce_async(self.dp.late_buffers())
             for w in works:
-                w.wait()
+                self.dp.transport.finish(w)
             gc.replay()
         self._bump()
         return self.eng.scalars

@@ -345,8 +345,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const int NAb = (h->H / 16) * DCB_PARTS;
+    // RN_RESERVE_CUS: CUs left to a collective kernel (RCCL) that is resident while this chain runs — data parallel runs
+    // all-reduce the reconstructor bucket under the decoder's BPTT (dp.py sets 64).  The chain would still complete
+    // without the reserve (the collective does not wait for it), but its first steps would spin until CUs free up.
+    const char* er = getenv("RN_RESERVE_CUS");
+    const int reserve = er ? atoi(er) : 0;
     h->persist_dec_bwd = (eb ? atoi(eb) : 1) && h->persist_dec && h->use_wcomb_t && (h->H & 15) == 0 && (h->ldWS & 7) == 0 &&
-                         (NAb > h->B ? NAb : h->B) + 1 <= ncu;
+                         (NAb > h->B ? NAb : h->B) + 1 + reserve <= ncu;
   }
   h->need = carve(h, nullptr);
   *out = h;

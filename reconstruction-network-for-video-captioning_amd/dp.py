@@ -18,20 +18,57 @@ def shard_bounds(global_batch, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_sum_(flat_buffers, group=None):
+class GradTransport:
+    """SUM all-reduce of fp32 gradient buffers, optionally carried in bf16 (`dtype="bf16"`): the gradient bucket is as
+    expensive as the compute on xGMI (99-344 MB fp32 per step), bf16 halves the bytes on the wire.
+    The fp32 buffer is rounded once into a bf16 staging buffer, reduced, and widened back; the rounding (2^-9 relative
+    per element) is at the level of the bf16 compute path's own operand rounding.  fp32 is the default and the form the
+    parity tests use."""
+
+    def __init__(self, dtype="f32", group=None):
+        if dtype not in ("f32", "bf16"):
+            raise NotImplementedError("gradient transport dtype %r" % dtype)
+        self.dtype, self.group, self._stage = dtype, group, {}
+
+    def start(self, buf):
+        """Launch the collective on `buf` (a contiguous fp32 tensor or slice); returns a token for finish()."""
+        import torch.distributed as dist
+        if self.dtype == "f32":
+            return (dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, None)
+        key = (buf.data_ptr(), buf.numel())
+        st = self._stage.get(key)
+        if st is None:
+            st = self._stage[key] = torch.empty(buf.numel(), dtype=torch.bfloat16, device=buf.device)
+        st.copy_(buf)
+        return (dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, st)
+
+    @staticmethod
+    def finish(token):
+        work, buf, st = token
+        work.wait()
+        if st is not None:
+            buf.copy_(st)
+
+
+def allreduce_sum_(flat_buffers, group=None, dtype="f32"):
     """One collective per flat gradient buffer (reconstructor first: it is ready first)."""
-    import torch.distributed as dist
-    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in flat_buffers]
-    for w in works:
-        w.wait()
+    tr = GradTransport(dtype, group)
+    for tok in [tr.start(t) for t in flat_buffers]:
+        tr.finish(tok)
 
 
 class DataParallelTrainStep:
     """Wraps api.TrainStep for world_size ranks.  Each rank owns captions [lo, hi) of the global batch."""
 
     def __init__(self, decoder, reconstructor, global_batch, rank, world_size, n_frames=None, group=None,
-                 always_reduce=False):
+                 always_reduce=False, grad_dtype="f32"):
+        import os
         from .api import TrainStep
+        if world_size > 1:
+            # RCCL's kernel of the reconstructor bucket is resident while the decoder's BPTT chain kernel runs: keep
+            # that many CUs out of the chain kernel's residency check (csrc/api.hip: RN_RESERVE_CUS)
+            os.environ.setdefault("RN_RESERVE_CUS", "64")
+        self.transport = GradTransport(grad_dtype, group)
         self.rank, self.world = rank, world_size
         # reduce even with one rank (exercises the collective path under torchrun --nproc-per-node 1)
         self.reduce = world_size > 1 or always_reduce
@@ -49,17 +86,31 @@ class DataParallelTrainStep:
     def prepare(self, global_targets_host):
         return self.step_impl.prepare(global_targets_host)
 
-    def grad_buffers(self):
+    def decoder_out_offset(self):
+        """Start of the out.weight / out.bias gradients in the decoder's flat buffer (they are its tail: parameters are
+        laid out in registration order, decoder.py:22-42).  They are complete before the decoder's BPTT starts."""
+        return self.decoder["_state"].flat()["grad"].offsets["out.weight"]
+
+    def early_buffers(self):
+        """Gradients that are complete when the reconstructor's backward is: the reconstructor bucket and the decoder's
+        output layer (all-reduced while the decoder's BPTT runs)."""
         bufs = []
         if self.reconstructor:
             bufs.append(self.reconstructor["_state"].flat()["grad"].flat)
-        bufs.append(self.decoder["_state"].flat()["grad"].flat)
+        bufs.append(self.decoder["_state"].flat()["grad"].flat[self.decoder_out_offset():])
         return bufs
+
+    def late_buffers(self):
+        return [self.decoder["_state"].flat()["grad"].flat[:self.decoder_out_offset()]]
+
+    def grad_buffers(self):
+        return self.early_buffers() + self.late_buffers()
 
     def __call__(self, enc_local, targets_local, T, step_weight, seed=None):
         self.step_impl.fwd_bwd(enc_local, targets_local, T, step_weight, seed)
         if self.reduce:
-            allreduce_sum_(self.grad_buffers(), self.group)
+            for tok in [self.transport.start(b) for b in self.grad_buffers()]:
+                self.transport.finish(tok)
         self.step_impl.optimizer_step()
         return self.step_impl.scalars
 

@@ -21,18 +21,19 @@ LENS = [9, 2, 5, 12, 1, 7, 4]
 SEED = 5
 
 
-def _problem(kind):
+def _problem(kind, B=None):
     d = DIMS
     decP = GU.formula_params(GU.decoder_shapes(d["V"], d["E"], d["H"], d["A"], d["D"]), 21)
     recP = GU.formula_params(GU.rec_shapes(kind, d["H"], d["D"], d["RA"]), 22) if kind else None
-    enc, targets = GU.make_batch(d["B"], d["F"], d["D"], d["V"], LENS, 33)
+    lens = LENS if B is None else [int(x) for x in np.random.RandomState(3).randint(1, 13, size=B)]
+    enc, targets = GU.make_batch(B or d["B"], d["F"], d["D"], d["V"], lens, 33)
     return decP, recP, enc, targets
 
 
 def _shard_grads(kind, decP, recP, enc, targets, lo, hi):
     """One rank's fwd+bwd on captions [lo, hi) with global normalisers (no regulariser: it is added once,
     after the reduction)."""
-    d = DIMS
+    d = dict(DIMS, B=targets.shape[1])                   # `targets` always covers the GLOBAL batch
     masks_g = (targets > 0).numpy()
     T = R.decode_len(masks_g)
     w = R.step_weights(masks_g, T)                       # 1 / (n_t * N), global counts
@@ -61,16 +62,16 @@ def _shard_grads(kind, decP, recP, enc, targets, lo, hi):
     return flat
 
 
-def _worker(rank, world, port, kind, out):
+def _worker(rank, world, port, kind, out, B=None, dtype="f32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    decP, recP, enc, targets = _problem(kind)
-    lo, hi = R.shard_bounds(DIMS["B"], world, rank)
+    decP, recP, enc, targets = _problem(kind, B)
+    lo, hi = R.shard_bounds(B or DIMS["B"], world, rank)
     flat = _shard_grads(kind, decP, recP, enc, targets, lo, hi)
     from recnet_amd.dp import allreduce_sum_
-    allreduce_sum_(list(reversed(flat)))                 # reconstructor bucket first, as on the GPU path
+    allreduce_sum_(list(reversed(flat)), dtype=dtype)    # reconstructor bucket first, as on the GPU path
     if rank == 0:
         out.put([f.numpy() for f in flat])
     dist.barrier()
@@ -108,3 +109,33 @@ def test_two_rank_gradients_equal_full_batch(kind):
     ((dl if rl is None else dl + rl)).backward()
     full = torch.cat([st.dec[k].grad.reshape(-1) for k in O.decoder_param_order(st.dec)]).numpy()
     assert np.linalg.norm(ref[0].numpy() - full) <= 2e-6 * np.linalg.norm(full)
+
+
+def _run(world, kind, B=None, dtype="f32"):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, out, B, dtype)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    decP, recP, enc, targets = _problem(kind, B)
+    ref = _shard_grads(kind, decP, recP, enc, targets, 0, B or DIMS["B"])
+    return got, [r.numpy() for r in ref]
+
+
+def test_eight_uneven_ranks_of_one_hundred_captions():
+    """BASELINE's headline batch over a full node: 100 captions over 8 ranks = 13,13,13,13,12,12,12,12."""
+    assert [R.shard_bounds(100, 8, r) for r in range(8)] == [(0, 13), (13, 26), (26, 39), (39, 52), (52, 64), (64, 76), (76, 88), (88, 100)]
+    got, ref = _run(8, "local", B=100)
+    for a, b in zip(got, ref):
+        assert np.linalg.norm(a - b) <= 3e-6 * np.linalg.norm(b)
+
+
+def test_bf16_gradient_transport_stays_inside_the_bf16_parity_bar():
+    got, ref = _run(2, "global", dtype="bf16")
+    for a, b in zip(got, ref):
+        assert 1e-5 < np.linalg.norm(a - b) / np.linalg.norm(b) <= 6e-3        # rounded once per rank, 2^-9 per element

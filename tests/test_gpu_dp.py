@@ -35,7 +35,7 @@ def _worker(rank, world, port, kind, q):
     # Two ranks share ONE GPU here (test rig only).  The persistent chain kernels need every workgroup of a launch resident
     # and spin on grid barriers: two such launches from two processes could each hold part of the CUs and wait for the
     # rest forever.  One process per GPU (the supported deployment) cannot get there; this rig switches them off.
-    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC"):
+    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC", "RN_PERSIST_LOC"):
         os.environ[k] = "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
@@ -44,6 +44,12 @@ def _worker(rank, world, port, kind, q):
     R_, dec, rec, enc, targets = _setup(kind, DIMS[0], lo, hi)
     step = R.DataParallelTrainStep(dec, rec, DIMS[0], rank, world, n_frames=DIMS[1])
     T, w = step.prepare(targets.numpy())
+    # the early buckets (reconstructor + the decoder's output layer) and the late one partition the gradients exactly
+    n_early = sum(b.numel() for b in step.early_buffers())
+    n_late = sum(b.numel() for b in step.late_buffers())
+    n_all = dec["_state"].flat()["grad"].flat.numel() + (rec["_state"].flat()["grad"].flat.numel() if rec else 0)
+    assert n_early + n_late == n_all and step.late_buffers()[0].data_ptr() == dec["_state"].flat()["grad"].flat.data_ptr()
+    assert step.early_buffers()[-1].numel() >= DIMS[3] * DIMS[5] + DIMS[3]          # out.weight [V,H] + out.bias [V]
     e, t = enc[lo:hi].cuda(), targets[:, lo:hi].contiguous().cuda()
     run = R.GraphedStep(step, e, t, T, w, warmup=0)
     for _ in range(2):
