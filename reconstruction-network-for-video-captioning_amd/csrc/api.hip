@@ -316,7 +316,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
                      (h->R & 7) == 0 && h->R <= 2048 && h->R / 8 <= ncu;   // <= 16 k-steps of resident weights per wave
     const char* ed = getenv("RN_PERSIST_DEC");
     const int N = 4 * h->H + h->A, NA = N / 16;
-    h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 && h->A <= 128 &&
+    h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 + DC_XF && h->A <= 128 &&
                      (N & 15) == 0 && h->B <= RC_PAN_ROWS && (NA > h->B ? NA : h->B) + 1 <= ncu;
     const char* eb = getenv("RN_PERSIST_REC_BWD");
     h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;

@@ -43,10 +43,17 @@ struct DecChainArgs {
 #define DC_TS(i) do { } while (0)
 #endif
 
+// XF: frames 32 .. 47 of the caption's P block and Uv rows are served from (dynamic) LDS — the register file holds 32
+// frames; F <= 32 launches the XF = false instance with no dynamic LDS.
+#define DC_XF 16              // extra frames
+template <bool XF>
 __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   __shared__ float red[4 * RC_PAN_ROWS * DC_RED_LD];                 // phase A: 4 K-partials of the [112 x 16] tile
   __shared__ __attribute__((aligned(16))) float spre[4 * 512];       // phase B: gate pre-activations
-  __shared__ float swh[128], sa[32];
+  __shared__ float swh[128], sa[32 + DC_XF];
+  extern __shared__ __attribute__((aligned(16))) float dc_dyn[];     // XF: [DC_XF][4H] bf16 P rows, then [DC_XF][128] fp32 Uv rows
+  bf16_t* plx = reinterpret_cast<bf16_t*>(dc_dyn);
+  float* suvx = dc_dyn + DC_XF * 4 * 512 / 2;
   __shared__ __attribute__((aligned(16))) bf16_t hl[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, B = p.B, W4 = 4 * H, N = 4 * H + A;
@@ -91,6 +98,20 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       for (int j = 0; j < 2; ++j) {
         const int k = lane + 64 * j;
         uvr[i][j] = (isB && f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+      }
+    }
+    if (XF) {     // every lane stores what it alone reads back: no barrier needed
+      for (int f = 32; f < 32 + DC_XF; ++f) {
+        Raw8<bf16_t> r; if (live && f < F) r.load(pp + (size_t)f * p.ldp); else r.zero();
+        if (u < 512) *reinterpret_cast<bf16x8*>(plx + (size_t)(f - 32) * 2048 + g * 512 + u) = r.v;
+      }
+      for (int i = 8; i < 8 + DC_XF / 4; ++i) {
+        const int f = g + 4 * i;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = lane + 64 * j;
+          if (k < 128) suvx[(f - 32) * 128 + k] = (isB && f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -232,6 +253,17 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
             if (lane == 0) { sa[f] = s; p.att[((size_t)t * B + b) * F + f] = s; }
           }
         }
+        if (XF) {
+          for (int i = 8; i < 8 + DC_XF / 4; ++i) {
+            const int f = g + 4 * i;
+            if (f < F) {
+              float s = wk[0] * rn_tanh(hk[0] + suvx[(f - 32) * 128 + lane] + bk[0]);
+              if (A > 64) s += wk[1] * rn_tanh(hk[1] + suvx[(f - 32) * 128 + lane + 64] + bk[1]);
+              s = wave_sum(s);
+              if (lane == 0) { sa[f] = s; p.att[((size_t)t * B + b) * F + f] = s; }
+            }
+          }
+        }
       }
       __syncthreads();
       DC_TS(8);
@@ -246,6 +278,14 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) c[j] += a * pv[f].at(j);
           }
+        if (XF) {
+          for (int f = 32; f < F; ++f) {
+            const float a = sa[f];
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(plx + (size_t)(f - 32) * 2048 + g * 512 + u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[j] += a * (float)r[j];
+          }
+        }
         const float invF = 1.0f / (float)F;
         float* dst = spre + g * 512 + lane * 8;
         *reinterpret_cast<f32x4*>(dst) = f32x4{pre[0] + c[0] * invF, pre[1] + c[1] * invF, pre[2] + c[2] * invF, pre[3] + c[3] * invF};
@@ -346,10 +386,18 @@ struct DecChainBwdArgs {
 #define DCB_RB 2              // 32 rows per workgroup in phase A', 4 row parts
 #define DCB_PARTS 4
 
+// XF: frames 32 .. 47 — the third 16-frame block of P as MFMA A fragments read from (dynamic) LDS (rows padded by 8
+// elements: the 16 lanes of a fragment load then fall into different banks), their Uv rows and dUv accumulators in LDS.
+#define DCB_PLD (4 * 512 + 8)
+template <bool XF>
 __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArgs p) {
   __shared__ float red[4 * DCB_RB * 16 * DC_RED_LD];
   __shared__ __attribute__((aligned(16))) bf16_t srow[4 * 512 + 128 + 64];   // [dgates | dWh] of this step (+ zero tail)
-  __shared__ float spartf[4 * 32], sda[32], spart[256];
+  __shared__ float spartf[4 * (32 + DC_XF)], sda[32 + DC_XF], spart[256];
+  extern __shared__ __attribute__((aligned(16))) float dc_dyn[];     // XF: [DC_XF][DCB_PLD] bf16, [DC_XF][128] Uv, [DC_XF][128] dUv
+  bf16_t* plx = reinterpret_cast<bf16_t*>(dc_dyn);
+  float* suvx = dc_dyn + DC_XF * DCB_PLD / 2;
+  float* sdux = suvx + DC_XF * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, B = p.B, W4 = 4 * H, KA = 4 * H + A;
   const int NU = H >> 4, NA = NU * DCB_PARTS;
@@ -401,6 +449,19 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
     duv[q] = 0.f;
   }
   const float abk = fk_on ? p.ab[kk] : 0.f, wk = fk_on ? p.w[kk] : 0.f;
+  if (XF) {
+    for (int idx = tid; idx < DC_XF * (W4 >> 3); idx += 256) {          // 16-byte chunks of the caption's rows 32 .. 47
+      const int fx = idx / (W4 >> 3), c8 = (idx % (W4 >> 3)) * 8;
+      *reinterpret_cast<bf16x8*>(plx + (size_t)fx * DCB_PLD + c8) =
+          (isB && 32 + fx < F) ? *reinterpret_cast<const bf16x8*>(p.P + ((size_t)b * F + 32 + fx) * p.ldp + c8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    for (int idx = tid; idx < DC_XF * 128; idx += 256) {
+      const int fx = idx >> 7, k = idx & 127;
+      suvx[idx] = (isB && 32 + fx < F && k < A) ? p.Uv[((size_t)b * F + 32 + fx) * A + k] : 0.f;
+      sdux[idx] = 0.f;
+    }
+    __syncthreads();
+  }
   float carry[2] = {0.f, 0.f};
   const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
   for (int j = tid; j < 64; j += 256) srow[W4 + 128 + j] = (bf16_t)0.f;
@@ -524,7 +585,10 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       __syncthreads();
       // (2) da[f] = (1/F) sum_n P[b,f,n] dgates[n]: MFMA, this wave's gate block, dgates replicated over the 16 columns
       {
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        constexpr int NFB = XF ? 3 : 2, SPF = 32 + (XF ? DC_XF : 0);
+        f32x4 acc[NFB];
+#pragma unroll
+        for (int fb = 0; fb < NFB; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           const int ku = ks * 32 + kq;
@@ -532,17 +596,24 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
           if (ks * 32 < H) {
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0][ks], bv, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1][ks], bv, acc[1], 0, 0, 0);
+            if (XF) {
+              const bf16x8 px = ku < H ? *reinterpret_cast<const bf16x8*>(plx + (size_t)(lane & 15) * DCB_PLD + g * H + ku) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+              acc[NFB - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(px, bv, acc[NFB - 1], 0, 0, 0);
+            }
           }
         }
         if ((lane & 15) == 0) {
 #pragma unroll
-          for (int fb = 0; fb < 2; ++fb)
+          for (int fb = 0; fb < NFB; ++fb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) spartf[g * 32 + fb * 16 + (lane >> 4) * 4 + r] = acc[fb][r];
+            for (int r = 0; r < 4; ++r) spartf[g * SPF + fb * 16 + (lane >> 4) * 4 + r] = acc[fb][r];
         }
       }
       __syncthreads();
-      if (tid < 32) sda[tid] = (spartf[tid] + spartf[32 + tid] + spartf[64 + tid] + spartf[96 + tid]) * (1.0f / (float)F);
+      {
+        constexpr int SPF = 32 + (XF ? DC_XF : 0);
+        if (tid < SPF) sda[tid] = (spartf[tid] + spartf[SPF + tid] + spartf[2 * SPF + tid] + spartf[3 * SPF + tid]) * (1.0f / (float)F);
+      }
       __syncthreads();
       // (3) attention backward on the (f, k) plane
       float dwh = 0.f;
@@ -559,6 +630,19 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
             dw += daf * tz;
             dwh += ds;
             duv[q] += ds;
+          }
+        }
+        if (XF) {      // frames beyond the 16 register slots of this thread (only when G <= 2, i.e. A > 85)
+          for (int q = 16; gi + q * G < F; ++q) {
+            const int f = gi + q * G;
+            if (f >= 32) {
+              const float tz = rn_tanh(wh + suvx[(f - 32) * 128 + kk]);
+              const float daf = sda[f];
+              const float ds = daf * wk * (1.f - tz * tz);
+              dw += daf * tz;
+              dwh += ds;
+              sdux[(f - 32) * 128 + kk] += ds;
+            }
           }
         }
         dwa += dw;
@@ -601,6 +685,16 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         if (f < F) {
           p.dUv[((size_t)b * F + f) * A + kk] = duv[q];
           p.dUv_lp[((size_t)b * F + f) * p.ld_dUv + kk] = (bf16_t)duv[q];
+        }
+      }
+      if (XF) {
+        for (int q = 16; gi + q * G < F; ++q) {
+          const int f = gi + q * G;
+          if (f >= 32) {
+            const float v = sdux[(f - 32) * 128 + kk];
+            p.dUv[((size_t)b * F + f) * A + kk] = v;
+            p.dUv_lp[((size_t)b * F + f) * p.ld_dUv + kk] = (bf16_t)v;
+          }
         }
       }
       spart[gi * A + kk] = dwa;

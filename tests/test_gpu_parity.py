@@ -278,6 +278,15 @@ EDGE = {
     "H32_T1_chain_without_barriers": ([5, 3, 32, 29, 8, 32, 16, 16], [0, 0, 0, 0, 0]),
     "H32_T2_one_hand_over": ([70, 3, 32, 29, 8, 32, 16, 16], [i % 2 for i in range(70)]),
     "H32_T31_longest": ([3, 3, 32, 29, 8, 32, 16, 16], [30, 7, 30]),
+    # frames 32 .. 47 of the decoder chains come from LDS (csrc/dec_chain.hpp, XF)
+    "F33_one_extra_frame": ([7, 33, 64, 53, 12, 32, 128, 16], [9, 2, 5, 12, 1, 7, 3]),
+    "F48_A40_all_extra_frames": ([5, 48, 32, 29, 8, 48, 40, 16], [4, 2, 6, 1, 3]),
+    # shapes the local reconstructor's chains take (csrc/loc_chain.hpp: R % 32 == 0, H % 32 == 0, RA % 4 == 0): two row
+    # parts / one part of 64 / of 32 rows; attention sizes that are not multiples of 16; the longest caption
+    "LOC_R64_B100_RA24": ([100, 4, 64, 29, 8, 32, 16, 24], [(7 * i) % 9 for i in range(100)]),
+    "LOC_R96_B40_RA128": ([40, 3, 96, 29, 8, 64, 16, 128], [(5 * i) % 8 for i in range(40)]),
+    "LOC_R32_B20_RA8_T31": ([20, 2, 32, 29, 8, 32, 16, 8], [30] + [(3 * i) % 6 for i in range(19)]),
+    "LOC_R128_B65_F1": ([65, 1, 128, 29, 8, 32, 16, 12], [(5 * i) % 7 for i in range(65)]),
 }
 
 

@@ -28,7 +28,7 @@ int main() {
   for (int rep = 0; rep < 3; ++rep) {
     
     hipEventRecord(e0, st);
-    hipLaunchKernelGGL(dec_chain_kernel, dim3((NA > B ? NA : B) + (c.master ? 1 : 0) - (getenv("SHORT") ? 1 : 0)), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(dec_chain_kernel<false>, dim3((NA > B ? NA : B) + (c.master ? 1 : 0) - (getenv("SHORT") ? 1 : 0)), dim3(256), 0, st, c);
     hipEventRecord(e1, st);
     hipStreamSynchronize(st);
   }
