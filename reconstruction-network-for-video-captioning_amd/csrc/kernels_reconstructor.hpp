@@ -259,6 +259,32 @@ __global__ __launch_bounds__(256) void mse_kernel(float* __restrict__ out, const
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+// 4-wide form (R % 4 == 0, 16-byte aligned rows): 16-byte accesses, and optionally the operand copy
+// dlp[i] = (AT)(lp_scale * gcoef * diff) of d loss / d out that the backward's GEMMs read (ld_lp == R: no padding to zero)
+template <typename AT>
+__global__ __launch_bounds__(256) void mse_vec_kernel(float* __restrict__ out, const float* __restrict__ ref, int Sn, int B,
+                                                      int R, size_t ref_bstride, size_t ref_sstride, float gcoef,
+                                                      float* __restrict__ partial, AT* __restrict__ dlp, float lp_scale) {
+  __shared__ float sm[4];
+  const int Rq = R >> 2;
+  const size_t total = (size_t)Sn * B * Rq;
+  float acc = 0.f;
+  typedef typename AT4<AT>::type at4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i % Rq) << 2, b = (int)((i / Rq) % B), s = (int)(i / ((size_t)Rq * B));
+    const size_t o = (i / Rq) * R + r;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(out + o);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(ref + (size_t)b * ref_bstride + (size_t)s * ref_sstride + r);
+    const f32x4 d = v - e;
+    acc += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    const f32x4 g = gcoef * d;
+    *reinterpret_cast<f32x4*>(out + o) = g;
+    if (dlp) *reinterpret_cast<at4*>(dlp + o) = AT4<AT>::cvt(lp_scale * g);
+  }
+  acc = block_sum256(acc, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
 // =============================================================================================
 // local reconstructor attention (local_reconstructor.py:38-50), one workgroup per caption
 //   beta[t'] = w . tanh(W hr + U h_t' + b)  (no softmax);  x = drop((1/T) sum_t' beta[t'] h_t')
