@@ -128,31 +128,78 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
   const float cl = clip ? *clip : 1.f;
   PackDesc pk; pk.ndst = 0; pk.cols = 1;
   if (pack) pk = pack[ch.x];
-  for (int i = ch.y + threadIdx.x; i < end; i += 256) {
-    const float p = td.p[i];
-    float g = (td.g[i] + k * p) * cl;
-    g = g + hp.wd * p;
-    float m = td.m[i];
-    m = m + hp.one_m_b1 * (g - m);
-    float v = td.v[i] * hp.beta2f + hp.one_m_b2 * g * g;
-    td.m[i] = m; td.v[i] = v;
-    float vh = v;
-    if (hp.amsgrad) { vh = fmaxf(td.vmax[i], v); td.vmax[i] = vh; }
-    const float denom = sqrtf(vh) / bc2s + hp.eps;
-    const float pn = p - step_size * (m / denom);
-    td.p[i] = pn;
-    if (pk.ndst) {
-      const int r = i / pk.cols, c = i - r * pk.cols;
+  // one element: the update and the packed image(s)
+  auto pack_one = [&](int i, float pn) {
+    const int r = i / pk.cols, c = i - r * pk.cols;
 #pragma unroll
-      for (int d = 0; d < 6; ++d)
-        if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc &&
-            (pk.d[d].mode || (r >= pk.d[d].r0 && r < pk.d[d].r0 + pk.d[d].nr))) {
-          int dr = r - pk.d[d].r0;
-          if (pk.d[d].mode) { const int gate = r / pk.d[d].nr, u = r - gate * pk.d[d].nr; dr = (u >> 3) * 32 + gate * 8 + (u & 7); }
-          const size_t o = (size_t)dr * pk.d[d].ld + (c - pk.d[d].c0);
-          if (lp) reinterpret_cast<bf16_t*>(pk.d[d].dst)[o] = (bf16_t)pn; else reinterpret_cast<float*>(pk.d[d].dst)[o] = pn;
+    for (int d = 0; d < 6; ++d)
+      if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc &&
+          (pk.d[d].mode || (r >= pk.d[d].r0 && r < pk.d[d].r0 + pk.d[d].nr))) {
+        int dr = r - pk.d[d].r0;
+        if (pk.d[d].mode) { const int gate = r / pk.d[d].nr, u = r - gate * pk.d[d].nr; dr = (u >> 3) * 32 + gate * 8 + (u & 7); }
+        const size_t o = (size_t)dr * pk.d[d].ld + (c - pk.d[d].c0);
+        if (lp) reinterpret_cast<bf16_t*>(pk.d[d].dst)[o] = (bf16_t)pn; else reinterpret_cast<float*>(pk.d[d].dst)[o] = pn;
+      }
+  };
+  auto upd = [&](float p, float gr, float& m, float& v, float& vmx) -> float {
+    float g = (gr + k * p) * cl;
+    g = g + hp.wd * p;
+    m = m + hp.one_m_b1 * (g - m);
+    v = v * hp.beta2f + hp.one_m_b2 * g * g;
+    float vh = v;
+    if (hp.amsgrad) { vh = fmaxf(vmx, v); vmx = vh; }
+    const float denom = sqrtf(vh) / bc2s + hp.eps;
+    return p - step_size * (m / denom);
+  };
+  // The update streams 28 (36 with AMSGrad) bytes per parameter: 16-byte accesses for the whole quads of the chunk (chunks
+  // start at multiples of RN_CHUNK elements of 16-byte aligned tensors); a quad that lies inside one row and inside (or
+  // outside) every packed window on a 4-column grid is packed with one 8-byte store per image.
+  const bool al = (((uintptr_t)td.p | (uintptr_t)td.g | (uintptr_t)td.m | (uintptr_t)td.v | (uintptr_t)(hp.amsgrad ? td.vmax : td.p)) & 15) == 0;
+  int i0 = ch.y;
+  if (al) {
+    const int nq = (end - ch.y) >> 2;
+    bool grid4 = (pk.cols & 3) == 0;
+    for (int d = 0; d < 6; ++d)
+      if (d < pk.ndst && (((pk.d[d].c0 | pk.d[d].nc | pk.d[d].ld) & 3) || pk.d[d].mode)) grid4 = false;
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      const int i = ch.y + (q << 2);
+      const f32x4 p4 = *reinterpret_cast<const f32x4*>(td.p + i), g4 = *reinterpret_cast<const f32x4*>(td.g + i);
+      f32x4 m4 = *reinterpret_cast<const f32x4*>(td.m + i), v4 = *reinterpret_cast<const f32x4*>(td.v + i);
+      f32x4 x4 = hp.amsgrad ? *reinterpret_cast<const f32x4*>(td.vmax + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 n4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float m = m4[e], v = v4[e], x = x4[e]; n4[e] = upd(p4[e], g4[e], m, v, x); m4[e] = m; v4[e] = v; x4[e] = x; }
+      *reinterpret_cast<f32x4*>(td.m + i) = m4; *reinterpret_cast<f32x4*>(td.v + i) = v4;
+      if (hp.amsgrad) *reinterpret_cast<f32x4*>(td.vmax + i) = x4;
+      *reinterpret_cast<f32x4*>(td.p + i) = n4;
+      if (pk.ndst) {
+        if (grid4) {
+          const int r = i / pk.cols, c = i - r * pk.cols;
+#pragma unroll
+          for (int d = 0; d < 6; ++d)
+            if (d < pk.ndst && c >= pk.d[d].c0 && c < pk.d[d].c0 + pk.d[d].nc && r >= pk.d[d].r0 && r < pk.d[d].r0 + pk.d[d].nr) {
+              const size_t o = (size_t)(r - pk.d[d].r0) * pk.d[d].ld + (c - pk.d[d].c0);
+              if (lp) {
+                bf16x4 hb; hb[0] = (bf16_t)n4[0]; hb[1] = (bf16_t)n4[1]; hb[2] = (bf16_t)n4[2]; hb[3] = (bf16_t)n4[3];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(pk.d[d].dst) + o) = hb;
+              } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(pk.d[d].dst) + o) = n4;
+              }
+            }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pack_one(i + e, n4[e]);
         }
+      }
     }
+    i0 = ch.y + (nq << 2);
+  }
+  for (int i = i0 + threadIdx.x; i < end; i += 256) {
+    float m = td.m[i], v = td.v[i], x = hp.amsgrad ? td.vmax[i] : 0.f;
+    const float pn = upd(td.p[i], td.g[i], m, v, x);
+    td.m[i] = m; td.v[i] = v;
+    if (hp.amsgrad) td.vmax[i] = x;
+    td.p[i] = pn;
+    if (pk.ndst) pack_one(i, pn);
   }
 }
-
