@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define RECNET_ABI_VERSION 3
+#define RECNET_ABI_VERSION 4
+#define RECNET_ATTN_NONE 0
+#define RECNET_ATTN_SOFTMAX 1
 #define RECNET_OK 0
 #define RECNET_EINVAL (-1)      /* bad dimension / null pointer / unsupported variant */
 #define RECNET_ESTATE (-2)      /* call order violated (e.g. backward before forward) */
@@ -53,6 +55,9 @@ typedef struct recnet_config {
   int32_t decoder_use_amsgrad, reconstructor_use_amsgrad;       /* config.py:90-91 */
   int32_t decoder_cell;               /* RECNET_CELL_*: decoder_model                    config.py:31  */
   int32_t reconstructor_cell;         /* RECNET_CELL_*: reconstructor_model              config.py:77  */
+  int32_t decoder_attn_normalize;     /* RECNET_ATTN_NONE (the reference: decoder.py:30's softmax is constructed but never
+                                         called, decoder.py:55-61) | RECNET_ATTN_SOFTMAX: softmax over the frames of the
+                                         attention energies before the weighted mean (opt-in; north_star's wording) */
   float embedding_scale;              /*                                                config.py:59  */
   float embedding_dropout;            /*                                                config.py:58  */
   float decoder_out_dropout;          /* dropout applied to the logits, decoder.py:69   config.py:70  */

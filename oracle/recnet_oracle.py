@@ -96,6 +96,10 @@ def _last_h(hidden, cell):
 
 
 # ----------------------------------------------------------------------------- decoder
+ATTN_NORMALIZE = "none"   # "softmax": the product's opt-in normalisation of the decoder's attention energies over the frames
+#                           (the reference constructs nn.Softmax(dim=1) at decoder.py:30 and never calls it)
+
+
 def decoder_step(P, tok, hidden, enc, *, cell="LSTM", emb_scale=1.0, p_emb=0.5, p_out=0.5,
                  drop=None, t=0):
     """Decoder.forward, models/decoder.py:45-70.  tok [1,B] int64; hidden (h,c) each [1,B,H]
@@ -107,6 +111,8 @@ def decoder_step(P, tok, hidden, enc, *, cell="LSTM", emb_scale=1.0, p_emb=0.5, 
     Uv = enc @ P["attn_U.weight"].t()                                    # :54 (recomputed each step)
     al = torch.tanh(Wh.unsqueeze(1) + Uv + P["attn_b"])                  # :55-57
     al = al @ P["attn_w.weight"].t()                                     # :58  [B,F,1]  (no softmax)
+    if ATTN_NORMALIZE == "softmax":
+        al = torch.softmax(al, dim=1)
     ctx = (al * enc).mean(dim=1)                                         # :59-61
     x = torch.cat((emb, ctx), dim=1)                                     # :64
     out, hidden = _rnn(P, "rnn.", cell, x, hidden)                       # :66

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip_probe.so" if os.environ.get("RN_LIB_PROBE") == "1" else "librecnet_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 REC_NONE, REC_GLOBAL, REC_LOCAL = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
@@ -22,7 +22,7 @@ class Config(C.Structure):
         "batch_size", "encoder_output_len", "encoder_output_size", "embedding_size", "decoder_hidden_size",
         "decoder_attn_size", "n_vocabs", "reconstructor_hidden_size", "reconstructor_attn_size",
         "caption_max_len", "reconstructor_type", "precision", "global_batch_size", "batch_offset",
-        "decoder_use_amsgrad", "reconstructor_use_amsgrad", "decoder_cell", "reconstructor_cell")] + [(n, _f) for n in (
+        "decoder_use_amsgrad", "reconstructor_use_amsgrad", "decoder_cell", "reconstructor_cell", "decoder_attn_normalize")] + [(n, _f) for n in (
         "embedding_scale", "embedding_dropout", "decoder_out_dropout", "reconstructor_decoder_dropout",
         "gradient_clip", "decoder_lambda_reg", "reconstructor_lambda_reg", "lambda_recon")] + [(n, _d) for n in (
         "decoder_learning_rate", "reconstructor_learning_rate", "decoder_weight_decay",

@@ -234,7 +234,8 @@ def build_decoder(n_vocabs, C=TrainConfig):
                     embedding_size=C.embedding_size, embedding_scale=C.embedding_scale,
                     hidden_size=C.decoder_hidden_size, attn_size=C.decoder_attn_size, output_size=n_vocabs,
                     embedding_dropout=C.embedding_dropout, dropout=C.decoder_dropout,
-                    out_dropout=C.decoder_out_dropout, precision=getattr(C, "precision", "bf16"))
+                    out_dropout=C.decoder_out_dropout, precision=getattr(C, "precision", "bf16"),
+                    attn_normalize=getattr(C, "decoder_attn_normalize", "none"))
     model = model.to(C.device)
     ms = ModelState(model, C.decoder_use_amsgrad)
     hy = _hyper_from(C)

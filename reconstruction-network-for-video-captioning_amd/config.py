@@ -31,6 +31,7 @@ _DEFAULTS = dict(
     decoder_lambda_reg=1e-3, reconstructor_lambda_reg=1e-2, lambda_recon=1.0,
     # additions
     precision="bf16",            # "bf16" (bf16 MFMA operands, fp32 accumulate) | "f32" (exact fp32 MFMA)
+    decoder_attn_normalize="none",   # "none": the reference (decoder.py:30's softmax is never called) | "softmax": opt-in
     dropout_seed=42,
 )
 

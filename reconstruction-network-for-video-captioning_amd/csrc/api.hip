@@ -277,6 +277,8 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     return fail(RECNET_EINVAL, "non-positive dimension");
   if (c.reconstructor_type < 0 || c.reconstructor_type > 2) return fail(RECNET_EINVAL, "unknown reconstructor_type");
   if (c.precision != RECNET_PREC_F32 && c.precision != RECNET_PREC_BF16) return fail(RECNET_EINVAL, "unknown precision");
+  if (c.decoder_attn_normalize != RECNET_ATTN_NONE && c.decoder_attn_normalize != RECNET_ATTN_SOFTMAX)
+    return fail(RECNET_EINVAL, "unknown decoder_attn_normalize (0 = none, 1 = softmax)");
   if (c.decoder_cell < 0 || c.decoder_cell > 1 || c.reconstructor_cell < 0 || c.reconstructor_cell > 1)
     return fail(RECNET_EINVAL, "unknown recurrent cell (0 = LSTM, 1 = GRU)");
   if (c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_hidden_size <= 0)

@@ -33,6 +33,7 @@ struct DecChainArgs {
   bf16_t* Hlp; int ld_hlp;         // [T][B][ld_hlp] row-major operand copy of h_t, zero padded
   float* Wh; float* att;           // [T][B][A], [T][B][F]
   unsigned* bar;
+  int softmax;                     // 1: softmax over the frames of the attention energies (recnet_config.decoder_attn_normalize)
   unsigned long long* ts;          // probe only (DC_PROBE_TS): [T][12] timestamps of one workgroup
 };
 
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
             float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
             if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
             s = wave_sum(s);
-            if (lane == 0) { sa[f] = s; p.att[((size_t)t * B + b) * F + f] = s; }
+            if (lane == 0) { sa[f] = s; if (!p.softmax) p.att[((size_t)t * B + b) * F + f] = s; }
           }
         }
         if (XF) {
@@ -260,12 +261,13 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
               float s = wk[0] * rn_tanh(hk[0] + suvx[(f - 32) * 128 + lane] + bk[0]);
               if (A > 64) s += wk[1] * rn_tanh(hk[1] + suvx[(f - 32) * 128 + lane + 64] + bk[1]);
               s = wave_sum(s);
-              if (lane == 0) { sa[f] = s; p.att[((size_t)t * B + b) * F + f] = s; }
+              if (lane == 0) { sa[f] = s; if (!p.softmax) p.att[((size_t)t * B + b) * F + f] = s; }
             }
           }
         }
       }
       __syncthreads();
+      if (p.softmax) { attn_softmax_lds(sa, F, p.att + ((size_t)t * B + b) * F); __syncthreads(); }
       DC_TS(8);
       if (live) {
         float c[8];
@@ -373,6 +375,7 @@ struct DecChainBwdArgs {
   const float* dHs; const float* dHs2;                      // [T][B][H]; dHs2 may be null
   const float* acts; const float* Cs; const float* Hs;      // [T][B][4H], [T][B][H], [T][B][H]
   const float* Wh;                 // [T][B][A]
+  const float* att; int softmax;   // softmax mode: the saved attention weights [T][B][F]
   float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh (ll: stamped 8-byte words)
   unsigned* epoch; int ll; int master; float* poison;
   bf16_t* Pan;                     // [T][rc_pan_elems(4H + A)] exchange (by chain step): rows [dgates | dWh]
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         if (tid < SPF) sda[tid] = (spartf[tid] + spartf[SPF + tid] + spartf[2 * SPF + tid] + spartf[3 * SPF + tid]) * (1.0f / (float)F);
       }
       __syncthreads();
+      if (p.softmax) { attn_softmax_bwd_lds(sda, p.att + ((size_t)t * B + b) * F, F); __syncthreads(); }
       // (3) attention backward on the (f, k) plane
       float dwh = 0.f;
       if (fk_on) {

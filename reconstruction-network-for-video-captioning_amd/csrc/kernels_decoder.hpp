@@ -30,6 +30,7 @@ struct DecCellArgs {
   float* acts;            // [B][4H] post-activation gates or nullptr
   float* Wh_out;          // [B][A] or nullptr
   float* att_out;         // [B][F] or nullptr
+  int softmax;            // 1: softmax over the frames of the energies (attn_softmax_lds)
 };
 
 template <typename AT>
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(1024) void dec_cell_kernel(const DecCellArgs p) {
         float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
         if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
         s = wave_sum(s);
-        if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+        if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0 && !p.softmax) p.att_out[(size_t)b * F + f] = s; }
       }
     }
   } else {
@@ -103,10 +104,11 @@ __global__ __launch_bounds__(1024) void dec_cell_kernel(const DecCellArgs p) {
       float s = 0.f;
       for (int k = lane; k < A; k += 64) s += p.w[k] * rn_tanh(swh[k] + uv[k] + p.ab[k]);
       s = wave_sum(s);
-      if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+      if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0 && !p.softmax) p.att_out[(size_t)b * F + f] = s; }
     }
   }
   __syncthreads();
+  if (p.softmax) { attn_softmax_lds(sa, F, (p.att_out && blockIdx.y == 0) ? p.att_out + (size_t)b * F : nullptr); __syncthreads(); }
   if (u < H) {
     float c0 = 0.f, c1 = 0.f;
 #pragma unroll
@@ -253,11 +255,12 @@ __global__ __launch_bounds__(256) void dec_cell_vec_kernel(const DecCellArgs p) 
         float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
         if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
         s = wave_sum(s);
-        if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0) p.att_out[(size_t)b * F + f] = s; }
+        if (lane == 0) { sa[f] = s; if (p.att_out && blockIdx.y == 0 && !p.softmax) p.att_out[(size_t)b * F + f] = s; }
       }
     }
   }
   __syncthreads();
+  if (p.softmax) { attn_softmax_lds(sa, F, (p.att_out && blockIdx.y == 0) ? p.att_out + (size_t)b * F : nullptr); __syncthreads(); }
   if (live) {
     float c[8];
 #pragma unroll
@@ -327,6 +330,7 @@ struct DecCellBwdArgs {
   float* dUv;            // [B][F][A] accumulated over t
   float* dwacc;          // [RN_FCH][B][A] accumulated over t
   void* dUv_lp; int ld_dUv; int last;   // at the last executed step (t == 0) also emit the AT copy of dUv
+  const float* att; int softmax;        // softmax mode: the saved attention weights [B][F] of step t
 };
 
 template <typename AT>
@@ -437,7 +441,19 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
   if (ch == 0) for (int j = W4 + RN_FCH * A + tid; j < p.ld_dgx; j += 256) dgx[j] = (AT)0.f;   // pad
   __syncthreads();
   const float invF = 1.0f / (float)F;
-  if (fast) {
+  if (p.softmax) {
+    // the softmax couples the frames: every chunk workgroup needs da of ALL frames before it can turn them into energy
+    // gradients (opt-in mode: the 4x redundant frame products are a few microseconds)
+    for (int f = wave; f < F; f += 4) {
+      const AT* pp = Pb + (size_t)f * p.ldp;
+      float s = 0.f;
+      for (int n = lane; n < W4; n += 64) s += sdg[n] * (float)pp[n];
+      s = wave_sum(s);
+      if (lane == 0) sda[f] = s * invF;
+    }
+    __syncthreads();
+    attn_softmax_bwd_lds(sda, p.att + (size_t)b * F, F);
+  } else if (fast) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int i = wave + 4 * q;

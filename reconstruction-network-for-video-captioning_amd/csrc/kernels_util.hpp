@@ -241,6 +241,37 @@ __global__ void copy_kernel(const float* __restrict__ x, float* __restrict__ y, 
 }
 
 // =============================================================================================
+// Optional softmax over the frames of the attention energies (recnet_config.decoder_attn_normalize; the reference builds
+// nn.Softmax(dim=1) at decoder.py:30 and never calls it, so the default is none).  sa[0..F) in LDS; wave 0 does the
+// wavefront max / sum reductions; the caller brackets the call with __syncthreads().
+__device__ __forceinline__ void attn_softmax_lds(float* sa, int F, float* att_out) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float m = -3.0e38f;
+    for (int f = lane; f < F; f += 64) m = fmaxf(m, sa[f]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int f = lane; f < F; f += 64) s += __expf(sa[f] - m);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int f = lane; f < F; f += 64) {
+      const float a = __expf(sa[f] - m) * inv;
+      sa[f] = a;
+      if (att_out) att_out[f] = a;
+    }
+  }
+}
+// its backward on the frame gradients: sda[f] <- a[f] (sda[f] - sum_g a[g] sda[g]),  a = the saved weights
+__device__ __forceinline__ void attn_softmax_bwd_lds(float* sda, const float* att, int F) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    float d = 0.f;
+    for (int f = lane; f < F; f += 64) d += att[f] * sda[f];
+    d = wave_sum(d);
+    for (int f = lane; f < F; f += 64) sda[f] = att[f] * (sda[f] - d);
+  }
+}
+
 // LSTM gate math (torch.nn.LSTM order i, f, g, o)
 // =============================================================================================
 struct LstmOut { float i, f, g, o, c, h; };

@@ -101,6 +101,7 @@ class Engine:
         c.batch_offset = batch_offset
         c.decoder_cell = _CELL[dims.get("dec_cell", "LSTM")]
         c.reconstructor_cell = _CELL[dims.get("rec_cell", "LSTM")]
+        c.decoder_attn_normalize = {"none": 0, "softmax": 1}[dims.get("attn_normalize", "none")]
         c.decoder_use_amsgrad = int(bool(hy["decoder_use_amsgrad"]))
         c.reconstructor_use_amsgrad = int(bool(hy["reconstructor_use_amsgrad"]))
         for k in ("embedding_scale", "embedding_dropout", "decoder_out_dropout", "reconstructor_decoder_dropout",

@@ -56,9 +56,14 @@ class Decoder(nn.Module, _Generation):
     """models/decoder.py:6-70."""
 
     def __init__(self, model_name, n_layers, encoder_size, embedding_size, embedding_scale, hidden_size,
-                 attn_size, output_size, embedding_dropout, dropout, out_dropout, precision="bf16"):
+                 attn_size, output_size, embedding_dropout, dropout, out_dropout, precision="bf16", attn_normalize="none"):
         super().__init__()
         G = _gates(model_name, n_layers, "Decoder")
+        # "none": the reference's behaviour (its nn.Softmax, decoder.py:30, is never called); "softmax": opt-in
+        # normalisation of the attention energies over the frames before the weighted mean
+        if attn_normalize not in ("none", "softmax"):
+            raise NotImplementedError("attn_normalize must be 'none' or 'softmax' (got %r)" % (attn_normalize,))
+        self.attn_normalize = attn_normalize
         self.model_name, self.n_layers = model_name, n_layers
         self.encoder_size, self.embedding_size, self.embedding_scale = encoder_size, embedding_size, embedding_scale
         self.hidden_size, self.attn_size, self.output_size = hidden_size, attn_size, output_size
@@ -95,7 +100,7 @@ class Decoder(nn.Module, _Generation):
 
     def dims(self, B, F):
         return dict(B=B, F=F, D=self.encoder_size, E=self.embedding_size, H=self.hidden_size, A=self.attn_size,
-                    V=self.output_size, dec_cell=self.model_name)
+                    V=self.output_size, dec_cell=self.model_name, attn_normalize=self.attn_normalize)
 
     def hyper(self):
         return dict(embedding_scale=self.embedding_scale, embedding_dropout=self.embedding_dropout_p,

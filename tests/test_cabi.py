@@ -39,7 +39,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layout_matches_header(lib):
     from recnet_amd import _lib
     # 18 int32 + 8 float + 7 double
-    assert C.sizeof(_lib.Config) == 18 * 4 + 8 * 4 + 7 * 8
+    assert C.sizeof(_lib.Config) == 19 * 4 + 8 * 4 + 4 + 7 * 8      # 27 four-byte fields, 4 bytes of alignment padding, 7 doubles
     assert C.sizeof(_lib.DecoderTensors) == 11 * 8
     assert C.sizeof(_lib.ReconstructorTensors) == 10 * 8
     hdr = open(HEADER).read()
