@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip_probe.so" if os.environ.get("RN_LIB_PROBE") == "1" else "librecnet_hip.so")
+# RN_LIB_PROBE=1: the probe build (in-kernel time stamps); RN_LIB_VARIANT=acqinv: the cross-check build with acquire fences
+_VARIANT = "_probe" if os.environ.get("RN_LIB_PROBE") == "1" else ("_" + os.environ["RN_LIB_VARIANT"] if os.environ.get("RN_LIB_VARIANT") else "")
+LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip%s.so" % _VARIANT)
 ABI_VERSION = 4
 
 REC_NONE, REC_GLOBAL, REC_LOCAL = 0, 1, 2

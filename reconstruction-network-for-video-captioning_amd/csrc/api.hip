@@ -80,7 +80,7 @@ struct recnet_handle {
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void* Hr_pan = nullptr;
-  void *lc_panh = nullptr, *lc_panx = nullptr; float* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
+  void *lc_panh = nullptr, *lc_panx = nullptr; _Float16* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
   void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
   int lcb_msx = 1, lcb_rbu = 4, lc_bwd_done = 0;
   float dout_scale = 0.f; int dout_ready = 0;   // dout_lp already holds dout_scale * d loss / d out (written by the MSE kernel)
@@ -233,7 +233,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->slab2 = take(16 * B * R);
     h->lc_panh = takev(F * rc_pan_elems((int)R) / 2 + 64);
     h->lc_panx = takev(F * rc_pan_elems((int)H) / 2 + 64);
-    h->lc_pw = take(F * B * ((R + 15) / 16) * RA);
+    h->lc_pw = (_Float16*)take(F * B * ((R + 15) / 16) * RA / 2 + 64);
     h->lc_pang = takev(F * rc_pan_elems((int)(4 * R)) / 2 + 64);
     h->lc_panw = takev(F * rc_pan_elems((int)RA) / 2 + 64);
     h->lc_dx = take(F * B * H);

@@ -33,7 +33,9 @@ struct LocChainArgs {
   bf16_t* Xcat; int ld_xcat;          // [F][B][ld_xcat]: x_s -> columns [0, H)
   float* beta; float* Whr;            // [F][B][T], [F][B][A]
   bf16_t* PanH; bf16_t* PanX;         // exchange: [F][rc_pan_elems(R)], [F][rc_pan_elems(H)]
-  float* Pw;                          // exchange: [F][B][NG][A] rank-16 contributions to Whr of step s (written at s-1)
+  _Float16* Pw;                       // exchange: [F][B][NG][A] rank-16 contributions to Whr of step s (written at s-1), fp16:
+                                      // |contribution| < 0.5, rounding 2^-11 per term — a quarter of the bf16 operand rounding
+                                      // already inside each product — for half the bytes of the step's largest store burst
   unsigned* bar; unsigned* epoch; float* poison;
   DropDesc dd;
   unsigned long long* ts;             // probe builds only (LC_PROBE): [role][step][8] wall-clock stamps of one workgroup per role
@@ -85,6 +87,7 @@ __device__ __forceinline__ void lc_store16(bf16_t* dst, const bf16_t* src) {    
   __hip_atomic_store(d + 1, s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 typedef short lc_s4 __attribute__((ext_vector_type(4)));
+typedef _Float16 lc_h4 __attribute__((ext_vector_type(4)));
 
 // release words: relU (word 0 of each line) = "every U workgroup has finished step .", relC (word 16) = "every C ...".
 // Flag / release values are fb + phase, fb = launch epoch << 7 (rec_chain.hpp).  Phases: U arrives with s + 1 after
@@ -161,16 +164,19 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
         // thread = (attention columns 4 aq .. 4 aq + 3, unit groups gg, gg + 4, ..): every load of the step is issued before
         // the first use (one memory round trip; the blocks were written by other XCDs a moment ago and come from memory)
         const int aq = j & 31, gg = j >> 5;
-        f32x4 v[32];
+        lc_h4 v[32];
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
           const int g = gg + 4 * q;
-          v[q] = (bok && 4 * aq < A && g < p.NG) ? *reinterpret_cast<const f32x4*>(p.Pw + (((size_t)s * B + b) * p.NG + g) * A + 4 * aq)
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+          v[q] = (bok && 4 * aq < A && g < p.NG) ? *reinterpret_cast<const lc_h4*>(p.Pw + (((size_t)s * B + b) * p.NG + g) * A + 4 * aq)
+                                               : lc_h4{0, 0, 0, 0};
         }
         f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 32; q += 4) a4 += (v[q] + v[q + 1]) + (v[q + 2] + v[q + 3]);
+        for (int q = 0; q < 32; q += 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a4[e] += ((float)v[q][e] + (float)v[q + 1][e]) + ((float)v[q + 2][e] + (float)v[q + 3][e]);
+        }
         *reinterpret_cast<f32x4*>(spw + ((c * 4 + gg) * 128 + 4 * aq)) = a4;
         __syncthreads();
         whr = (spw[(c * 4 + 0) * 128 + j] + spw[(c * 4 + 1) * 128 + j]) + (spw[(c * 4 + 2) * 128 + j] + spw[(c * 4 + 3) * 128 + j]);
@@ -372,17 +378,15 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       }
       __syncthreads();
       {
-        const int nq = A >> 2;                                  // float4 items per row
-        float* Pn = p.Pw + ((size_t)(s + 1) * B * p.NG + ug) * A;
+        const int nq = A >> 2;                                  // 4-column items per row: one 8-byte store each
+        _Float16* Pn = p.Pw + ((size_t)(s + 1) * B * p.NG + ug) * A;
         for (int idx = tid; idx < own * nq; idx += 256) {
           const int rg = own_lo + idx / nq, qc = (idx % nq) * 4;
           if (rg < B && rg - r0 < ROWS) {
-            const float* src = tw + (rg - r0) * tld + qc;
-            union { float f[2]; uint64_t u; } lo, hi;
-            lo.f[0] = src[0]; lo.f[1] = src[1]; hi.f[0] = src[2]; hi.f[1] = src[3];
-            uint64_t* dst = reinterpret_cast<uint64_t*>(Pn + (size_t)rg * p.NG * A + qc);
-            __hip_atomic_store(dst, lo.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dst + 1, hi.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tw + (rg - r0) * tld + qc);
+            union { lc_h4 h; uint64_t u; } pk;
+            pk.h[0] = (_Float16)v[0]; pk.h[1] = (_Float16)v[1]; pk.h[2] = (_Float16)v[2]; pk.h[3] = (_Float16)v[3];
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(Pn + (size_t)rg * p.NG * A + qc), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
@@ -489,6 +493,7 @@ struct LocChainBwdArgs {
   bf16_t* PanG; bf16_t* PanW; float* Dx;    // exchange: [F][rc_pan_elems(4R)], [F][rc_pan_elems(A)], [F][B][H]
   unsigned* bar; unsigned* epoch; float* poison;
   DropDesc dd;
+  int defer_big;                     // 1: U' starts its recurrent product after X' has finished with the same panel (L2 bandwidth)
   unsigned long long* ts;            // probe builds only
 };
 
@@ -794,7 +799,9 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       f32x4 acc[RBU];
 #pragma unroll
       for (int i = 0; i < RBU; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      lc_wait(relG, fb + (unsigned)q, p.bar);                        // dG_{s+1} is complete
+      // dG_{s+1} is complete.  X' (on the critical path) streams the same 1.4 MB panel out of the L2s at the same time: with
+      // defer_big U' waits until X' has published dx (its own product is only needed after C' has finished as well)
+      if (p.defer_big) lc_wait(relX, fb + (unsigned)q, p.bar); else lc_wait(relG, fb + (unsigned)q, p.bar);
       if (wg == 0) LC_TS(4, q, 0);
       lcb_product<STEPS, PF, RBU>(acc, wb, p.PanG + (size_t)(q - 1) * pan_g + lane_off, K, kw0, rot);
       if (wg == 0) LC_TS(4, q, 1);
