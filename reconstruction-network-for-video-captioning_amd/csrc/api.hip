@@ -83,6 +83,7 @@ struct recnet_handle {
   void *lc_panh = nullptr, *lc_panx = nullptr; _Float16* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
   void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
   int lcb_msx = 1, lcb_rbu = 4, lc_bwd_done = 0;
+  int deferred_early = 0, deferred_early_flags = -1, deferred_done = 0, join_recorded = 0;   // rec_deferred_fork (host_reconstructor.inc)
   float dout_scale = 0.f; int dout_ready = 0;   // dout_lp already holds dout_scale * d loss / d out (written by the MSE kernel)
   unsigned long long* lc_ts = nullptr;   // probe builds (make PROBE=1): wall-clock stamps of the local chain kernels
   int lc_ms = 1, lc_rb = 4, lc_ng = 0, lc_nc = 0;
