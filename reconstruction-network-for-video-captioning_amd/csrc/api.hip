@@ -84,6 +84,7 @@ struct recnet_handle {
   void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
   int lcb_msx = 1, lcb_rbu = 4, lc_bwd_done = 0;
   int deferred_early = 0, deferred_early_flags = -1, deferred_done = 0, join_recorded = 0;   // rec_deferred_fork (host_reconstructor.inc)
+  float mse_scale = 0.f; int mse_nb = 0;   // pending MSE partials: fwd_rec finalises the loss scalars in one launch
   float dout_scale = 0.f; int dout_ready = 0;   // dout_lp already holds dout_scale * d loss / d out (written by the MSE kernel)
   unsigned long long* lc_ts = nullptr;   // probe builds (make PROBE=1): wall-clock stamps of the local chain kernels
   int lc_ms = 1, lc_rb = 4, lc_ng = 0, lc_nc = 0;
@@ -214,7 +215,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->mp = take(B * H); h->Xg = take(Tm * B * 4 * R);
     h->Hr = take(Tm * B * R); h->Cr = take(Tm * B * R); h->acts_r = take(Tm * B * 4 * R);
     h->hrmean = take(B * R); h->outm = take(B * R); h->encmean = take(B * R); h->dhrmean = take(B * R);
-    h->dmpd = take(Tm * B * H); h->dmp = take(B * H);
+    h->dmpd = take(Tm * B * 2 * H); h->dmp = take(B * H);   // dmpd: [T][B][2H] merged input-side product of the backward
     h->Xcat_g = takev(Tm * B * (size_t)h->ld2H); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
     h->Hr_pan = takev(Tm * rc_pan_elems((int)R) / 2 + 64);       // bf16: k-group-major copies of h_t for rec_chain_kernel
     h->dG_pan = takev(Tm * rc_pan_elems((int)(4 * R)) / 2 + 64);

@@ -223,6 +223,20 @@ __global__ void bcast_drop_bwd_kernel(const float* __restrict__ dmpd, float* __r
     dmp[i] = s;
   }
 }
+// Global reconstructor, d loss / d decoder states from the merged input-side product tmp[t,b,0:2H) = dG_t . W_ih:
+//   dmp[b,h] = sum_t tmp[t,b,H+h] * dropmask(t,b,h) ;  dhid[t,b,h] = tmp[t,b,h] + c * dmp[b,h]     (c = caption_max_len / T^2)
+__global__ void global_dhid_kernel(const float* __restrict__ tmp, float* __restrict__ dhid, int T, int B, int H, float c, DropDesc dd) {
+  const uint32_t key = drop_key(dd);
+  const size_t n = (size_t)B * H;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H), b = (int)(i / H);
+    const float* row = tmp + (size_t)b * 2 * H + h;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += row[(size_t)t * B * 2 * H + H] * drop_at(dd, key, t, b, H, h);
+    s *= c;
+    for (int t = 0; t < T; ++t) dhid[(size_t)t * n + i] = row[(size_t)t * B * 2 * H] + s;
+  }
+}
 // Y[t*n + i] (+)= c * x[i]
 __global__ void add_bcast_kernel(float* __restrict__ Y, const float* __restrict__ x, int T, size_t n, float c, int accumulate) {
   const size_t total = (size_t)T * n;

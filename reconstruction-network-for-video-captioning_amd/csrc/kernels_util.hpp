@@ -110,6 +110,19 @@ __device__ __forceinline__ float drop_at(const DropDesc& dd, uint32_t key, int t
   return rn_drop_scale(key, dd.thr, dd.inv_keep, idx);
 }
 
+// The reconstructor's loss scalars in one launch: mse = scale * sum_j x[j] ; rec_loss = mse + lam_reg * reg ;
+// total = dec_loss + lam_recon * rec_loss   (scal: [2] dec_loss [3] mse [4] reg [5] rec_loss [6] total)
+__global__ __launch_bounds__(256) void rec_loss_finalize_kernel(const float* __restrict__ x, int n, float scale, float* scal, float lam_reg,
+                                                                float lam_recon) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) {
+    const float mse = s * scale, rl = mse + lam_reg * scal[4];
+    scal[3] = mse; scal[5] = rl; scal[6] = scal[2] + lam_recon * rl;
+  }
+}
 // out[i] = scale * sum_j x[j]   (single block; deterministic order)
 __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float* out, float scale) {
   __shared__ float sm[4];
