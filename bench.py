@@ -75,7 +75,7 @@ def algorithmic_hbm_bytes(kind, B, F, D, V=4188, E=468, H=512, A=128, RA=128):
     return 36.0 * p_dec + 28.0 * p_rec + 4.0 * B * F * D + 8.0 * 31 * B
 
 
-def roofline(eng, run_step, kind, precision, iters=5):
+def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
     """Dominant kernel = the longest of the persistent recurrent-chain kernels (one launch = all T dependent steps of
     one chain, weights resident on chip, grid barrier / stamped hand-over per step), else the per-step recurrent GEMM.
     `achieved` = algorithmic bytes of one launch (recnet_recurrent_step_bytes) / its average duration, measured with
@@ -141,7 +141,8 @@ def roofline(eng, run_step, kind, precision, iters=5):
     tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s_%s.json" % (kind or "none", short))
     if precision == "bf16" and os.path.exists(tf):
         meta = json.load(open(tf))
-        if meta.get("B") == eng.dims["B"] and meta.get("D") == eng.dims["D"] and meta.get("F") == eng.dims["F"]:
+        if (meta.get("B") == eng.dims["B"] and meta.get("D") == eng.dims["D"] and meta.get("F") == eng.dims["F"] and
+                meta.get("T", 31) == T and meta.get("cell", "LSTM") == cell):
             traffic, traffic_src = int(meta["traffic_bytes_per_launch"]), "stored: profiles/" + os.path.basename(tf)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -275,7 +276,7 @@ def main():
                 return eng.profile_site_graph(s_id, one)
             # (never the data-parallel step itself: this runs on rank 0 only, a collective here would wait for ever)
             return eng.profile_site(s_id, one, 5)
-        prof = roofline(eng, prof_pass, kind, args.precision)
+        prof = roofline(eng, prof_pass, kind, args.precision, T=T, cell=args.cell)
         # whole-step roofline fractions: algorithmic FLOPs against the dense bf16 MFMA peak and
         # algorithmic HBM bytes (optimiser + inputs) against 8 TB/s; per GPU (every rank does the same work)
         Bl = hi - lo

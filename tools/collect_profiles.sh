@@ -17,7 +17,7 @@ pmc() {  # name kernel-pattern rec batch frames feat kind
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${n}_$c -- python3 bench.py $args --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
   done
   python3 tools/pmc_traffic.py $O/pmc_${n}_FETCH_SIZE $O/pmc_${n}_WRITE_SIZE "$pat" | python3 -c "
-import json,sys; d=json.load(sys.stdin); d.update(B=$4, F=$5, D=$6, kind='$7'); print(json.dumps(d))" > $O/pmc_traffic_$7_$pat.json
+import json,sys; d=json.load(sys.stdin); d.update(B=$4, F=$5, D=$6, kind='$7', T=31, cell='LSTM'); print(json.dumps(d))" > $O/pmc_traffic_$7_$pat.json
 }
 run c2 global 100 28 1536 ""
 run c3 local 100 28 1536 "--no-cpu-baseline"
