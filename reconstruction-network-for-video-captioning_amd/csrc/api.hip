@@ -14,9 +14,8 @@
 //   abi_search.inc           per-step decoder API, greedy / beam search
 //   abi_step.inc             sequence-level entry points and the fused train step (stream orchestration)
 //   abi_misc.inc             profiling hooks, bare GEMM entry points
-// Device code: kernels.hpp -> kernels_{util,decoder,reconstructor,search,optim}.hpp, gemm*.hpp (GEMMs), rec_step.hpp,
-// rec_chain.hpp / dec_chain.hpp (the four recurrent chains as persistent kernels)
-// (experimental fused step), common.hpp.
+// Device code: kernels.hpp -> kernels_{util,decoder,reconstructor,search,optim}.hpp, gemm*.hpp (GEMMs),
+// rec_chain.hpp / loc_chain.hpp / dec_chain.hpp (the recurrent chains as persistent kernels), common.hpp.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -27,7 +26,6 @@
 
 #include "../../include/recnet_hip.h"
 #include "kernels.hpp"
-#include "rec_step.hpp"
 #include "rec_chain.hpp"
 #include "dec_chain.hpp"
 #include "loc_chain.hpp"
@@ -105,8 +103,6 @@ struct recnet_handle {
   float* dc_G2 = nullptr; void* dc_pan2 = nullptr;
   void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_f, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;
-  void* Whh_g = nullptr;   // gate-interleaved W_hh of the fused recurrent step (rec_step.hpp); global reconstructor, LSTM, bf16
-  int fused_rec = 0;
   int persist_rec = 0;     // rec_chain.hpp: the reconstructor's forward chain as one launch with W_hh resident in registers
   // inference search scratch (beam width <= 8)
   float *sr_logits, *sr_scores, *sr_h[2], *sr_c[2], *sr_hn, *sr_cn, *sr_cum[2], *sr_vals;
@@ -222,7 +218,6 @@ static size_t carve(recnet_handle* h, char* base) {
     h->WhhT = takev(R * (size_t)h->ld4R);
     h->dout_lp = takev(B * ldR); h->dGr = takev(Tm * B * ld4R);
     h->Wih_f = takev(4 * R * (size_t)h->ld2H); h->Whh_w = takev(4 * R * ldR);
-    h->Whh_g = takev(4 * R * ldR);
   } else if (h->kind == RECNET_REC_LOCAL) {
     h->Ud = take(Tm * B * RA);
     h->Hr = take(F * B * R); h->Cr = take(F * B * R); h->acts_r = take(F * B * 4 * R);
@@ -302,22 +297,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   {
-    // fused recurrent step of the global reconstructor (rec_step.hpp): bf16 path, LSTM, B <= 112, R % 8 == 0, K <= 2048.
-    // Opt-in (RN_FUSED_REC=1): at B=100, R=1536 it runs 15-18 us per step against 17.4 us for the GEMM + pointwise pair
-    // (tools/micro/rec_probe.hip) — every workgroup re-reads the whole activation block from L2, which costs more than
-    // the split-K slab round trip it removes; see DESIGN.md section 5.
-    const char* e = getenv("RN_FUSED_REC");
-    const int want = e ? atoi(e) : 0;
-    h->fused_rec = want && h->lp && h->kind == RECNET_REC_GLOBAL && !h->rgru && h->B <= 112 && (h->R & 7) == 0 && h->R <= 2048;
-  }
-  {
     // rec_chain.hpp: every workgroup (8 hidden units) must be resident at once — one per CU
     const char* e = getenv("RN_PERSIST_REC");
     int dev = 0, ncu = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     h->ncu = ncu;
-    h->persist_rec = (e ? atoi(e) : 1) && !h->fused_rec && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
+    h->persist_rec = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
                      (h->R & 7) == 0 && h->R <= 2048 && h->R / 8 <= ncu;   // <= 16 k-steps of resident weights per wave
     const char* ed = getenv("RN_PERSIST_DEC");
     const int N = 4 * h->H + h->A, NA = N / 16;
@@ -408,7 +394,6 @@ static void build_pack_tables(recnet_handle* h, int g) {
   } else if (h->kind == RECNET_REC_GLOBAL) {
     add_ih(0, 2 * H, h->Wih_f, h->ld2H, 0, 2 * H);
     add_hh(h->rgru, R, 1, R, h->Whh_w, h->ldR, 0, R);
-    if (h->fused_rec) { addr(1, R, h->Whh_g, h->ldR, 0, R, 0, R); o.pack[1].d[o.pack[1].ndst - 1].mode = 1; }
     add(4, R, h->Wor_w, h->ldR, 0, R);
   } else if (h->kind == RECNET_REC_LOCAL) {
     add(1, R, h->Wr_w, h->ldR, 0, R);
@@ -443,7 +428,14 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   if (!h->s2) {
     const char* ov = getenv("RN_OVERLAP");
     h->overlap = ov ? atoi(ov) : 1;
-    HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
+    // RN_SIDE_PRIO=1: the side stream at the lowest priority, so that work on the caller's stream (the chains and what they
+    // wait for) wins the CUs when both have workgroups to place
+    const char* pr = getenv("RN_SIDE_PRIO");
+    int lo = 0, hi = 0;
+    if (pr && atoi(pr) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      HIPCHK(hipStreamCreateWithPriority(&h->s2, hipStreamNonBlocking, lo));
+    else
+      HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
     for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
   }
   h->fwd_dec_done = h->fwd_rec_done = h->rec_bwd_done = 0;

@@ -38,6 +38,10 @@ struct DecChainArgs {
 };
 
 #define DC_RED_LD 17
+#if defined(LC_PROBE) && !defined(DC_PROBE_TS)      // the library's probe build (make probe): stamps of workgroup 0
+#define DC_PROBE_TS
+#define DC_PROBE_WG 0
+#endif
 #ifdef DC_PROBE_TS
 #define DC_TS(i) do { if (wg == DC_PROBE_WG && tid == 0) p.ts[(size_t)t * 12 + (i)] = wall_clock64(); } while (0)
 #else

@@ -10,7 +10,7 @@ struct TensorDesc { float* p; float* g; float* m; float* v; float* vmax; int n; 
 // writes them directly, so the weights are re-packed (bf16) in the same pass that updates them.
 // Rows: only source rows [r0, r0 + nr) are written, to destination row (r - r0) (dst is pre-offset) — the GRU's
 // 3-block weights land in the 4-block packed layout this way.
-// mode 1 (gate interleave, rec_step.hpp): r = gate * nr + u goes to destination row (u / 8) * 32 + gate * 8 + u % 8.
+// (mode: reserved, 0)
 struct PackDst { void* dst; int ld; int c0; int nc; int r0; int nr; int mode; int pad; };
 struct PackDesc { int ndst; int cols; PackDst d[6]; };
 #define RN_CHUNK 8192

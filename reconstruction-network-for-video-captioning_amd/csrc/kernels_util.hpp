@@ -227,16 +227,6 @@ __global__ __launch_bounds__(256) void transpose_at_kernel(const AT* __restrict_
     if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][i];
   }
 }
-// gate-interleaved image of a [4 Hd][cols] recurrent weight (rec_step.hpp): destination row (u/8)*32 + gate*8 + u%8
-template <typename DT>
-__global__ void pack_interleave_kernel(DT* __restrict__ dst, int ld_dst, int Hd, const float* __restrict__ src, int ld_src, int cols) {
-  const size_t total = (size_t)4 * Hd * ld_dst;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int d = (int)(i / ld_dst), c = (int)(i % ld_dst);
-    const int j = d >> 5, gate = (d >> 3) & 3, ul = d & 7;
-    dst[i] = (DT)(c < cols ? src[(size_t)(gate * Hd + j * 8 + ul) * ld_src + c] : 0.f);
-  }
-}
 // dst[r][c] = sum_j src[r*ld_src + j*cols + c]  (sum of NCH side-by-side partial blocks), zero padded to ld_dst
 template <typename AT>
 __global__ void sum_chunks_kernel(AT* __restrict__ dst, int ld_dst, const AT* __restrict__ src, int ld_src, int rows,

@@ -248,14 +248,6 @@ def test_free_running_pass_is_differentiable(kind, cells):
             assert rel_err(p.grad.cpu().numpy(), st.rec[k].grad.numpy()) <= tol["grad"], k
 
 
-@pytest.mark.parametrize("name", ["global_train", "global_eval", "full_global_B8"])
-def test_fused_reconstructor_step_opt_in(name, monkeypatch):
-    """RN_FUSED_REC=1 routes the global reconstructor's forward chain through csrc/rec_step.hpp (one kernel per step:
-    h . W_hh^T over the full K per workgroup + LSTM pointwise in the epilogue); same bars as the default path."""
-    monkeypatch.setenv("RN_FUSED_REC", "1")
-    test_autograd_api_losses_and_grads(name, "bf16")
-
-
 # shapes that leave the fast paths of the kernels (F > 32 as in BASELINE config C4, attention sizes > 128 / > 256,
 # H > 512 so a caption spans several cell workgroups) and the degenerate ends (one caption, one frame, one step)
 EDGE = {

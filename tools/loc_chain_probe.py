@@ -17,8 +17,9 @@ import recnet_amd as R  # noqa: E402
 from recnet_amd.synthetic import synthetic_features, synthetic_targets  # noqa: E402
 
 B, F, D = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (100, 28, 1536)
+KIND = sys.argv[4] if len(sys.argv) > 4 else "local"
 V = 4188
-Cc = R.make_config(batch_size=B, use_recon=True, reconstructor_type="local", encoder_output_len=F, encoder_output_size=D,
+Cc = R.make_config(batch_size=B, use_recon=True, reconstructor_type=KIND, encoder_output_len=F, encoder_output_size=D,
                    reconstructor_hidden_size=D, precision="bf16", device="cuda")
 torch.manual_seed(0)
 dec, rec = R.build_decoder(V, Cc), R.build_reconstructor(Cc)
@@ -30,10 +31,23 @@ for _ in range(3):
     step.fwd_bwd(enc, tg.cuda(), T, w, seed=1)
 torch.cuda.synchronize()
 eng = step.engine
-n = 7 * 64 * 8
+n = 8 * 64 * 8
 buf = (C.c_uint64 * n)()
 R._lib.check(eng.lib.recnet_probe_read(eng.handle, buf, n), "recnet_probe_read")
-ts = np.frombuffer(buf, dtype=np.uint64).reshape(7, 64, 8).astype(np.float64) / 100.0   # 100 MHz -> us
+raw = np.frombuffer(buf, dtype=np.uint64).astype(np.float64) / 100.0                      # 100 MHz -> us
+ts = raw[:7 * 64 * 8].reshape(7, 64, 8)
+# decoder forward chain (dec_chain.hpp DC_TS, workgroup 0 = phase-A owner of 16 columns AND caption 0): [t][12]
+dts = raw[4096:4096 + T * 12].reshape(T, 12)
+dn = [(0, "step start (phase A)"), (1, "A: panel . W + reduction"), (4, "hand-over: own words stamped"), (8, "scores"), (9, "context"),
+      (5, "cell"), (6, "publish + ack (arrive)"), (7, "barrier passed")]
+print("dec fwd    period %.2f us" % np.median(np.diff(dts[3:T - 2, 0])))
+prev = 0
+for i, nm in dn[1:]:
+    print("    %-30s +%.2f" % (nm, np.median(dts[3:T - 2, i] - dts[3:T - 2, prev])))
+    prev = i
+print("    %-30s +%.2f" % ("(to the next step start)", np.median(dts[4:T - 1, 0] - dts[3:T - 2, 7])))
+if KIND != "local":
+    sys.exit(0)
 names = {0: ("fwd U", ["x arrived", "x GEMM + red", "cell", "stores issued", "ack + arrive", "hr released", "hh GEMM"]),
          1: ("fwd C", ["Pw released", "Whr summed", "beta + x", "ack + arrive"]),
          2: ("fwd relay", ["U all arrived", "C all arrived"]),
