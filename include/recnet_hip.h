@@ -290,6 +290,9 @@ int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, i
 /* Probe builds only (csrc: make PROBE=1): in-kernel wall-clock stamps of the local chain kernels' last launch,
  * [role][step][8] uint64 ticks; RECNET_ESTATE in the product build. */
 int recnet_probe_read(recnet_handle* h, uint64_t* out, int32_t n);
+/* Test hook: fills the LDS of every CU with NaN patterns, so that a kernel reading LDS it never wrote fails the parity
+ * tests deterministically. */
+int recnet_debug_poison_lds(recnet_handle* h, void* stream);
 /* Dimensions a handle was created with (the torch.ops layer sizes its outputs from these). */
 #define RECNET_DIM_B 0
 #define RECNET_DIM_F 1

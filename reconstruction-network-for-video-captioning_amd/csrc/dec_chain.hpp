@@ -55,10 +55,10 @@ template <bool XF>
 __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   __shared__ float red[4 * RC_PAN_ROWS * DC_RED_LD];                 // phase A: 4 K-partials of the [112 x 16] tile
   __shared__ __attribute__((aligned(16))) float spre[4 * 512];       // phase B: gate pre-activations
-  __shared__ float swh[128], sa[32 + DC_XF];
-  extern __shared__ __attribute__((aligned(16))) float dc_dyn[];     // XF: [DC_XF][4H] bf16 P rows, then [DC_XF][128] fp32 Uv rows
-  bf16_t* plx = reinterpret_cast<bf16_t*>(dc_dyn);
-  float* suvx = dc_dyn + DC_XF * 4 * 512 / 2;
+  __shared__ float swh[128];
+  __shared__ __attribute__((aligned(16))) float sa[32 + DC_XF];
+  extern __shared__ __attribute__((aligned(16))) float dc_dyn[];     // XF: P fragments of frames 32..47 (64 KB), then [DC_XF][128] fp32 Uv rows
+  float* suvx = dc_dyn + 4 * 32 * 64 * 2;
   __shared__ __attribute__((aligned(16))) bf16_t hl[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, B = p.B, W4 = 4 * H, N = 4 * H + A;
@@ -90,40 +90,49 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   const int u = lane * 8;
   const bool live = isB && u < H;
   const int col = g * H + u;
-  Raw8<bf16_t> pv[32];
-  float uvr[8][2], wk[2], bk[2], cpre[2] = {0.f, 0.f}, hs_sum[2] = {0.f, 0.f};
+  // The caption's P block as MFMA B fragments: for column group cg (16 columns of this wave's gate block) lane l holds
+  // P[b][8 (l >> 4) .. + 7][g H + 16 cg + (l & 15)] — the context (1/F) sum_f a_f P[b,f,:] is then one 16x16x32 MFMA per column
+  // group against an A operand whose rows 0 / 1 are the attention weights split into a bf16 high and low part (31 VALU
+  // multiply-adds per column pair before).  Frames 32 .. 47 (XF): 16x16x16 fragments in LDS, each lane its own 8 bytes.
+  bf16x8 pb[32];
+  typedef short dc_s4 __attribute__((ext_vector_type(4)));
+  bf16x4* plf = reinterpret_cast<bf16x4*>(dc_dyn);                     // XF: [4 waves][32 cg][64 lanes] x 8 bytes
+  // scores: thread = (frame tid % 32, attention columns [16 ko, 16 ko + 16), ko = tid / 32): 16 independent tanh per thread,
+  // the eight partial sums of a frame are added through LDS — no wavefront reductions
+  __shared__ float swab[256], sps[8 * 32 + 16 * DC_XF];
+  const int sf = tid & 31, ko = tid >> 5;
+  float uvq[16], cpre[2] = {0.f, 0.f}, hs_sum[2] = {0.f, 0.f};
   {
-    const bf16_t* pp = p.P + (size_t)b * F * p.ldp + (live ? col : 0);
 #pragma unroll
-    for (int f = 0; f < 32; ++f) { if (live && f < F) pv[f].load(pp + (size_t)f * p.ldp); else pv[f].zero(); }
+    for (int cg = 0; cg < 32; ++cg) {
+      const int hc = cg * 16 + (lane & 15);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int f = g + 4 * i;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int k = lane + 64 * j;
-        uvr[i][j] = (isB && f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const int f = (lane >> 4) * 8 + j;
+        pb[cg][j] = (isB && hc < H && f < F) ? p.P[((size_t)b * F + f) * p.ldp + g * H + hc] : (bf16_t)0.f;
       }
-    }
-    if (XF) {     // every lane stores what it alone reads back: no barrier needed
-      for (int f = 32; f < 32 + DC_XF; ++f) {
-        Raw8<bf16_t> r; if (live && f < F) r.load(pp + (size_t)f * p.ldp); else r.zero();
-        if (u < 512) *reinterpret_cast<bf16x8*>(plx + (size_t)(f - 32) * 2048 + g * 512 + u) = r.v;
-      }
-      for (int i = 8; i < 8 + DC_XF / 4; ++i) {
-        const int f = g + 4 * i;
+      if (XF) {
+        bf16x4 r;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int k = lane + 64 * j;
-          if (k < 128) suvx[(f - 32) * 128 + k] = (isB && f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const int f = 32 + (lane >> 4) * 4 + j;
+          r[j] = (isB && hc < H && f < F) ? p.P[((size_t)b * F + f) * p.ldp + g * H + hc] : (bf16_t)0.f;
         }
+        plf[(g * 32 + cg) * 64 + lane] = r;
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = lane + 64 * j;
-      wk[j] = k < A ? p.w[k] : 0.f; bk[j] = k < A ? p.ab[k] : 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const int k = 16 * ko + i;
+      uvq[i] = (isB && sf < F && k < A) ? p.Uv[((size_t)b * F + sf) * A + k] : 0.f;
     }
+    if (XF) {
+      for (int idx = tid; idx < DC_XF * 128; idx += 256) {
+        const int f = 32 + (idx >> 7), k = idx & 127;
+        suvx[idx] = (isB && f < F && k < A) ? p.Uv[((size_t)b * F + f) * A + k] : 0.f;
+      }
+    }
+    if (tid < 128) { swab[2 * tid] = tid < A ? p.w[tid] : 0.f; swab[2 * tid + 1] = tid < A ? p.ab[tid] : 0.f; }
   }
   const int lane_off = ((lane >> 4) * RC_PAN_ROWS + (lane & 15)) * 8;
   unsigned ph = 0;
@@ -241,61 +250,101 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
         pre[0] += g0[0]; pre[1] += g0[1]; pre[2] += g0[2]; pre[3] += g0[3];
         pre[4] += g1[0]; pre[5] += g1[1]; pre[6] += g1[2]; pre[7] += g1[3];
       }
-      if (tid < A) { swh[tid] = whv; p.Wh[((size_t)t * B + b) * A + tid] = whv; }
+      // all 128 entries: the score threads read swh[k] for every k of their column range (w_k = 0 beyond A, but 0 x garbage
+      // from uninitialised LDS could be NaN)
+      if (tid < 128) swh[tid] = tid < A ? whv : 0.f;
+      if (tid < A) p.Wh[((size_t)t * B + b) * A + tid] = whv;
       __syncthreads();
       DC_TS(4);
       {
-        float hk[2];
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int k = lane + 64 * j; hk[j] = k < A ? swh[k] : 0.f; }
+        for (int i = 0; i < 16; i += 2) {
+          const int k = 16 * ko + i;
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(swab + 2 * k);          // (w_k, b_k, w_k+1, b_k+1)
+          s0 += wa[0] * rn_tanh(swh[k] + wa[1] + uvq[i]);
+          s1 += wa[2] * rn_tanh(swh[k + 1] + wa[3] + uvq[i + 1]);
+        }
+        sps[ko * 32 + sf] = s0 + s1;
+        if (XF) {      // frames 32 .. 47: thread = (frame 32 + tid % 16, columns [8 kp, 8 kp + 8), kp = tid / 16)
+          const int f2 = tid & 15, kp = tid >> 4;
+          float e0 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int f = g + 4 * i;
-          if (f < F) {
-            float s = wk[0] * rn_tanh(hk[0] + uvr[i][0] + bk[0]);
-            if (A > 64) s += wk[1] * rn_tanh(hk[1] + uvr[i][1] + bk[1]);
-            s = wave_sum(s);
-            if (lane == 0) { sa[f] = s; if (!p.softmax) p.att[((size_t)t * B + b) * F + f] = s; }
+          for (int i = 0; i < 8; ++i) {
+            const int k = 8 * kp + i;
+            e0 += swab[2 * k] * rn_tanh(swh[k] + swab[2 * k + 1] + suvx[f2 * 128 + k]);
           }
+          sps[256 + kp * 16 + f2] = e0;
         }
-        if (XF) {
-          for (int i = 8; i < 8 + DC_XF / 4; ++i) {
-            const int f = g + 4 * i;
-            if (f < F) {
-              float s = wk[0] * rn_tanh(hk[0] + suvx[(f - 32) * 128 + lane] + bk[0]);
-              if (A > 64) s += wk[1] * rn_tanh(hk[1] + suvx[(f - 32) * 128 + lane + 64] + bk[1]);
-              s = wave_sum(s);
-              if (lane == 0) { sa[f] = s; if (!p.softmax) p.att[((size_t)t * B + b) * F + f] = s; }
-            }
-          }
-        }
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const float sc = ((sps[tid] + sps[32 + tid]) + (sps[64 + tid] + sps[96 + tid])) + ((sps[128 + tid] + sps[160 + tid]) + (sps[192 + tid] + sps[224 + tid]));
+        sa[tid] = tid < F ? sc : 0.f;
+        if (tid < F && !p.softmax) p.att[((size_t)t * B + b) * F + tid] = sc;
+      } else if (XF && tid < 32 + DC_XF) {
+        const int f2 = tid - 32;
+        float sc = 0.f;
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) sc += sps[256 + kp * 16 + f2];
+        sa[tid] = tid < F ? sc : 0.f;
+        if (tid < F && !p.softmax) p.att[((size_t)t * B + b) * F + tid] = sc;
       }
       __syncthreads();
       if (p.softmax) { attn_softmax_lds(sa, F, p.att + ((size_t)t * B + b) * F); __syncthreads(); }
       DC_TS(8);
-      if (live) {
-        float c[8];
+      {
+        // context of this wave's gate block: ctx[n] = sum_f a_f P[b, f, n] as MFMAs.  Rows 4i / 4i + 1 of the A operand are the
+        // attention weights split into a bf16 high / low part (the other rows zero), so EVERY 16-lane group of the result holds
+        // ctx of the 16 columns in d[0] + d[1]; four column groups per round, lane group q keeps group 4 r + q, and one
+        // full-wave LDS store writes 64 consecutive columns (all 32 groups are computed: fragments beyond H are zero)
+        bf16x8 av;
+        const int q = lane >> 4, m4 = lane & 3;
+        // branch-free: hm * hi + lm * (a - hi) is exactly hi (rows 4i), the low part (rows 4i + 1) or zero
+        const float hm = m4 == 0 ? 1.f : 0.f, lm = m4 == 1 ? 1.f : 0.f;
+        {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + 8 * q), a1 = *reinterpret_cast<const f32x4*>(sa + 8 * q + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = 0.f;
-#pragma unroll
-        for (int f = 0; f < 32; ++f)
-          if (f < F) {
-            const float a = sa[f];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) c[j] += a * pv[f].at(j);
-          }
-        if (XF) {
-          for (int f = 32; f < F; ++f) {
-            const float a = sa[f];
-            const bf16x8 r = *reinterpret_cast<const bf16x8*>(plx + (size_t)(f - 32) * 2048 + g * 512 + u);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) c[j] += a * (float)r[j];
+          for (int j = 0; j < 8; ++j) {
+            const float a = j < 4 ? a0[j] : a1[j - 4];
+            const float hif = (float)(bf16_t)a;
+            av[j] = (bf16_t)(hm * hif + lm * (a - hif));
           }
         }
+        bf16x4 ax = {0, 0, 0, 0};
+        if (XF) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + 32 + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float hif = (float)(bf16_t)a0[j];
+            ax[j] = (bf16_t)(hm * hif + lm * (a0[j] - hif));
+          }
+        }
+        const float k0 = q == 0 ? 1.f : 0.f, k1 = q == 1 ? 1.f : 0.f, k2 = q == 2 ? 1.f : 0.f, k3 = q == 3 ? 1.f : 0.f;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[4 * r], z4, 0, 0, 0);
+          f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[4 * r + 1], z4, 0, 0, 0);
+          f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[4 * r + 2], z4, 0, 0, 0);
+          f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[4 * r + 3], z4, 0, 0, 0);
+          if (XF) {
+            const dc_s4 axs = __builtin_bit_cast(dc_s4, ax);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(axs, __builtin_bit_cast(dc_s4, plf[(g * 32 + 4 * r) * 64 + lane]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(axs, __builtin_bit_cast(dc_s4, plf[(g * 32 + 4 * r + 1) * 64 + lane]), d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(axs, __builtin_bit_cast(dc_s4, plf[(g * 32 + 4 * r + 2) * 64 + lane]), d2, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(axs, __builtin_bit_cast(dc_s4, plf[(g * 32 + 4 * r + 3) * 64 + lane]), d3, 0, 0, 0);
+          }
+          const float c0 = d0[0] + d0[1], c1 = d1[0] + d1[1], c2 = d2[0] + d2[1], c3 = d3[0] + d3[1];
+          spre[g * 512 + r * 64 + lane] = (k0 * c0 + k1 * c1) + (k2 * c2 + k3 * c3);
+        }
+      }
+      if (live) {        // (the wave reads back what it wrote itself: LDS accesses of a wave are in order)
         const float invF = 1.0f / (float)F;
         float* dst = spre + g * 512 + lane * 8;
-        *reinterpret_cast<f32x4*>(dst) = f32x4{pre[0] + c[0] * invF, pre[1] + c[1] * invF, pre[2] + c[2] * invF, pre[3] + c[3] * invF};
-        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{pre[4] + c[4] * invF, pre[5] + c[5] * invF, pre[6] + c[6] * invF, pre[7] + c[7] * invF};
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(dst), c1 = *reinterpret_cast<const f32x4*>(dst + 4);
+        *reinterpret_cast<f32x4*>(dst) = f32x4{pre[0] + c0[0] * invF, pre[1] + c0[1] * invF, pre[2] + c0[2] * invF, pre[3] + c0[3] * invF};
+        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{pre[4] + c1[0] * invF, pre[5] + c1[1] * invF, pre[6] + c1[2] * invF, pre[7] + c1[3] * invF};
       }
       __syncthreads();
       DC_TS(9);

@@ -258,6 +258,10 @@ class Engine:
                    "recnet_reconstructor_step")
         return out, hr, cr
 
+    def poison_lds(self):
+        """Test hook: NaN patterns into the LDS of every CU (uninitialised-LDS reads then show up in the parity tests)."""
+        _lib.check(self.lib.recnet_debug_poison_lds(self.handle, _stream()), "recnet_debug_poison_lds")
+
     def chain_status(self):
         """Bit mask of persistent chain kernels that gave up a bounded wait (0 = healthy).  Synchronises the stream."""
         s = C.c_int32(0)

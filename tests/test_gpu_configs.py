@@ -77,6 +77,7 @@ def test_full_size_step_matches_oracle_elementwise(case, prec):
     _, dec, rec = make_models([B, F, D, V, E, H, A, RA], kind, prec, decP, recP)
     step = R.TrainStep(dec, rec, batch_size=B, n_frames=F, global_batch=Bg, batch_offset=off)
     T, w = step.prepare(tg_g.numpy())
+    step.engine.poison_lds()
     step.fwd_bwd(enc.cuda(), tg.cuda(), T, w, seed=5)
     step.engine.add_reg_grad(0, 1.0)
     step.engine.add_reg_grad(1, 1.0)

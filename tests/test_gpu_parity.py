@@ -297,6 +297,7 @@ def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
     step = R.TrainStep(dec, rec)
     T, w = step.prepare(targets.numpy())
     assert T == max(lens) + 1
+    step.engine.poison_lds()       # NaN in every CU's LDS: a kernel reading LDS it never wrote cannot pass by luck
     step.fwd_bwd(enc.cuda(), targets.cuda(), T, w, seed=6)
     step.engine.add_reg_grad(0, 1.0)
     step.engine.add_reg_grad(1, 1.0)

@@ -42,6 +42,7 @@ def test_softmax_attention_matches_oracle(case, kind, prec, softmax_oracle):
     C, dec, rec = make_models(dims, kind, prec, decP, recP, attn_normalize="softmax")
     step = R.TrainStep(dec, rec)
     T, w = step.prepare(targets.numpy())
+    step.engine.poison_lds()
     step.fwd_bwd(enc.cuda(), targets.cuda(), T, w, seed=6)
     step.engine.add_reg_grad(0, 1.0)
     if rec:

@@ -31,7 +31,7 @@ for _ in range(3):
     step.fwd_bwd(enc, tg.cuda(), T, w, seed=1)
 torch.cuda.synchronize()
 eng = step.engine
-n = 8 * 64 * 8
+n = 2 * 8 * 64 * 8
 buf = (C.c_uint64 * n)()
 R._lib.check(eng.lib.recnet_probe_read(eng.handle, buf, n), "recnet_probe_read")
 raw = np.frombuffer(buf, dtype=np.uint64).astype(np.float64) / 100.0                      # 100 MHz -> us
