@@ -436,8 +436,14 @@ struct DecChainBwdArgs {
   float* dUv; bf16_t* dUv_lp; int ld_dUv;                   // [B][F][A], [B F][ld_dUv]
   float* dwacc;                    // [RN_FCH][B][A]
   unsigned* bar;
+  unsigned long long* ts;          // probe builds only: [T][12] stamps of workgroup 0
 };
 
+#ifdef DC_PROBE_TS
+#define DCB_TS(i) do { if (wg == DC_PROBE_WG && tid == 0) p.ts[(size_t)s * 12 + (i)] = wall_clock64(); } while (0)
+#else
+#define DCB_TS(i) do { } while (0)
+#endif
 #define DCB_STEPS 17          // k32-steps per wave: 4 x 17 x 32 = 2176 >= 4H + A
 #define DCB_RB 2              // 32 rows per workgroup in phase A', 4 row parts
 #define DCB_PARTS 4
@@ -551,6 +557,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
     const int t = p.T - 1 - s;
     if (s > 0) {
       // ================= phase A': G2[s][rows, 16 units] = rows_{s-1} . W
+      DCB_TS(0);
       if (isA) {
         const bf16_t* Ap = p.Pan + (size_t)(s - 1) * pan_t + lane_off;
         bf16x8 fa[DCB_STEPS][DCB_RB];
@@ -608,6 +615,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
     // ================= phase B': caption b
     if (isB) {
       // (1) cell backward of the thread's two units -> dgates (bf16) into the row buffer
+      DCB_TS(1);
       float grec[2] = {0.f, 0.f};
       if (s > 0 && p.ll) {
         const uint64_t* L = reinterpret_cast<const uint64_t*>(p.G2) + ((size_t)s * B + b) * H;
@@ -640,6 +648,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       }
       __syncthreads();
       // (2) da[f] = (1/F) sum_n P[b,f,n] dgates[n]: MFMA, this wave's gate block, dgates replicated over the 16 columns
+      DCB_TS(2);
       {
         constexpr int NFB = XF ? 3 : 2, SPF = 32 + (XF ? DC_XF : 0);
         f32x4 acc[NFB];
@@ -673,6 +682,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       __syncthreads();
       if (p.softmax) { attn_softmax_bwd_lds(sda, p.att + ((size_t)t * B + b) * F, F); __syncthreads(); }
       // (3) attention backward on the (f, k) plane
+      DCB_TS(3);
       float dwh = 0.f;
       if (fk_on) {
         const float wh = whk + abk;
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       }
       __syncthreads();
       // (4) publish the row [dgates | dWh]: 16 bytes per k-group, written through
+      DCB_TS(4);
       const bool more = s + 1 < p.T;
       for (int kg = tid; kg < (KA >> 3); kg += 256) {
         const uint64_t* src = reinterpret_cast<const uint64_t*>(srow + kg * 8);
@@ -721,11 +732,13 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; rc_arrive(p.bar, fb + ph); }
+      DCB_TS(5);
       // ---- off the critical path: the row-major copy [dgates | dWh | 0 ..] for the deferred GEMMs
       bf16_t* Gt = p.dGx + ((size_t)t * B + b) * p.ld_dgx;
       for (int kg = tid; kg < (p.ld_dgx >> 3); kg += 256)
         *reinterpret_cast<bf16x8*>(Gt + kg * 8) = kg < (KA >> 3) ? *reinterpret_cast<const bf16x8*>(srow + kg * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       if (more) { prefetch(t - 1); { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); } }
+      DCB_TS(6);
     } else if (s + 1 < p.T) {
       __syncthreads();
       ++ph;

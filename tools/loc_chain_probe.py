@@ -46,6 +46,14 @@ for i, nm in dn[1:]:
     print("    %-30s +%.2f" % (nm, np.median(dts[3:T - 2, i] - dts[3:T - 2, prev])))
     prev = i
 print("    %-30s +%.2f" % ("(to the next step start)", np.median(dts[4:T - 1, 0] - dts[3:T - 2, 7])))
+bts = raw[4096 + 512:4096 + 512 + T * 12].reshape(T, 12)
+bn = [(0, "step start (phase A')"), (1, "A': rows . W + reduction, words stamped"), (2, "hand-over + cell backward"), (3, "da = P . dgates (MFMA)"),
+      (4, "attention backward (f, k) plane"), (5, "publish + ack (arrive)"), (6, "barrier passed")]
+print("dec bwd    period %.2f us" % np.median(np.diff(bts[3:T - 2, 0])))
+prev = 0
+for i, nm in bn[1:]:
+    print("    %-40s +%.2f" % (nm, np.median(bts[3:T - 2, i] - bts[3:T - 2, prev])))
+    prev = i
 if KIND != "local":
     sys.exit(0)
 names = {0: ("fwd U", ["x arrived", "x GEMM + red", "cell", "stores issued", "ack + arrive", "hr released", "hh GEMM"]),
