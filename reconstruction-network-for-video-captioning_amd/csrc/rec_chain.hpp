@@ -403,12 +403,16 @@ struct RecChainBwdArgs {
   unsigned* bar; unsigned* epoch; int master; float* poison;
 };
 
-template <int STEPS, int PF, int RB, int CG>
+// KL > 0: the fragments of the last KL k-steps of every wave live in LDS instead of registers (wl, 16 bytes per thread and
+// fragment, conflict-free) - what lets a workgroup own 32 units over 32 rows (CG 2, RB 2, four row parts): the gate-gradient
+// panel a workgroup reads every step, ROWS x 4R x 2 bytes through its CU's 64 B/clk L1 fill path, is halved.
+template <int STEPS, int PF, int RB, int CG, int KL = 0>
 __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArgs p) {
-  constexpr int UW = 16 * CG, ROWS = RB * 16, RED_LD = UW + 1, KG = UW / 8, NP = STEPS / 2;
+  constexpr int UW = 16 * CG, ROWS = RB * 16, RED_LD = UW + 1, KG = UW / 8, NP = STEPS / 2, KREG = STEPS - KL;
   extern __shared__ __attribute__((aligned(16))) float rc_smem[];
   float* red = rc_smem;                                                   // [4 waves][ROWS][RED_LD]
   bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD + (4 - (4 * ROWS * RED_LD) % 4) % 4);   // [ROWS][4][UW]
+  bf16x8* wl = reinterpret_cast<bf16x8*>(hl + (size_t)ROWS * 4 * UW);     // [KL][CG][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
   const int u0 = blockIdx.x * UW, R = p.R, B = p.B, K = 4 * R;
   const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   const int rot = blockIdx.x % NP;
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
-  bf16x8 wb[STEPS][CG];
+  bf16x8 wb[KREG > 0 ? KREG : 1][CG];
 #pragma unroll
   for (int g = 0; g < CG; ++g) {
     const bf16_t* wrow = p.Wt + (size_t)(u0 + g * 16 + (lane & 15)) * p.ldwt + kq;
@@ -432,8 +436,9 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
     for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const int k = k_of(pr, hh);
-        wb[pr * 2 + hh][g] = (k + kq < K) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        const int k = k_of(pr, hh), ks = pr * 2 + hh;
+        const bf16x8 w = (k + kq < K) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (ks < KREG) wb[ks][g] = w; else wl[((ks - KREG) * CG + g) * 256 + tid] = w;
       }
   }
   constexpr int CPT = (ROWS * UW + 255) / 256;
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   const size_t pan_t = rc_pan_elems(K);
 
   // what this thread publishes every step: items (gate, k-group, owned row) of 16 bytes
-  constexpr int IPT = (4 * KG * RC_PAN_ROWS + 255) / 256;            // upper bound: own <= 112
+  constexpr int IPT = (4 * KG * (KL ? ROWS : RC_PAN_ROWS) + 255) / 256;   // upper bound: own <= 112 (KL: own <= ROWS)
   const bf16_t* it_src[IPT]; int it_rg[IPT], it_col[IPT]; bool it_on[IPT];
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
@@ -509,7 +514,8 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
           for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int g = 0; g < CG; ++g)
-              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], wb[ks][g], acc[i][g], 0, 0, 0);
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], ks < KREG ? wb[ks < KREG ? ks : 0][g] : wl[((ks - KREG) * CG + g) * 256 + tid],
+                                                                  acc[i][g], 0, 0, 0);
         }
         if (pr + PF < NP) {
           __builtin_amdgcn_sched_barrier(0);
@@ -579,6 +585,6 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   rc_epoch_bump(p.epoch, ep);
   rc_poison(p.bar, p.poison);
 }
-template <int RB, int CG> constexpr size_t rc_bwd_smem_bytes() {
-  return ((size_t)4 * RB * 16 * (16 * CG + 1) + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * CG * 2;
+template <int RB, int CG, int KL = 0> constexpr size_t rc_bwd_smem_bytes() {
+  return ((size_t)4 * RB * 16 * (16 * CG + 1) + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * CG * 2 + (size_t)KL * CG * 256 * 16;
 }
