@@ -81,6 +81,7 @@ struct recnet_handle {
   void *lc_panh = nullptr, *lc_panx = nullptr; _Float16* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
   void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
   int lcb_msx = 1, lcb_rbu = 4, lc_bwd_done = 0;
+  int lcb_xs = 0;           // X' of the backward chain with K split over workgroups: k-steps per wave (0: whole K per workgroup)
   int deferred_early = 0, deferred_early_flags = -1, deferred_done = 0, join_recorded = 0;   // rec_deferred_fork (host_reconstructor.inc)
   float mse_scale = 0.f; int mse_nb = 0;   // pending MSE partials: fwd_rec finalises the loss scalars in one launch
   float dout_scale = 0.f; int dout_ready = 0;   // dout_lp already holds dout_scale * d loss / d out (written by the MSE kernel)
@@ -233,7 +234,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->lc_pw = (_Float16*)take(F * B * ((R + 15) / 16) * RA / 2 + 64);
     h->lc_pang = takev(F * rc_pan_elems((int)(4 * R)) / 2 + 64);
     h->lc_panw = takev(F * rc_pan_elems((int)RA) / 2 + 64);
-    h->lc_dx = take(F * B * H);
+    h->lc_dx = take(F * 4 * B * H);     // up to 4 K parts (lcb_xsplit_role)
     h->WihhT = takev((H + R) * (size_t)h->ld4R);
   }
   // optimiser tables (sizes are upper bounds; filled at bind time)
@@ -324,7 +325,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     // ... and its backward chain: U' all rows (RB 7) + X' two row parts above 64 captions, one part of 64 rows below
     const char* eb = getenv("RN_PERSIST_LOC_BWD");
     h->lcb_msx = h->B > 64 ? 2 : 1; h->lcb_rbu = h->B > 64 ? 7 : (h->B > 32 ? 4 : 2);
-    const int nwb = h->lc_ng + (h->H / 16) * h->lcb_msx + h->lc_nc + 1;
+    int nwb = h->lc_ng + (h->H / 16) * h->lcb_msx + h->lc_nc + 1;
+    {   // X' with K split in parts of 2048 (64 columns x 32 rows x one part per workgroup) when those workgroups fit as well
+      const char* ex = getenv("RN_LOC_XSPLIT");
+      const int ksx = (4 * h->R + 2047) / 2048, nwx = h->lc_ng + ((h->H + 63) / 64) * ((h->B + 31) / 32) * ksx + h->lc_nc + 1;
+      const int fx = ex ? atoi(ex) : 1;
+      if (fx && ksx <= 4 && (h->R >= 512 || fx == 2) && nwx <= h->ncu && nwx - 1 <= 256) { h->lcb_xs = 16; nwb = nwx; }
+    }
     h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && (h->H & 15) == 0 && !(h->B > 64 && h->R > 1536) &&
                          nwb <= h->ncu && nwb - 1 <= 256;
   }

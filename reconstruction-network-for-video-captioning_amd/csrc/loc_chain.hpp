@@ -478,6 +478,7 @@ template <int RB> constexpr size_t lc_smem_bytes() {
 struct LocChainBwdArgs {
   int F, T, B, R, H, A, gru;
   int NGU, MSU, NGX, MSX, NC;        // U' = NGU unit groups x MSU row parts, X' = NGX column groups x MSX row parts, C'
+  int KSX;                           // X' parts of the contraction (1: the whole of K = 4R per workgroup; > 1: lcb_xsplit_role)
   const bf16_t* WT; int ldwt;        // [H + R][ldwt]: rows [0,H) = W_ih^T (x columns), rows [H, H+R) = W_hh^T; K = 4R contiguous
   const bf16_t* Wr; int ldwr;        // [A][ldwr]
   const float* dHr;                  // [F][B][R] d loss / d hr_s through the output layer
@@ -490,7 +491,7 @@ struct LocChainBwdArgs {
   float* dUd; bf16_t* dUd_lp; int ld_dUd;   // [T][B][A] (+ operand copy, zero padded)
   float* dwacc;                      // [nch][B][A]: chunk 0 = sum_t dbeta tanh(.), other chunks zero
   int nch;
-  bf16_t* PanG; bf16_t* PanW; float* Dx;    // exchange: [F][rc_pan_elems(4R)], [F][rc_pan_elems(A)], [F][B][H]
+  bf16_t* PanG; bf16_t* PanW; float* Dx;    // exchange: [F][rc_pan_elems(4R)], [F][rc_pan_elems(A)], [F][KSX][B][H]
   unsigned* bar; unsigned* epoch; float* poison;
   DropDesc dd;
   int defer_big;                     // 1: U' starts its recurrent product after X' has finished with the same panel (L2 bandwidth)
@@ -543,13 +544,115 @@ __device__ __forceinline__ void lcb_load_weights(bf16x8 (&wb)[STEPS], const bf16
     }
 }
 
-template <int STEPS, int PF, int RBU, int RBX>
+// X' with the contraction split over workgroups (XS k-steps of 32 per wave, XS * 128 of K per workgroup): a workgroup owns
+// 64 columns of dx x 32 rows x one K part, its 64 x XS * 128 weights in registers, and reads 32 rows x XS * 128 of the
+// gate-gradient panel per step instead of 64 rows x 4R - the panel goes through the CU's 64 B/clk L1 fill path, which is
+// what bounds the whole-K form.  The KSX partial dx (each masked: the dropout mask is a per-element factor) are summed by
+// the caption workgroups when they read them.
+template <int XS, int PF>
+__device__ __forceinline__ void lcb_xsplit_role(const LocChainBwdArgs& p, float* red, int xi, int wg, unsigned fb, const unsigned* relG) {
+  constexpr int CG = 4, RB = 2, UWX = 16 * CG, ROWS = RB * 16, RED_LD = UWX + 1, NP = XS / 2, OWN = ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R = p.R, B = p.B, H = p.H, F = p.F, K = 4 * R;
+  const int xg = xi % p.NGX, rest = xi / p.NGX, part = rest % p.MSX, kp = rest / p.MSX;
+  const int j0 = xg * UWX, own_lo = part * OWN;
+  const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
+  const int kq = (lane >> 4) * 8, kw0 = kp * (XS * 128) + wave * (XS * 32);
+  const int rot = xg % NP;
+  auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
+  bf16x8 wb[XS][CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const int jr = j0 + g * 16 + (lane & 15);
+    const bf16_t* wrow = p.WT + (size_t)(jr < H ? jr : 0) * p.ldwt + kq;
+    const int Kg = jr < H ? K : 0;
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = k_of(pr, hh);
+        wb[pr * 2 + hh][g] = (k + kq < Kg) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+  }
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + r0 + (lane & 15)) * 8;
+  const size_t pan_g = rc_pan_elems(K);
+  const uint32_t key = drop_key(p.dd);
+  for (int q = 0; q < F; ++q) {
+    const int s = F - 1 - q;
+    lc_wait(relG, fb + (unsigned)(q + 1), p.bar);
+    if (xi == 0) LC_TS(5, q, 0);
+    const bf16_t* A = p.PanG + (size_t)q * pan_g + lane_off;
+    bf16x8 fa[PF][2][RB];
+    auto issue_pair = [&](int slot, int pr) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int k = k_of(pr, hh);
+          fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(A + ((k < K ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+        }
+    };
+#pragma unroll
+    for (int pr = 0; pr < PF; ++pr)
+      if (pr < NP) issue_pair(pr, pr);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[RB][CG];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int g = 0; g < CG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+      const int slot = pr % PF;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int g = 0; g < CG; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], wb[pr * 2 + hh][g], acc[i][g], 0, 0, 0);
+      if (pr + PF < NP) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_pair(slot, pr + PF);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float* prt = red + wave * (ROWS * RED_LD);
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int g = 0; g < CG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + g * 16 + (lane & 15)] = acc[i][g][r];
+    __syncthreads();
+    if (xi == 0) LC_TS(5, q, 1);
+    float* Dq = p.Dx + ((size_t)q * p.KSX + kp) * B * H;
+    for (int idx = tid; idx < OWN * (UWX / 2); idx += 256) {
+      const int rg = own_lo + idx / (UWX / 2), pc = (idx % (UWX / 2)) * 2, rl = rg - r0;
+      if (rg < B && j0 + pc < H) {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { v0 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc]; v1 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc + 1]; }
+        union { float f[2]; uint64_t u; } pk;
+        pk.f[0] = v0 * drop_at(p.dd, key, s, rg, H, j0 + pc); pk.f[1] = v1 * drop_at(p.dd, key, s, rg, H, j0 + pc + 1);
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(Dq + (size_t)rg * H + j0 + pc), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lc_arrive(p.bar + wg, fb + (unsigned)(q + 1));
+    if (xi == 0) LC_TS(5, q, 2);
+  }
+  __syncthreads();
+  lc_arrive(p.bar + wg, fb + (unsigned)(F + 1));
+}
+
+template <int STEPS, int PF, int RBU, int RBX, int XS = 0>
 __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArgs p) {
   constexpr int UW = 16, RED_LD = UW + 1, KG = UW / 8;
   extern __shared__ __attribute__((aligned(16))) float lc_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x, R = p.R, B = p.B, H = p.H, A = p.A, F = p.F, T = p.T, K = 4 * R;
-  const int NU = p.NGU * p.MSU, NX = p.NGX * p.MSX;
+  const int NU = p.NGU * p.MSU, NX = p.NGX * p.MSX * p.KSX;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
   unsigned* relG = p.bar + 256; unsigned* relX = p.bar + 256 + 8; unsigned* relW = p.bar + 256 + 16;
   const size_t pan_g = rc_pan_elems(K), pan_w = rc_pan_elems(A);
@@ -612,10 +715,17 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       const float bt = (bok && tt < T) ? p.beta[((size_t)s * B + b) * T + tt] * invT : 0.f;
       lc_wait(relX, fb + (unsigned)(q + 1), p.bar);
       if (ci == 0) LC_TS(6, q, 0);
+      {   // the KSX <= 4 partial dx of the X' workgroups: every load in flight before the first add
+        float pv[4][4];
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int h = j + 128 * qq;
-        sdx[c * 512 + h] = (bok && h < H) ? p.Dx[((size_t)q * B + b) * H + h] : 0.f;
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+          for (int kp = 0; kp < 4; ++kp) {
+            const int h = j + 128 * qq;
+            pv[qq][kp] = (bok && h < H && kp < p.KSX) ? p.Dx[(((size_t)q * p.KSX + kp) * B + b) * H + h] : 0.f;
+          }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) sdx[c * 512 + j + 128 * qq] = (pv[qq][0] + pv[qq][1]) + (pv[qq][2] + pv[qq][3]);
       }
       __syncthreads();
       // dbeta[tt] = (1/T) dx . h_tt (this thread's quarter) and dHs[tt] += (beta_s[tt] / T) dx
@@ -689,6 +799,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 
   // ================================================================================== X': dx_s = mask * dG_s . W_ih
   if (wg >= NU) {
+    if constexpr (XS > 0) { lcb_xsplit_role<XS, 3>(p, lc_smem, wg - NU, wg, fb, relG); return; }
     constexpr int ROWS = RBX * 16;
     float* red = lc_smem;                                   // [4 waves][ROWS][RED_LD]
     const int xi = wg - NU, xg = xi % p.NGX, part = xi / p.NGX;
@@ -863,7 +974,8 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
   __syncthreads();
   lc_arrive(p.bar + wg, fb + (unsigned)(F + 1));
 }
-template <int RBU, int RBX> constexpr size_t lcb_smem_bytes() {
+template <int RBU, int RBX, int XS = 0> constexpr size_t lcb_smem_bytes() {
   constexpr int RB = RBU > RBX ? RBU : RBX;
-  return ((size_t)4 * RB * 16 * 17 + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * 2 + 1024;
+  constexpr size_t a = ((size_t)4 * RB * 16 * 17 + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * 2 + 1024, x = XS ? (size_t)4 * 32 * 65 * 4 : 0;
+  return a > x ? a : x;
 }

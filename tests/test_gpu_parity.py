@@ -280,13 +280,15 @@ EDGE = {
     "LOC_R32_B20_RA8_T31": ([20, 2, 32, 29, 8, 32, 16, 8], [30] + [(3 * i) % 6 for i in range(19)]),
     "LOC_R128_B65_F1": ([65, 1, 128, 29, 8, 32, 16, 12], [(5 * i) % 7 for i in range(65)]),
 }
+# K = 4R = 4096: two K parts in the backward chain's X' role (lcb_xsplit_role), second row part with two rows
+EDGE_KSPLIT = {"LOC_R1024_B34_two_k_parts": ([34, 2, 1024, 29, 8, 64, 16, 16], [(5 * i) % 6 for i in range(34)])}
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 @pytest.mark.parametrize("kind", ["global", "local"])
 @pytest.mark.parametrize("case", sorted(EDGE))
 def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
-    dims, lens = EDGE[case]
+    dims, lens = EDGE[case] if case in EDGE else EDGE_KSPLIT[case]
     B, F, D, V, E, H, A, RA = dims
     if H > 512 and kind == "local":
         pytest.skip("the H > 512 case exercises the decoder cell kernels; one reconstructor is enough")
@@ -315,6 +317,18 @@ def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
             if e > tol["grad"]:
                 bad.append((grp, k, e))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("case", [c for c in sorted(EDGE) if c.startswith("LOC_")] + sorted(EDGE_KSPLIT))
+def test_local_backward_chain_with_k_split_forced(case, monkeypatch):
+    """lcb_xsplit_role is selected from R = 512 up; forced here so the small ragged shapes run through it as well."""
+    monkeypatch.setenv("RN_LOC_XSPLIT", "2")
+    test_fused_step_vs_oracle_edge_shapes(case, "local", "bf16")
+
+
+def test_global_backward_chain_wide_tiling_equals_the_narrow_one(monkeypatch):
+    """rec_chain_bwd_kernel<48, 3, 2, 2, 16> (32 units x 32 rows, a third of the weights in LDS; B > 64, R in (1024, 1536])."""
+    _chain_variants({"RN_REC_BWD_WIDE": "0"}, "LSTM", monkeypatch, [100, 2, 1536, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(100)])
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
