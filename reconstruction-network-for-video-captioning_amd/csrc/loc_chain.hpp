@@ -357,36 +357,28 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     if (more) {
       // publish hr_s (what the recurrent product of the next step reads)
       if (it_on) lc_store16(p.PanH + (size_t)s * pan_h + ((size_t)(ug * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, it_src);
-      // this workgroup's rank-16 contribution to Whr_{s+1}: [ROWS x 16 units] . W_r[:, own units]^T, 16x16x16 MFMAs
-      // (wave -> attention columns [32 wave, 32 wave + 32)), staged through LDS so that a lane stores 16 bytes
-      float* tw = red;                                          // [ROWS][A + 4]; red was consumed above
-      const int tld = A + 4;
-#pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const bf16x4 fa = *reinterpret_cast<const bf16x4*>(hl + (i * 16 + (lane & 15)) * UW + (lane >> 4) * 4);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int a0 = (2 * wave + q) * 16;
-          if (a0 < A) {
-            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(lc_s4, fa), __builtin_bit_cast(lc_s4, wr[q]),
-                                                                      f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (a0 + (lane & 15) < A) tw[(i * 16 + (lane >> 4) * 4 + r) * tld + a0 + (lane & 15)] = d[r];
-          }
-        }
-      }
-      __syncthreads();
+      // this workgroup's rank-16 contribution to Whr_{s+1}, transposed: W_r[:, own units] . [ROWS x 16 units]^T as 16x16x16
+      // MFMAs (wave -> attention columns [32 wave, 32 wave + 32)): a lane then holds four consecutive attention columns of
+      // one caption - one 8-byte fp16 store straight from the accumulator, no staging through LDS
       {
-        const int nq = A >> 2;                                  // 4-column items per row: one 8-byte store each
         _Float16* Pn = p.Pw + ((size_t)(s + 1) * B * p.NG + ug) * A;
-        for (int idx = tid; idx < own * nq; idx += 256) {
-          const int rg = own_lo + idx / nq, qc = (idx % nq) * 4;
-          if (rg < B && rg - r0 < ROWS) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tw + (rg - r0) * tld + qc);
-            union { lc_h4 h; uint64_t u; } pk;
-            pk.h[0] = (_Float16)v[0]; pk.h[1] = (_Float16)v[1]; pk.h[2] = (_Float16)v[2]; pk.h[3] = (_Float16)v[3];
-            __hip_atomic_store(reinterpret_cast<uint64_t*>(Pn + (size_t)rg * p.NG * A + qc), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const bf16x4 fa = *reinterpret_cast<const bf16x4*>(hl + (i * 16 + (lane & 15)) * UW + (lane >> 4) * 4);
+          const int rg = r0 + i * 16 + (lane & 15);
+          const bool ron = rg >= own_lo && rg < own_lo + own && rg < B;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int a0 = (2 * wave + q) * 16 + (lane >> 4) * 4;
+            if ((2 * wave + q) * 16 < A) {
+              const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(lc_s4, wr[q]), __builtin_bit_cast(lc_s4, fa),
+                                                                        f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              if (ron && a0 < A) {
+                union { lc_h4 h; uint64_t u; } pk;
+                pk.h[0] = (_Float16)d[0]; pk.h[1] = (_Float16)d[1]; pk.h[2] = (_Float16)d[2]; pk.h[3] = (_Float16)d[3];
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(Pn + (size_t)rg * p.NG * A + a0), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
           }
         }
       }
