@@ -927,6 +927,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + (lane & 15)] = acc[i][r];
       __syncthreads();
+      if (wg == 0) LC_TS(4, q, 5);
     }
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {

@@ -70,6 +70,8 @@ for role, (nm, pts) in names.items():
     for i in range(1, len(pts)):
         print("    %-22s +%.2f" % (pts[i], np.median(t[:, i] - t[:, i - 1])))
     print("    %-22s +%.2f (to the next step's first stamp)" % ("...", np.median(ts[role, 3:F - 1, 0] - t[:, len(pts) - 1])))
+t4 = ts[4, 3:F - 2]
+print("bwd U': dWhr released -> partial sums in LDS %.2f, -> cells done %.2f" % (np.median(t4[:, 5] - t4[:, 2]), np.median(t4[:, 3] - t4[:, 5])))
 # cross-role offsets inside a step (forward): relay 'C all arrived' -> U 'x arrived', U 'ack + arrive' -> relay 'U all arrived'
 s = slice(3, F - 2)
 print("fwd: relay C-arrived -> U sees x      %.2f" % np.median(ts[0, s, 0] - ts[2, s, 1]))
