@@ -326,9 +326,11 @@ def test_local_backward_chain_with_k_split_forced(case, monkeypatch):
     test_fused_step_vs_oracle_edge_shapes(case, "local", "bf16")
 
 
-def test_global_backward_chain_wide_tiling_equals_the_narrow_one(monkeypatch):
-    """rec_chain_bwd_kernel<48, 3, 2, 2, 16> (32 units x 32 rows, a third of the weights in LDS; B > 64, R in (1024, 1536])."""
-    _chain_variants({"RN_REC_BWD_WIDE": "0"}, "LSTM", monkeypatch, [100, 2, 1536, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(100)])
+@pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 100, 1536), ("LSTM", 65, 1056), ("LSTM", 112, 1280)])
+def test_global_backward_chain_wide_tiling_equals_the_narrow_one(cell, B, R, monkeypatch):
+    """rec_chain_bwd_kernel<48, 3, 2, 2, 16> (32 units x 32 rows, a third of the weights in LDS; B > 64, R in (1024, 1536]):
+    the headline size, the GRU block map, one row in the third row part with the fewest k-steps, every panel row in use."""
+    _chain_variants({"RN_REC_BWD_WIDE": "0"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
