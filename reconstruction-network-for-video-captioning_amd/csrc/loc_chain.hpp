@@ -705,6 +705,10 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       // saved tensors of step s: independent of the chain, requested before waiting
       const float whk = (kon ? p.Whr[((size_t)s * B + b) * A + j] : 0.f) + abk;
       const float bt = (bok && tt < T) ? p.beta[((size_t)s * B + b) * T + tt] * invT : 0.f;
+      // tanh(W hr_s + U h_t + b) of the (t, k) plane: saved operands only, so it is formed while this workgroup waits for dx_s
+      float tzr[32];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) tzr[t] = rn_tanh(whk + ud[t]);
       lc_wait(relX, fb + (unsigned)(q + 1), p.bar);
       if (ci == 0) LC_TS(6, q, 0);
       {   // the KSX <= 4 partial dx of the X' workgroups: every load in flight before the first add
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
         if (t < T) {
-          const float tz = rn_tanh(whk + ud[t]);
+          const float tz = tzr[t];
           const float db = sdbt[c * 32 + t];
           const float dz = db * wk * (1.f - tz * tz);
           dwa += db * tz;
