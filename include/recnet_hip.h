@@ -287,7 +287,7 @@ int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, c
 int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, int32_t b_col, int32_t ldb, float* C,
                      int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
                      int32_t splitk, float* splitk_ws, int32_t tag, void* stream);
-/* Probe builds only (csrc: make PROBE=1): in-kernel wall-clock stamps of the local chain kernels' last launch,
+/* Probe builds only (csrc: make probe): in-kernel wall-clock stamps of the local chain kernels' last launch,
  * [role][step][8] uint64 ticks; RECNET_ESTATE in the product build. */
 int recnet_probe_read(recnet_handle* h, uint64_t* out, int32_t n);
 /* Test hook: fills the LDS of every CU with NaN patterns, so that a kernel reading LDS it never wrote fails the parity
@@ -320,6 +320,9 @@ int recnet_reconstructor_step(recnet_handle* h, const float* input, const float*
  * disable_persistent != 0 switches the handle to the per-step kernels for every later call. */
 int recnet_chain_status(recnet_handle* h, int32_t* status_out, void* stream);
 int recnet_chain_reset(recnet_handle* h, int32_t disable_persistent, void* stream);
+/* Test hook: what a chain kernel does when it gives up a bounded wait (rec_chain.hpp: rc_give_up) — raises the sticky word
+ * of chain `chain_bit` (one of 1, 2, 4, 8, 32, 64) and the poison word, stream-ordered. */
+int recnet_debug_raise_give_up(recnet_handle* h, int32_t chain_bit, void* stream);
 /* Name / start / duration of the dominant kernel's launches inside the last train step are measured
  * by the caller with hipEvents; this returns the ALGORITHMIC bytes of one launch: loop invariants once, every input /
  * saved tensor once.  The step-to-step exchange blocks of a persistent chain kernel are not part of it. */

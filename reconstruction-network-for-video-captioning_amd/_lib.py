@@ -145,3 +145,4 @@ EXPORTS["recnet_chain_reset"] = (_i, [C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_dim"] = (_i, [C.c_void_p, _i])
 EXPORTS["recnet_probe_read"] = (_i, [C.c_void_p, C.c_void_p, _i])
 EXPORTS["recnet_debug_poison_lds"] = (_i, [C.c_void_p, C.c_void_p])
+EXPORTS["recnet_debug_raise_give_up"] = (_i, [C.c_void_p, _i, C.c_void_p])

@@ -85,7 +85,7 @@ struct recnet_handle {
   int deferred_early = 0, deferred_early_flags = -1, deferred_done = 0, join_recorded = 0;   // rec_deferred_fork (host_reconstructor.inc)
   float mse_scale = 0.f; int mse_nb = 0;   // pending MSE partials: fwd_rec finalises the loss scalars in one launch
   float dout_scale = 0.f; int dout_ready = 0;   // dout_lp already holds dout_scale * d loss / d out (written by the MSE kernel)
-  unsigned long long* lc_ts = nullptr;   // probe builds (make PROBE=1): wall-clock stamps of the local chain kernels
+  unsigned long long* lc_ts = nullptr;   // probe builds (make probe): wall-clock stamps of the local chain kernels
   int lc_ms = 1, lc_rb = 4, lc_ng = 0, lc_nc = 0;
   void* dG_pan = nullptr;   // exchange copies of the gate gradients, rec_chain_bwd_kernel
   void* WhhT = nullptr;     // [R][ld4R] transpose of Whh_w (K contiguous) for rec_chain_bwd_kernel
@@ -147,7 +147,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
   h->dc_G2 = take(2 * Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
   h->scal = take(64);
-  h->lc_ts = (unsigned long long*)take(2 * 8 * 64 * 8);
+  h->lc_ts = (unsigned long long*)take(2 * (2 * 8 * 64 * 8));   // 8192 u64 entries (take counts floats): local chains [8 roles][64][8], decoder chains at +4096 / +4608
   h->stepw = take(Tm);
   h->msep = take(1024);
   h->bsum_d = take(4 * H);
@@ -304,11 +304,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     h->ncu = ncu;
-    h->persist_rec = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 &&
+    // Tm <= 60: stamped words carry epoch << 6 | step and barrier words epoch << 7 | phase (rec_chain.hpp) — a longer
+    // caption limit would let one launch's values run into the next epoch's, so it takes the per-step kernels
+    h->persist_rec = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 && h->Tm <= 60 &&
                      (h->R & 7) == 0 && h->R <= 2048 && h->R / 8 <= ncu;   // <= 16 k-steps of resident weights per wave
     const char* ed = getenv("RN_PERSIST_DEC");
     const int N = 4 * h->H + h->A, NA = N / 16;
-    h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 + DC_XF && h->A <= 128 &&
+    h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && h->Tm <= 60 && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 + DC_XF && h->A <= 128 &&
                      (N & 15) == 0 && h->B <= RC_PAN_ROWS && (NA > h->B ? NA : h->B) + 1 <= ncu;
     const char* eb = getenv("RN_PERSIST_REC_BWD");
     h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
@@ -321,6 +323,10 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const int nwg = h->lc_ng * h->lc_ms + h->lc_nc + 1;
     h->persist_loc = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && h->B <= RC_PAN_ROWS && (h->R & 31) == 0 &&
                      h->R <= 2048 && (h->H & 31) == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 3) == 0 && h->Tm <= 32 &&
+                     h->F + 1 < LC_MAX_PHASE &&   // barrier words are epoch << 7 | phase, phase <= F + 1 (loc_chain.hpp)
+#ifdef LC_PROBE
+                     h->F <= 64 &&                // LC_TS indexes [role][step < 64][8]
+#endif
                      nwg <= h->ncu && nwg - 1 <= 256;
     // ... and its backward chain: U' all rows (RB 7) + X' two row parts above 64 captions, one part of 64 rows below
     const char* eb = getenv("RN_PERSIST_LOC_BWD");

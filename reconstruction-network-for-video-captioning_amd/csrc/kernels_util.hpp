@@ -5,6 +5,11 @@
 // small utilities
 // =============================================================================================
 __global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
+// Data parallel: a rank whose chain kernel gave up (rec_chain.hpp: the poison word is NaN, else 0) marks one element of the
+// gradient bucket that is all-reduced LAST; after the SUM every rank sees the NaN and raises its own poison word, so all
+// ranks skip the optimiser update together (adam_chunk_kernel tests the word) instead of the healthy ones applying garbage.
+__global__ void poison_mark_kernel(float* g0, const float* poison) { if (*poison != 0.f) *g0 = __int_as_float(0x7fc00000); }
+__global__ void poison_collect_kernel(const float* g0, float* poison) { if (*g0 != *g0) *poison = __int_as_float(0x7fc00000); }
 __global__ void set_f32_kernel(float* p, float v) { *p = v; }
 // step counter += 1; seed slot = seed_base + step (graph-replay friendly train step)
 __global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t seed_base) {

@@ -47,6 +47,7 @@ struct LocChainArgs {
 #define LC_TS(role, step, i) do { } while (0)
 #endif
 #define LC_CPW 2              // captions per C workgroup
+#define LC_MAX_PHASE 128       // barrier words are (launch epoch << 7) + phase: every phase number of a launch stays below this
 __device__ __forceinline__ void lc_poll(const unsigned* flags, int n, unsigned target, unsigned* bar, unsigned& spin) {
   // wave 0 of the relay workgroup: all n <= 256 flags have reached `target`
   const int l = threadIdx.x;

@@ -36,12 +36,33 @@ const float* fptr(const c10::optional<at::Tensor>& t, const char* name) {
   return t->data_ptr<float>();
 }
 at::Tensor scalars_like(const at::Tensor& ref) { return at::zeros({8}, ref.options().dtype(at::kFloat)); }
+int64_t dim(int64_t h, int which) { return recnet_dim(H(h), which); }
+// Shapes come from the handle (recnet_dim), never from the caller's tensors: a wrong-shaped tensor is a RuntimeError,
+// not an out-of-bounds device write.
+void shape(const at::Tensor& t, std::initializer_list<int64_t> want, const char* name) {
+  int64_t n = 1;
+  for (auto w : want) n *= w;
+  TORCH_CHECK(t.numel() == n, "recnet: ", name, " has ", t.numel(), " elements (sizes ", t.sizes(), "), the engine expects ",
+              at::IntArrayRef(want.begin(), want.size()));
+}
+void chk_enc(int64_t h, const at::Tensor& enc) {
+  chk(enc, at::kFloat, "encoder_outputs");
+  TORCH_CHECK(enc.dim() == 3 && enc.size(0) == dim(h, RECNET_DIM_B) && enc.size(1) == dim(h, RECNET_DIM_F) && enc.size(2) == dim(h, RECNET_DIM_D),
+              "recnet: encoder_outputs has sizes ", enc.sizes(), ", the engine expects [", dim(h, RECNET_DIM_B), ", ", dim(h, RECNET_DIM_F), ", ",
+              dim(h, RECNET_DIM_D), "]");
+}
+void chk_targets(int64_t h, const at::Tensor& targets, int64_t T) {
+  chk(targets, at::kLong, "targets");
+  TORCH_CHECK(targets.dim() == 2 && targets.size(1) == dim(h, RECNET_DIM_B) && targets.size(0) >= T && T >= 1 && T <= dim(h, RECNET_DIM_TM),
+              "recnet: targets has sizes ", targets.sizes(), ", the engine expects [>= T = ", T, " (<= ", dim(h, RECNET_DIM_TM), "), ",
+              dim(h, RECNET_DIM_B), "]");
+}
+void chk_T(int64_t h, int64_t T) { TORCH_CHECK(T >= 1 && T <= dim(h, RECNET_DIM_TM), "recnet: T = ", T, " outside [1, ", dim(h, RECNET_DIM_TM), "]"); }
 
 // ---------------------------------------------------------------- sequence level
 std::tuple<at::Tensor, at::Tensor, at::Tensor> forward_decoder(int64_t h, const at::Tensor& enc, const at::Tensor& targets, int64_t T,
                                                                const at::Tensor& step_weight, bool train, int64_t seed) {
-  chk(enc, at::kFloat, "encoder_outputs"); chk(targets, at::kLong, "targets"); chk(step_weight, at::kFloat, "step_weight");
-  TORCH_CHECK(enc.dim() == 3 && targets.dim() == 2 && targets.size(1) == enc.size(0), "recnet: encoder_outputs [B,F,D], targets [Tm,B]");
+  chk_enc(h, enc); chk_targets(h, targets, T); chk(step_weight, at::kFloat, "step_weight");
   TORCH_CHECK(step_weight.numel() == T, "recnet: step_weight must have T entries");
   auto sc = scalars_like(enc);
   auto hid = at::empty({T, 1, enc.size(0), recnet_dim(H(h), RECNET_DIM_H)}, enc.options());
@@ -52,7 +73,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> forward_decoder(int64_t h, const 
 std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> forward_decoder_free(int64_t h, const at::Tensor& enc, const at::Tensor& targets,
                                                                                 int64_t T, const at::Tensor& step_weight, bool train,
                                                                                 int64_t seed) {
-  chk(enc, at::kFloat, "encoder_outputs"); chk(targets, at::kLong, "targets"); chk(step_weight, at::kFloat, "step_weight");
+  chk_enc(h, enc); chk_targets(h, targets, T); chk(step_weight, at::kFloat, "step_weight");
   TORCH_CHECK(step_weight.numel() == T, "recnet: step_weight must have T entries");
   auto sc = scalars_like(enc);
   auto hid = at::empty({T, 1, enc.size(0), recnet_dim(H(h), RECNET_DIM_H)}, enc.options());
@@ -64,23 +85,27 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> forward_decoder_free(
 }
 void backward_decoder(int64_t h, const at::Tensor& enc, const at::Tensor& targets, const c10::optional<at::Tensor>& dhiddens,
                       double grad_scale) {
-  chk(enc, at::kFloat, "encoder_outputs"); chk(targets, at::kLong, "targets");
+  chk_enc(h, enc); chk(targets, at::kLong, "targets");
+  TORCH_CHECK(targets.dim() == 2 && targets.size(1) == dim(h, RECNET_DIM_B), "recnet: targets must be [Tm, B]");
+  if (dhiddens.has_value() && dhiddens->defined())
+    TORCH_CHECK(dhiddens->numel() % (dim(h, RECNET_DIM_B) * dim(h, RECNET_DIM_H)) == 0 && dhiddens->numel() > 0 &&
+                    dhiddens->numel() / (dim(h, RECNET_DIM_B) * dim(h, RECNET_DIM_H)) <= dim(h, RECNET_DIM_TM),
+                "recnet: dhiddens must be [T,1,B,H] of the forward pass, got ", dhiddens->sizes());
   ok(recnet_backward_decoder(H(h), enc.data_ptr<float>(), targets.data_ptr<int64_t>(), fptr(dhiddens, "dhiddens"), (float)grad_scale,
                              stream()), "backward_decoder");
 }
 std::tuple<at::Tensor, at::Tensor> forward_reconstructor(int64_t h, const at::Tensor& enc, const c10::optional<at::Tensor>& hiddens,
                                                          int64_t T, bool train, int64_t seed) {
-  chk(enc, at::kFloat, "encoder_outputs");
-  if (hiddens.has_value() && hiddens->defined())
-    TORCH_CHECK(hiddens->numel() == T * enc.size(0) * recnet_dim(H(h), RECNET_DIM_H), "recnet: decoder_hiddens must be [T,1,B,H]");
+  chk_enc(h, enc); chk_T(h, T);
+  if (hiddens.has_value() && hiddens->defined()) shape(*hiddens, {T, 1, dim(h, RECNET_DIM_B), dim(h, RECNET_DIM_H)}, "decoder_hiddens");
   auto sc = scalars_like(enc);
   ok(recnet_forward_reconstructor(H(h), enc.data_ptr<float>(), fptr(hiddens, "decoder_hiddens"), (int32_t)T, train, (uint32_t)seed,
                                   (recnet_scalars*)sc.data_ptr<float>(), stream()), "forward_reconstructor");
   return {sc.select(0, 5).clone(), sc};
 }
 at::Tensor backward_reconstructor(int64_t h, const at::Tensor& enc, int64_t T, double grad_scale) {
-  chk(enc, at::kFloat, "encoder_outputs");
-  auto dh = at::empty({T, 1, enc.size(0), recnet_dim(H(h), RECNET_DIM_H)}, enc.options());
+  chk_enc(h, enc); chk_T(h, T);
+  auto dh = at::empty({T, 1, dim(h, RECNET_DIM_B), dim(h, RECNET_DIM_H)}, enc.options());
   ok(recnet_backward_reconstructor(H(h), enc.data_ptr<float>(), (float)grad_scale, dh.data_ptr<float>(), stream()), "backward_reconstructor");
   return dh;
 }
@@ -89,7 +114,7 @@ void add_reg_grad(int64_t h, int64_t which, double grad_scale) { ok(recnet_add_r
 // ---------------------------------------------------------------- fused step (train.py:248-273)
 at::Tensor train_step_fwd_bwd(int64_t h, const at::Tensor& enc, const at::Tensor& targets, int64_t T, const at::Tensor& step_weight,
                               int64_t seed) {
-  chk(enc, at::kFloat, "encoder_outputs"); chk(targets, at::kLong, "targets"); chk(step_weight, at::kFloat, "step_weight");
+  chk_enc(h, enc); chk_targets(h, targets, T); chk(step_weight, at::kFloat, "step_weight");
   TORCH_CHECK(step_weight.numel() == T, "recnet: step_weight must have T entries");
   auto sc = scalars_like(enc);
   ok(recnet_train_step_fwd_bwd(H(h), enc.data_ptr<float>(), targets.data_ptr<int64_t>(), (int32_t)T, step_weight.data_ptr<float>(),
@@ -98,7 +123,7 @@ at::Tensor train_step_fwd_bwd(int64_t h, const at::Tensor& enc, const at::Tensor
 }
 at::Tensor train_step(int64_t h, const at::Tensor& enc, const at::Tensor& targets, int64_t T, const at::Tensor& step_weight, int64_t seed,
                       int64_t step) {
-  chk(enc, at::kFloat, "encoder_outputs"); chk(targets, at::kLong, "targets"); chk(step_weight, at::kFloat, "step_weight");
+  chk_enc(h, enc); chk_targets(h, targets, T); chk(step_weight, at::kFloat, "step_weight");
   TORCH_CHECK(step_weight.numel() == T, "recnet: step_weight must have T entries");
   auto sc = scalars_like(enc);
   ok(recnet_train_step(H(h), enc.data_ptr<float>(), targets.data_ptr<int64_t>(), (int32_t)T, step_weight.data_ptr<float>(), (uint32_t)seed,
@@ -117,7 +142,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> decoder_step(int64_t h, const at:
                                                             const c10::optional<at::Tensor>& c_in, const c10::optional<at::Tensor>& enc,
                                                             bool train, int64_t seed, int64_t t) {
   chk(tokens, at::kLong, "input");
-  const int64_t B = tokens.numel();
+  const int64_t B = dim(h, RECNET_DIM_B), Hd = dim(h, RECNET_DIM_H);
+  shape(tokens, {1, B}, "input");
+  if (h_in.has_value() && h_in->defined()) shape(*h_in, {B, Hd}, "hidden h");
+  if (c_in.has_value() && c_in->defined()) shape(*c_in, {B, Hd}, "hidden c");
+  if (enc.has_value() && enc->defined()) chk_enc(h, *enc);
   auto opt = tokens.options().dtype(at::kFloat);
   auto logits = at::empty({B, recnet_dim(H(h), RECNET_DIM_V)}, opt);
   auto ho = at::empty({B, recnet_dim(H(h), RECNET_DIM_H)}, opt), co = at::empty_like(ho);
@@ -131,7 +160,13 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> reconstructor_step(int64_t h, con
                                                                   const c10::optional<at::Tensor>& decoder_hiddens, int64_t T, bool train,
                                                                   int64_t seed, int64_t t) {
   chk(hr_in, at::kFloat, "hidden hr");
-  auto out = at::empty_like(hr_in), ho = at::empty_like(hr_in), co = at::empty_like(hr_in);
+  const int64_t B = dim(h, RECNET_DIM_B), R = dim(h, RECNET_DIM_R), Hd = dim(h, RECNET_DIM_H);
+  chk_T(h, T);
+  shape(hr_in, {B, R}, "hidden hr");
+  if (cr_in.has_value() && cr_in->defined()) shape(*cr_in, {B, R}, "hidden cr");
+  if (input.has_value() && input->defined()) shape(*input, {B, Hd}, "input");
+  if (decoder_hiddens.has_value() && decoder_hiddens->defined()) shape(*decoder_hiddens, {T, 1, B, Hd}, "decoder_hiddens");
+  auto out = at::empty({B, R}, hr_in.options()), ho = at::empty({B, R}, hr_in.options()), co = at::empty({B, R}, hr_in.options());
   ok(recnet_reconstructor_step(H(h), fptr(input, "input"), hr_in.data_ptr<float>(), fptr(cr_in, "hidden cr"),
                                fptr(decoder_hiddens, "decoder_hiddens"), (int32_t)T, out.data_ptr<float>(), ho.data_ptr<float>(),
                                co.data_ptr<float>(), train, (uint32_t)seed, (int32_t)t, stream()), "reconstructor_step");
@@ -140,14 +175,14 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> reconstructor_step(int64_t h, con
 
 // ---------------------------------------------------------------- search (eval.py:19-120)
 std::tuple<at::Tensor, at::Tensor> greedy_search(int64_t h, const at::Tensor& enc) {
-  chk(enc, at::kFloat, "encoder_outputs");
+  chk_enc(h, enc);
   auto toks = at::zeros({recnet_dim(H(h), RECNET_DIM_TM), enc.size(0)}, enc.options().dtype(at::kLong));
   auto n = at::zeros({1}, enc.options().dtype(at::kInt));
   ok(recnet_greedy_search(H(h), enc.data_ptr<float>(), toks.data_ptr<int64_t>(), n.data_ptr<int32_t>(), stream()), "greedy_search");
   return {toks, n};
 }
 std::tuple<at::Tensor, at::Tensor> beam_search(int64_t h, const at::Tensor& enc, int64_t beam_width) {
-  chk(enc, at::kFloat, "encoder_outputs");
+  chk_enc(h, enc);
   auto best = at::zeros({recnet_dim(H(h), RECNET_DIM_TM), enc.size(0)}, enc.options().dtype(at::kLong));
   auto n = at::zeros({1}, enc.options().dtype(at::kInt));
   ok(recnet_beam_search(H(h), enc.data_ptr<float>(), (int32_t)beam_width, best.data_ptr<int64_t>(), n.data_ptr<int32_t>(), stream()), "beam_search");

@@ -268,6 +268,10 @@ class Engine:
         _lib.check(self.lib.recnet_chain_status(self.handle, C.byref(s), _stream()), "recnet_chain_status")
         return s.value
 
+    def debug_raise_give_up(self, chain_bit=1):
+        """Test hook: raise chain `chain_bit`'s sticky word and the poison word the way a chain kernel that gives up does."""
+        _lib.check(self.lib.recnet_debug_raise_give_up(self.handle, int(chain_bit), _stream()), "recnet_debug_raise_give_up")
+
     def chain_reset(self, disable_persistent=True):
         _lib.check(self.lib.recnet_chain_reset(self.handle, int(bool(disable_persistent)), _stream()), "recnet_chain_reset")
 

@@ -51,16 +51,34 @@ class Trainer:
     def check_health(self, scalars=None):
         """Raises if a persistent chain kernel gave up a bounded wait (the step's gradients were garbage; the optimiser
         kernels skipped the update) or the loss is not finite.  Before raising, the handle is switched to the per-step
-        kernels and the captured graphs are dropped, so a caller that catches the error can keep training."""
+        kernels and the captured graphs are dropped, so a caller that catches the error can keep training.
+
+        Data parallel: a collective — every rank calls it at the same iterations (fit does) and the status words are
+        MAX-reduced first, so all ranks raise (and fall back) together instead of the healthy ones blocking in the next
+        all-reduce.  The update itself was already skipped on EVERY rank: the affected rank marks the last gradient
+        bucket with a NaN before the all-reduce (csrc/kernels_util.hpp: poison_mark_kernel / poison_collect_kernel)."""
         eng = self.dp.step_impl.engine
         st = eng.chain_status()
         bad_loss = scalars is not None and not bool(torch.isfinite(scalars[6]))
+        where = ""
+        if self.world > 1:
+            import torch.distributed as dist
+            # gloo has no bitwise OR: one MAX per status bit (9 bits) + the loss flag
+            word = torch.tensor([float((st >> k) & 1) for k in range(9)] + [float(bad_loss)], device=scalars.device if scalars is not None
+                                else next(self.decoder["model"].parameters()).device)
+            mine = (st, bad_loss)
+            dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.dp.group)
+            w = word.cpu().tolist()
+            st = sum(1 << k for k in range(9) if w[k] > 0)
+            bad_loss = w[9] > 0
+            if (st & 0xFF) and not (mine[0] & 0xFF):
+                where = " (raised by another rank)"
         if st or bad_loss:
             eng.chain_reset(disable_persistent=True)
             self._graphs.clear()
-            raise RuntimeError("train step %d: %s; the optimiser updates of the affected steps were skipped, the engine now "
-                               "uses the per-step kernels" % (self.iteration, "persistent chain kernel gave up waiting (status "
-                               "0x%x: another kernel held the CUs it needs)" % st if st else "non-finite loss"))
+            raise RuntimeError("train step %d: %s%s; the optimiser updates of the affected steps were skipped on every rank, the "
+                               "engine now uses the per-step kernels" % (self.iteration, "persistent chain kernel gave up waiting "
+                               "(status 0x%x: another kernel held the CUs it needs)" % st if st else "non-finite loss", where))
 
     def global_scalars(self, acc):
         """acc: device scalars summed over steps on THIS rank.  Under data parallelism the CE / MSE parts ([0], [3]) are
@@ -131,7 +149,7 @@ class Trainer:
 
     # ------------------------------------------------------------------ the loop, train.py:227-420
     def fit(self, batches, n_iterations, log_every=None, val_batches=None, validate_every=None, save_every=None,
-            save_dpath=None, idx2word=None, log=print):
+            save_dpath=None, idx2word=None, log=print, health_every=200):
         C = self.C
         lo, hi = self.dp.lo, self.dp.hi
         dev = next(self.decoder["model"].parameters()).device
@@ -144,8 +162,9 @@ class Trainer:
             acc += sc                                   # stays on the device; read at log time only
             n_acc += 1
             it = self.iteration
+            checked = False
             if log_every and it % log_every == 0:
-                self.check_health(sc)
+                self.check_health(sc); checked = True
                 # the reference divides its running sums by log_every * batch_size (train.py:282-286)
                 a = [x / (n_acc * C.batch_size) for x in self.global_scalars(acc)]
                 rec = {"iteration": it, "loss": a[6], "dec": a[2], "rec": a[5]}
@@ -162,12 +181,16 @@ class Trainer:
                 log("[Validation] Iter {} / {}: loss {:.5f} (dec {:.5f} + rec {:.5f})".format(it, n_iterations, v["loss"],
                                                                                             v["dec"], v["rec"]))
             if save_every and save_dpath and it % save_every == 0:
-                self.check_health(sc)                  # never write weights of a step that went wrong
+                if not checked:
+                    self.check_health(sc); checked = True   # never write weights of a step that went wrong
                 gl = self.global_scalars(sc)           # collective under data parallelism: every rank
                 if self.rank == 0:
                     os.makedirs(save_dpath, exist_ok=True)
                     save_checkpoint(os.path.join(save_dpath, "{}_checkpoint.tar".format(it)), it, self.decoder,
                                     self.reconstructor, loss=torch.tensor(gl[6]), config=C)
+            # health is checked even when nothing is logged or saved (one stream sync + a 40-byte read every health_every steps)
+            if not checked and health_every and (it % health_every == 0 or it >= n_iterations):
+                self.check_health(sc)
             if it >= n_iterations:
                 break
         return hist

@@ -123,10 +123,13 @@ class Decoder(nn.Module, _Generation):
         # The reference recomputes attn_U(encoder_outputs) on every call (decoder.py:54); here the loop invariants
         # (Uv, P) and the packed weights are refreshed only when the features or the parameters changed —
         # eval.py's search loops call forward 31 x beam times with the same encoder_outputs.
+        # Freshness is keyed on the tensor OBJECT (kept alive here, so its address cannot be handed to another batch
+        # by the caching allocator) and its in-place version counter — never on data_ptr alone.
         enc = encoder_outputs.contiguous()
         pver = self.weights_signature()
-        sig = (enc.data_ptr(), enc._version, tuple(enc.shape), pver)
-        fresh = getattr(eng, "_inv_sig", None) != sig
+        sig = (enc._version, tuple(enc.shape), pver)
+        fresh = getattr(eng, "_inv_ref", None) is not encoder_outputs or getattr(eng, "_inv_sig", None) != sig
+        eng._inv_ref = encoder_outputs
         if fresh:
             if getattr(eng, "_pver", None) != pver:
                 eng.pack_weights()
@@ -175,9 +178,12 @@ class _Reconstructor(nn.Module, _Generation):
             eng._pver = pver
         # the reference recomputes the pooled states / U_r . hiddens on every call (global_reconstructor.py:33-37,
         # local_reconstructor.py:42); here they are refreshed only when decoder_hiddens or the parameters changed
+        # — keyed on the tensor OBJECT (a reference is kept, so the caching allocator cannot hand its address to the
+        # next batch's hiddens) and its in-place version counter, never on data_ptr alone.
         dh = decoder_hiddens.contiguous()
-        sig = (dh.data_ptr(), dh._version, tuple(dh.shape), pver)
-        fresh = getattr(eng, "_inv_sig", None) != sig
+        sig = (dh._version, tuple(dh.shape), pver)
+        fresh = getattr(eng, "_inv_ref", None) is not decoder_hiddens or getattr(eng, "_inv_sig", None) != sig
+        eng._inv_ref = decoder_hiddens
         eng._inv_sig = sig
         gru = self.model_name == "GRU"
         h, c = (hidden, hidden) if gru else hidden

@@ -92,3 +92,71 @@ def test_two_ranks_on_one_gpu_match_single_rank(kind):
         assert np.abs(dec2[k] - v.cpu().numpy()).max() <= 2e-6, k
     for k, v in rec["model"].state_dict().items():
         assert np.abs(rec2[k] - v.cpu().numpy()).max() <= 2e-6, k
+
+
+def _worker_giveup(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC", "RN_PERSIST_LOC"):
+        os.environ[k] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import recnet_amd as R
+    lo, hi = R.shard_bounds(DIMS[0], world, rank)
+    R_, dec, rec, enc, targets = _setup("global", DIMS[0], lo, hi)
+    step = R.DataParallelTrainStep(dec, rec, DIMS[0], rank, world, n_frames=DIMS[1])
+    T, w = step.prepare(targets.numpy())
+    e, t = enc[lo:hi].cuda(), targets[:, lo:hi].contiguous().cuda()
+    run = R.GraphedStep(step, e, t, T, w, warmup=0)
+    run()
+    torch.cuda.synchronize()
+    eng = step.step_impl.engine
+    snap = lambda: {k: v.detach().clone() for m in (dec, rec) for k, v in m["model"].state_dict().items()}
+    before = snap()
+    if rank == 1:
+        eng.debug_raise_give_up(1)            # what rec_chain_kernel does when a bounded wait runs out, on ONE rank
+    sc = run().clone()
+    torch.cuda.synchronize()
+    after = snap()
+    unchanged = all(torch.equal(before[k], after[k]) for k in before)
+    status = eng.chain_status()
+    tr = R.Trainer.__new__(R.Trainer)
+    tr.dp, tr.world, tr.rank, tr.decoder, tr._graphs, tr.iteration = step, world, rank, dec, {}, 2
+    raised = ""
+    try:
+        tr.check_health(sc)
+    except RuntimeError as ex:
+        raised = str(ex)
+    run2 = R.GraphedStep(step, e, t, T, w, warmup=0)       # graphs re-captured after the reset, both ranks keep training
+    run2()
+    torch.cuda.synchronize()
+    moved = any(not torch.equal(after[k], v) for k, v in snap().items())
+    q.put((rank, unchanged, status, raised, bool(torch.isfinite(sc[6])), moved, eng.chain_status()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_give_up_on_one_rank_skips_the_update_on_every_rank():
+    """chain give-up handling was rank-local — the healthy rank applied the garbage bucket and blocked in the
+    next collective while the affected one raised.  Now the poison travels with the last gradient bucket and
+    check_health is collective."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_giveup, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, unchanged, status, raised, finite, moved, status_after in res:
+        assert unchanged, "rank %d applied an update from a poisoned step" % rank
+        assert status & 256, (rank, status)
+        assert not finite
+        assert "gave up" in raised, (rank, raised)
+        assert moved and status_after == 0, (rank, moved, status_after)
+    assert res[0][2] & 0xFF == 0 and "another rank" in res[0][3]       # rank 0's own chains were healthy
+    assert res[1][2] & 1

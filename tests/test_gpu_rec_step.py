@@ -78,3 +78,61 @@ def test_eval_mode_switches_dropout_off_and_state_dict_round_trips():
     o_train, _ = m(hidden, hid.cuda())
     assert np.abs(o_train.cpu().numpy() - g["out"][0]).max() <= 2e-5
     assert np.abs(o_train.cpu().numpy() - o_eval.cpu().numpy()).max() > 1e-4
+
+
+@pytest.mark.parametrize("kind", ["global", "local"])
+def test_two_batches_at_the_same_address_are_not_confused(kind):
+    """the loop invariants (pooled states / U_r . hiddens) were keyed on (data_ptr, _version); the caching
+    allocator hands a freed batch's address to the next batch with _version 0.  Two different decoder_hiddens at ONE
+    address, weights unchanged (eval mode): the second call has to see the second batch."""
+    g, (B, T, F, H, Rr, RA), _, cell, P, hid = case_inputs("recstep_%s_eval" % kind)
+    if kind == "global":
+        m = R.GlobalReconstructor(model_name=cell, n_layers=1, decoder_hidden_size=H, hidden_size=Rr, dropout=0.5,
+                                  decoder_dropout=0.5, caption_max_len=30, precision="f32")
+    else:
+        m = R.LocalReconstructor(model_name=cell, n_layers=1, decoder_hidden_size=H, hidden_size=Rr, dropout=0.5,
+                                 decoder_dropout=0.5, attn_size=RA, precision="f32")
+    m.load_state_dict(P)
+    m = m.to("cuda").eval()
+    zeros = lambda: (torch.zeros(1, B, Rr, device="cuda"), torch.zeros(1, B, Rr, device="cuda"))
+
+    def first_step(hiddens_cpu):
+        dh = hiddens_cpu.cuda()                      # a local: freed on return, its block goes back to the allocator
+        ptr = dh.data_ptr()
+        out = m(dh[0], zeros(), dh)[0] if kind == "global" else m(zeros(), dh)[0]
+        return out.cpu().numpy(), ptr
+
+    other = torch.flip(hid, dims=[0, 2]) * 0.5 + 0.1
+    want_a, _ = first_step(hid)
+    # reference value for `other` from a fresh module (no cached invariants)
+    fresh = (R.GlobalReconstructor(model_name=cell, n_layers=1, decoder_hidden_size=H, hidden_size=Rr, dropout=0.5, decoder_dropout=0.5,
+                                   caption_max_len=30, precision="f32") if kind == "global" else
+             R.LocalReconstructor(model_name=cell, n_layers=1, decoder_hidden_size=H, hidden_size=Rr, dropout=0.5, decoder_dropout=0.5,
+                                  attn_size=RA, precision="f32"))
+    fresh.load_state_dict(P)
+    fresh = fresh.to("cuda").eval()
+    dho = other.cuda()
+    want_b = (fresh(dho[0], zeros(), dho)[0] if kind == "global" else fresh(zeros(), dho)[0]).cpu().numpy()
+    del dho
+    torch.cuda.synchronize()
+    got_a, pa = first_step(hid)
+    got_b, pb = first_step(other)
+    # Before the fix pa == pb here (the allocator reused the block) and got_b came out equal to got_a.  The module now
+    # keeps the tensor it derived its invariants from alive, so the address cannot be reused while they are cached.
+    assert np.abs(got_a - want_a).max() <= 1e-6
+    assert np.abs(want_b - want_a).max() > 1e-4, "the two batches have to differ for the test to mean anything"
+    assert np.abs(got_b - want_b).max() <= 1e-6
+
+
+def test_wrong_shaped_hidden_is_a_runtime_error_not_a_device_write():
+    """the torch.ops layer sizes its outputs from the handle and checks every tensor against recnet_dim."""
+    g, (B, T, F, H, Rr, RA), kind, cell, P, hid = case_inputs("recstep_local_eval")
+    m = R.LocalReconstructor(model_name=cell, n_layers=1, decoder_hidden_size=H, hidden_size=Rr, dropout=0.5,
+                             decoder_dropout=0.5, attn_size=RA, precision="f32").to("cuda").eval()
+    m.load_state_dict(P)
+    dh = hid.cuda()
+    good = (torch.zeros(1, B, Rr, device="cuda"), torch.zeros(1, B, Rr, device="cuda"))
+    m(good, dh)
+    for bad in ((torch.zeros(1, B, Rr - 8, device="cuda"),) * 2, (torch.zeros(1, B + 1, Rr, device="cuda"),) * 2):
+        with pytest.raises(RuntimeError):
+            m(bad, dh)
