@@ -75,49 +75,61 @@ def algorithmic_hbm_bytes(kind, B, F, D, V=4188, E=468, H=512, A=128, RA=128):
     return 36.0 * p_dec + 28.0 * p_rec + 4.0 * B * F * D + 8.0 * 31 * B
 
 
+def stored_traffic(kernel_full, kind, dims, T, cell):
+    """HBM-side bytes per launch from the rocprofv3 --pmc passes stored under profiles/ (tools/pmc_traffic.py; counters
+    cannot be read from inside the timed process): the newest round's file whose metadata names exactly this kernel,
+    workload shape and cell.  Returns (bytes, source) or (None, None)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic_*.json"))):
+        try:
+            meta = json.load(open(f))
+        except Exception:
+            continue
+        if (meta.get("kernel", "") in (kernel_full, kernel_full.split("<")[0]) and meta.get("kind") == (kind or "none") and meta.get("B") == dims["B"] and
+                meta.get("D") == dims["D"] and meta.get("F") == dims["F"] and meta.get("T", 31) == T and meta.get("cell", "LSTM") == cell):
+            best = (int(meta["traffic_bytes_per_launch"]), "stored: profiles/" + os.path.basename(f))
+    return best or (None, None)
+
+
 def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
-    """Dominant kernel = the longest of the persistent recurrent-chain kernels (one launch = all T dependent steps of
-    one chain, weights resident on chip, grid barrier / stamped hand-over per step), else the per-step recurrent GEMM.
-    `achieved` = algorithmic bytes of one launch (recnet_recurrent_step_bytes) / its average duration, measured with
-    hipEvents on the launch stream inside the replayed step; bound = HBM, the bound SURVEY.md §8d names — the chains are
-    latency-bound by their per-step exchange, so the fraction is small by construction.
-    run_step(site) -> (launches, avg ms)."""
+    """Dominant kernel = the kernel of the recurrent part with the largest TIME PER TRAIN STEP (launches x average duration):
+    one of the persistent chain kernels (one launch = all T / F dependent steps of a chain, weights resident on chip) or,
+    where a chain runs on per-step kernels (R = 3584, B > 112, the fp32 path), its recurrent-step GEMM (28-31 launches per
+    step).  `achieved` = algorithmic bytes of one launch (recnet_recurrent_step_bytes) / its average duration, measured
+    with hipEvents on the launch stream; bound = HBM, the bound SURVEY.md section 8d names for the recurrent kernels.
+    run_step(site) -> (launches per step, avg ms per launch)."""
     import torch
     torch.cuda.synchronize()
-    # All four recurrent chains run as persistent launches when the shape allows (csrc/rec_chain.hpp, csrc/dec_chain.hpp):
-    # the dominant kernel is the longest of them.  Otherwise the per-step recurrent GEMM of the reconstructor / decoder.
+    local = kind == "local"
+    # (site, `which` of recnet_recurrent_step_bytes, name)
     cands = [(9, 5, "dec_chain_kernel (decoder forward chain, T steps in one launch)"),
              (10, 6, "dec_chain_bwd_kernel (decoder BPTT chain, T steps in one launch)"),
-             (8, 4, "rec_chain_bwd_kernel<48, 3, 4, 1> (reconstructor backward chain, T steps in one launch)" if kind == "global" else
-                    "loc_chain_bwd_kernel (local reconstructor backward chain, F steps in one launch)"),
-             (7, 3, "rec_chain_kernel<12, 2, 4, 4> (reconstructor forward chain, T steps in one launch)" if kind == "global" else
-                    "loc_chain_kernel (local reconstructor forward chain, F steps in one launch)")]
-    best = None
-    chains = {}
-    meas = []
+             (8, 4, "loc_chain_bwd_kernel (local reconstructor backward chain, F steps in one launch)" if local else
+                    "rec_chain_bwd_kernel (reconstructor backward chain, T steps in one launch)"),
+             (7, 3, "loc_chain_kernel (local reconstructor forward chain, F steps in one launch)" if local else
+                    "rec_chain_kernel (reconstructor forward chain, T steps in one launch)"),
+             (1, 0, "gemm_chain_kernel (recurrent-step GEMM, decoder fwd, one launch per step)"),
+             (3, 1, "gemm_lds_kernel<false, false, 4, 3, 96> (recurrent-step GEMM, reconstructor fwd, one launch per step)"),
+             (4, 2, "gemm_lds_kernel<false, true, 4, 4, 128> (recurrent-step GEMM, reconstructor bwd, one launch per step)")]
+    chains, per_step, meas = {}, {}, []
     for s_id, wh, nm in cands:
-        if wh in (3, 4) and kind is None:
+        if wh in (1, 2, 3, 4) and kind is None:
             continue
         n_, ms_ = run_step(s_id)
         if n_ > 0:
-            chains[nm.split(" ")[0].split("<")[0]] = round(ms_ * 1e3, 1)
+            short = nm.split(" ")[0].split("<")[0]
+            if s_id >= 7:
+                chains[short] = round(ms_ * 1e3, 1)
+            per_step["site %d: %s" % (s_id, nm.split(" (")[0])] = {"launches_per_step": n_, "avg_us": round(ms_ * 1e3, 1),
+                                                                    "us_per_step": round(n_ * ms_ * 1e3, 1)}
             meas.append((n_, ms_, s_id, wh, nm))
-    if meas:
-        # the chains of the benchmark shape are within a few percent of each other: the first in the list above that is
-        # within 5 % of the longest is reported, so that the choice does not flip from run to run
-        top = max(m[1] for m in meas)
-        best = next(m for m in meas if m[1] >= 0.95 * top)
-    if best is not None:
-        n, ms_raw, site, which, kname = best
-    else:
-        site = 3 if kind else 1
-        which = 1 if kind else 0
-        n, ms_raw = run_step(site)
-        kname = "%s (recurrent-step GEMM, %s)" % ("gemm_lds_kernel<false, false, 4, 3, 96>" if kind else "gemm_chain_kernel<1, 2, 1>", "reconstructor fwd" if kind else "decoder fwd")
-        if n == 0 and kind == "global":
-            site, which = 4, 2
-            n, ms_raw = run_step(site)
-            kname = "gemm_lds_kernel<false, true, 4, 4, 128> (recurrent-step GEMM, reconstructor bwd)"
+    if not meas:
+        return None
+    # the kernels of the benchmark shape are within a few percent of each other: the first in the list above that is
+    # within 5 % of the largest time per step is reported, so that the choice does not flip from run to run
+    top = max(m[0] * m[1] for m in meas)
+    n, ms_raw, site, which, kname = next(m for m in meas if m[0] * m[1] >= 0.95 * top)
     # What the two event records add to a bracket (E), from brackets around 1 and around 17 empty kernels in the same
     # mode (graph nodes / eager): b(c) = E + c * f.  The kernel's dispatch-to-completion time — what rocprofv3 reports as
     # its duration — is its bracket minus E.
@@ -130,26 +142,34 @@ def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
     exchange = eng.chain_exchange_bytes(which) if which >= 3 else 0.0
     achieved = bytes_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     peak = 8000.0
-    # HBM-side bytes per launch from the PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 runs,
-    # FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM; tools/pmc_traffic.py) — only valid for the configuration it was
-    # collected on (global reconstructor, bf16, B=100, 28x1536)
-    # traffic: HBM-side bytes per launch from rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py), stored
-    # under profiles/ — counters cannot be read from inside the timed process.  Only reported for the exact workload and
-    # kernel the stored file was collected on; `traffic_source` names the file.
-    traffic, traffic_src = None, None
-    short = kname.split(" ")[0].split("<")[0]
-    tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s_%s.json" % (kind or "none", short))
-    if precision == "bf16" and os.path.exists(tf):
-        meta = json.load(open(tf))
-        if (meta.get("B") == eng.dims["B"] and meta.get("D") == eng.dims["D"] and meta.get("F") == eng.dims["F"] and
-                meta.get("T", 31) == T and meta.get("cell", "LSTM") == cell):
-            traffic, traffic_src = int(meta["traffic_bytes_per_launch"]), "stored: profiles/" + os.path.basename(tf)
+    traffic, traffic_src = stored_traffic(kname.split(" (")[0], kind, eng.dims, T, cell) if precision == "bf16" else (None, None)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": kname, "exchange_bytes_per_launch": int(exchange),
-            "launches_timed": n, "avg_launch_us": round(ms * 1e3, 3), "bracket_us": round(ms_raw * 1e3, 3),
+            "kernel": kname, "launches_per_step": n, "us_per_step": round(n * ms * 1e3, 1), "exchange_bytes_per_launch": int(exchange),
+            "avg_launch_us": round(ms * 1e3, 3), "bracket_us": round(ms_raw * 1e3, 3),
             "event_pair_overhead_us": round(ms_null * 1e3, 3), "empty_kernel_us": round(f_empty * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch),
-            "chain_kernel_brackets_us": chains}
+            "chain_kernel_brackets_us": chains, "recurrent_kernels": per_step}
+
+
+def fp32_exact(R, cfg_over, V, enc, targets, targets_g, B, F, steps=10, warmup=3):
+    """The same workload on the exact-fp32 path (`precision="f32"`: fp32 operands, v_mfma_f32_16x16x4_f32, the arithmetic of
+    the reference — the path the 1e-4 gradient parity bar is held on), timed the same way; reported beside the bf16 headline."""
+    import torch
+    C, dec, rec = build_models(R, dict(cfg_over, precision="f32"), V)
+    step = R.DataParallelTrainStep(dec, rec, B, 0, 1, n_frames=F)
+    T, w = step.prepare(targets_g.numpy())
+    run = R.GraphedStep(step, enc, targets, T, w)
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del run, step
+    return {"ms_per_step": round(ms, 4), "value": round(B * 1e3 / ms, 1), "unit": "captions/s", "dtype": "f32", "steps": steps, "warmup": warmup,
+            "note": "same workload, precision=f32 (fp32 MFMA operands); the parity path of TOL['f32'] in tests/gpu_util.py"}
 
 
 def main():
@@ -163,6 +183,7 @@ def main():
     ap.add_argument("--frames", type=int, default=28, help="encoder_output_len F (C4: 40)")
     ap.add_argument("--feat", type=int, default=1536, help="encoder_output_size D = reconstructor size (C4: 2048, C5: 3584)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-exact", action="store_true", help="skip the fp32_exact sub-record (the same workload on the exact-fp32 path)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"], help="recurrent cell of decoder and reconstructor "
@@ -200,10 +221,10 @@ def main():
     if args.global_batch:
         B = R.shard_bounds(args.global_batch, world, 0)[1]          # the largest shard sizes the engines
     kind = None if args.rec == "none" else args.rec
-    C, dec, rec = build_models(R, dict(batch_size=B, use_recon=kind is not None, reconstructor_type=kind or "global",
-                                       encoder_output_len=F, encoder_output_size=D, reconstructor_hidden_size=D,
-                                       precision=args.precision, device=str(dev), decoder_model=args.cell,
-                                       reconstructor_model=args.cell), V)
+    cfg_over = dict(batch_size=B, use_recon=kind is not None, reconstructor_type=kind or "global",
+                    encoder_output_len=F, encoder_output_size=D, reconstructor_hidden_size=D,
+                    precision=args.precision, device=str(dev), decoder_model=args.cell, reconstructor_model=args.cell)
+    C, dec, rec = build_models(R, cfg_over, V)
     Bg = args.global_batch if args.global_batch else B * world
     targets_g = synthetic_targets(Bg, V, seed=1234, lengths=args.lengths)
     lo, hi = R.shard_bounds(Bg, world, rank)
@@ -271,11 +292,13 @@ def main():
             if site >= 7:
                 # a chain kernel runs for hundreds of microseconds: bracketed in eager launches of the step (event
                 # records inside a replayed graph can be scheduled long before the node they precede)
-                return eng.profile_site(s_id, one, 5)
+                n_, ms_ = eng.profile_site(s_id, one, 5)
+                return n_ // 5, ms_
             if args.graph and not step.reduce:
                 return eng.profile_site_graph(s_id, one)
             # (never the data-parallel step itself: this runs on rank 0 only, a collective here would wait for ever)
-            return eng.profile_site(s_id, one, 5)
+            n_, ms_ = eng.profile_site(s_id, one, 5)
+            return (n_ // 5 if site > 0 else n_), ms_
         prof = roofline(eng, prof_pass, kind, args.precision, T=T, cell=args.cell)
         # whole-step roofline fractions: algorithmic FLOPs against the dense bf16 MFMA peak and
         # algorithmic HBM bytes (optimiser + inputs) against 8 TB/s; per GPU (every rank does the same work)
@@ -297,6 +320,8 @@ def main():
                        "loss": round(sc["total_loss"], 5)},
             "roofline": prof, "whole_step": whole,
         }
+        if not args.no_fp32_exact and world == 1 and args.precision == "bf16" and not args.feed:
+            out["fp32_exact"] = fp32_exact(R, cfg_over, V, enc, targets, targets_g, B, F)
         if not args.no_cpu_baseline and world == 1:
             v, cores, med = cpu_baseline(kind, B, F, D, V, args.cpu_steps, 1, args.cell)
             out["cpu_baseline"] = {"value": round(v, 2), "unit": "captions/s", "cores": cores, "kind": "port",

@@ -323,6 +323,9 @@ int recnet_chain_reset(recnet_handle* h, int32_t disable_persistent, void* strea
 /* Test hook: what a chain kernel does when it gives up a bounded wait (rec_chain.hpp: rc_give_up) — raises the sticky word
  * of chain `chain_bit` (one of 1, 2, 4, 8, 32, 64) and the poison word, stream-ordered. */
 int recnet_debug_raise_give_up(recnet_handle* h, int32_t chain_bit, void* stream);
+/* Test hook: a kernel of `n_workgroups` workgroups that each take a whole CU (160 KB of LDS) and spin for `microseconds` —
+ * what a resident collective (RCCL) kernel looks like to the persistent chain kernels.  Launch it on another stream. */
+int recnet_debug_occupy(recnet_handle* h, int32_t n_workgroups, int32_t microseconds, void* stream);
 /* Name / start / duration of the dominant kernel's launches inside the last train step are measured
  * by the caller with hipEvents; this returns the ALGORITHMIC bytes of one launch: loop invariants once, every input /
  * saved tensor once.  The step-to-step exchange blocks of a persistent chain kernel are not part of it. */

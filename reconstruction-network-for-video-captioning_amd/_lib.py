@@ -146,3 +146,4 @@ EXPORTS["recnet_dim"] = (_i, [C.c_void_p, _i])
 EXPORTS["recnet_probe_read"] = (_i, [C.c_void_p, C.c_void_p, _i])
 EXPORTS["recnet_debug_poison_lds"] = (_i, [C.c_void_p, C.c_void_p])
 EXPORTS["recnet_debug_raise_give_up"] = (_i, [C.c_void_p, _i, C.c_void_p])
+EXPORTS["recnet_debug_occupy"] = (_i, [C.c_void_p, _i, _i, C.c_void_p])

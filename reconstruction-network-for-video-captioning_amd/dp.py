@@ -19,40 +19,100 @@ def shard_bounds(global_batch, world_size, rank):
 
 
 class GradTransport:
-    """SUM all-reduce of fp32 gradient buffers, optionally carried in bf16 (`dtype="bf16"`): the gradient bucket is as
-    expensive as the compute on xGMI (99-344 MB fp32 per step), bf16 halves the bytes on the wire.
-    The fp32 buffer is rounded once into a bf16 staging buffer, reduced, and widened back; the rounding (2^-9 relative
-    per element) is at the level of the bf16 compute path's own operand rounding.  fp32 is the default and the form the
-    parity tests use."""
+    """SUM all-reduce of fp32 gradient buffers.
 
-    def __init__(self, dtype="f32", group=None):
+    algo "ring" (default for fp32): one `dist.all_reduce` per buffer — RCCL picks the algorithm.
+    algo "direct" ("direct reduce-scatter + all-gather using all 7 links concurrently"): the
+    buffer is cut into world_size chunks; every rank sends chunk r to rank r (`all_to_all_single`: one message per peer,
+    i.e. per xGMI link), sums the world_size copies of its own chunk IN FP32 in rank order, and the reduced chunks are
+    all-gathered.  Bytes per rank and direction: 2 (W-1)/W S like the ring, but spread over all peers at once instead
+    of over one ring neighbour.
+
+    dtype "bf16" halves the bytes on the wire (99-344 MB fp32 per step) and always uses the
+    direct form, so that the accumulation happens in fp32 at the destination: each rank's contribution is rounded to
+    bf16 once (2^-9 relative per element, the level of the bf16 compute path's own operand rounding), the W
+    contributions are summed in fp32, the sum is rounded to bf16 once for the all-gather.  (A plain `all_reduce` of a
+    bf16 buffer would accumulate in bf16 inside RCCL: W - 1 roundings of the running sum.)  Every rank receives the
+    same bytes, so the replicas stay bit-identical.  gloo (CPU tests) has no all_to_all: there the chunks travel by
+    `all_gather` of the staged buffers and the same fp32 rank-order sum is formed locally — same result bit for bit.
+    fp32 ring is the default and the form the parity tests use."""
+
+    def __init__(self, dtype="f32", group=None, algo=None):
         if dtype not in ("f32", "bf16"):
             raise NotImplementedError("gradient transport dtype %r" % dtype)
-        self.dtype, self.group, self._stage = dtype, group, {}
+        algo = algo or ("direct" if dtype == "bf16" else "ring")
+        if algo not in ("ring", "direct"):
+            raise NotImplementedError("gradient transport algorithm %r" % algo)
+        if dtype == "bf16" and algo != "direct":
+            raise NotImplementedError("bf16 transport accumulates in fp32 at the destination: algo='direct'")
+        self.dtype, self.group, self.algo, self._stage, self._side = dtype, group, algo, {}, None
+
+    # ------------------------------------------------------------------ direct reduce-scatter + all-gather
+    def _buffers(self, buf, W):
+        key = (buf.data_ptr(), buf.numel(), W)
+        st = self._stage.get(key)
+        if st is None:
+            wire = torch.bfloat16 if self.dtype == "bf16" else torch.float32
+            chunk = (buf.numel() + W - 1) // W
+            chunk = (chunk + 7) // 8 * 8                      # 16-byte multiples on the wire
+            st = self._stage[key] = dict(chunk=chunk, send=torch.zeros(W * chunk, dtype=wire, device=buf.device),
+                                         recv=torch.empty(W * chunk, dtype=wire, device=buf.device),
+                                         red=torch.empty(chunk, dtype=wire, device=buf.device),
+                                         out=torch.empty(W * chunk, dtype=wire, device=buf.device))
+        return st
+
+    def _start_direct(self, buf):
+        import torch.distributed as dist
+        W = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        st = self._buffers(buf, W)
+        n, chunk = buf.numel(), st["chunk"]
+        cuda = buf.is_cuda
+        if cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=buf.device)
+            self._side.wait_stream(torch.cuda.current_stream(buf.device))
+            ctx = torch.cuda.stream(self._side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            st["send"][:n].copy_(buf)                          # one rounding per rank (bf16 wire) / plain copy (fp32 wire)
+            if dist.get_backend(self.group) == "gloo":
+                parts = [torch.empty_like(st["send"]) for _ in range(W)]
+                dist.all_gather(parts, st["send"], group=self.group)
+                mine = [p[rank * chunk:(rank + 1) * chunk] for p in parts]
+            else:
+                dist.all_to_all_single(st["recv"], st["send"], group=self.group)      # chunk r of every rank -> rank r
+                mine = [st["recv"][r * chunk:(r + 1) * chunk] for r in range(W)]
+            acc = mine[0].float()
+            for r in range(1, W):                              # fp32 accumulation at the destination, rank order
+                acc += mine[r]
+            st["red"].copy_(acc)                               # one rounding of the sum (bf16 wire)
+            work = dist.all_gather_into_tensor(st["out"], st["red"], group=self.group, async_op=True)
+        return (work, buf, st)
 
     def start(self, buf):
         """Launch the collective on `buf` (a contiguous fp32 tensor or slice); returns a token for finish()."""
         import torch.distributed as dist
-        if self.dtype == "f32":
+        if self.algo == "ring":
             return (dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, None)
-        key = (buf.data_ptr(), buf.numel())
-        st = self._stage.get(key)
-        if st is None:
-            st = self._stage[key] = torch.empty(buf.numel(), dtype=torch.bfloat16, device=buf.device)
-        st.copy_(buf)
-        return (dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, st)
+        return self._start_direct(buf)
 
-    @staticmethod
-    def finish(token):
+    def finish(self, token):
         work, buf, st = token
         work.wait()
         if st is not None:
-            buf.copy_(st)
+            if buf.is_cuda and self._side is not None:
+                with torch.cuda.stream(self._side):
+                    work.wait()
+                torch.cuda.current_stream(buf.device).wait_stream(self._side)
+            buf.copy_(st["out"][:buf.numel()])
 
 
-def allreduce_sum_(flat_buffers, group=None, dtype="f32"):
+def allreduce_sum_(flat_buffers, group=None, dtype="f32", algo=None):
     """One collective per flat gradient buffer (reconstructor first: it is ready first)."""
-    tr = GradTransport(dtype, group)
+    tr = GradTransport(dtype, group, algo)
     for tok in [tr.start(t) for t in flat_buffers]:
         tr.finish(tok)
 
@@ -61,14 +121,14 @@ class DataParallelTrainStep:
     """Wraps api.TrainStep for world_size ranks.  Each rank owns captions [lo, hi) of the global batch."""
 
     def __init__(self, decoder, reconstructor, global_batch, rank, world_size, n_frames=None, group=None,
-                 always_reduce=False, grad_dtype="f32"):
+                 always_reduce=False, grad_dtype="f32", grad_algo=None):
         import os
         from .api import TrainStep
         if world_size > 1:
             # RCCL's kernel of the reconstructor bucket is resident while the decoder's BPTT chain kernel runs: keep
             # that many CUs out of the chain kernel's residency check (csrc/api.hip: RN_RESERVE_CUS)
             os.environ.setdefault("RN_RESERVE_CUS", "64")
-        self.transport = GradTransport(grad_dtype, group)
+        self.transport = GradTransport(grad_dtype, group, grad_algo)
         self.rank, self.world = rank, world_size
         # reduce even with one rank (exercises the collective path under torchrun --nproc-per-node 1)
         self.reduce = world_size > 1 or always_reduce

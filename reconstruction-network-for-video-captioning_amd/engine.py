@@ -272,6 +272,11 @@ class Engine:
         """Test hook: raise chain `chain_bit`'s sticky word and the poison word the way a chain kernel that gives up does."""
         _lib.check(self.lib.recnet_debug_raise_give_up(self.handle, int(chain_bit), _stream()), "recnet_debug_raise_give_up")
 
+    def debug_occupy(self, n_workgroups, microseconds, stream=None):
+        """Test hook: n_workgroups CU-filling workgroups spinning for `microseconds` on `stream` (a torch stream; default: the current one)."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+        _lib.check(self.lib.recnet_debug_occupy(self.handle, int(n_workgroups), int(microseconds), st), "recnet_debug_occupy")
+
     def chain_reset(self, disable_persistent=True):
         _lib.check(self.lib.recnet_chain_reset(self.handle, int(bool(disable_persistent)), _stream()), "recnet_chain_reset")
 

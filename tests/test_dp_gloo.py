@@ -62,7 +62,7 @@ def _shard_grads(kind, decP, recP, enc, targets, lo, hi):
     return flat
 
 
-def _worker(rank, world, port, kind, out, B=None, dtype="f32"):
+def _worker(rank, world, port, kind, out, B=None, dtype="f32", algo=None, out2=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -71,9 +71,12 @@ def _worker(rank, world, port, kind, out, B=None, dtype="f32"):
     lo, hi = R.shard_bounds(B or DIMS["B"], world, rank)
     flat = _shard_grads(kind, decP, recP, enc, targets, lo, hi)
     from recnet_amd.dp import allreduce_sum_
-    allreduce_sum_(list(reversed(flat)), dtype=dtype)    # reconstructor bucket first, as on the GPU path
+    mine = [f.clone() for f in flat]
+    allreduce_sum_(list(reversed(flat)), dtype=dtype, algo=algo)    # reconstructor bucket first, as on the GPU path
     if rank == 0:
         out.put([f.numpy() for f in flat])
+    if out2 is not None:
+        out2.put((rank, [f.numpy() for f in mine], [f.numpy() for f in flat]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -111,14 +114,17 @@ def test_two_rank_gradients_equal_full_batch(kind):
     assert np.linalg.norm(ref[0].numpy() - full) <= 2e-6 * np.linalg.norm(full)
 
 
-def _run(world, kind, B=None, dtype="f32"):
+def _run(world, kind, B=None, dtype="f32", algo=None, per_rank=None):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
+    out2 = ctx.Queue() if per_rank is not None else None
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, out, B, dtype)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, out, B, dtype, algo, out2)) for r in range(world)]
     for p in procs:
         p.start()
     got = out.get(timeout=300)
+    if per_rank is not None:
+        per_rank.extend(sorted((out2.get(timeout=300) for _ in range(world)), key=lambda x: x[0]))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -139,3 +145,34 @@ def test_bf16_gradient_transport_stays_inside_the_bf16_parity_bar():
     got, ref = _run(2, "global", dtype="bf16")
     for a, b in zip(got, ref):
         assert 1e-5 < np.linalg.norm(a - b) / np.linalg.norm(b) <= 6e-3        # rounded once per rank, 2^-9 per element
+
+
+def test_bf16_transport_at_world_size_8_accumulates_in_fp32_at_the_destination():
+    """a bf16 `all_reduce` accumulates in bf16 inside the collective (7 roundings of the running sum at
+    8 ranks).  The direct transport (dp.GradTransport, algo "direct") rounds each rank's contribution once, sums the 8
+    contributions in fp32 and rounds the sum once — checked here against exactly that arithmetic, redone in numpy from
+    the per-rank gradients, bit for bit; and every rank ends with the same bytes."""
+    per_rank = []
+    got, ref = _run(8, "local", B=100, dtype="bf16", per_rank=per_rank)
+    to_bf16 = lambda a: torch.from_numpy(a).to(torch.bfloat16)
+    for i in range(len(got)):
+        acc = to_bf16(per_rank[0][1][i]).float()
+        for r in range(1, 8):
+            acc += to_bf16(per_rank[r][1][i]).float()
+        want = acc.to(torch.bfloat16).float().numpy()
+        for r in range(8):
+            assert np.array_equal(per_rank[r][2][i], want), (i, r)          # bit-identical replicas, fp32 accumulation
+        rel = np.linalg.norm(got[i] - ref[i]) / np.linalg.norm(ref[i])
+        assert 1e-5 < rel <= 6e-3, rel
+        # what an in-collective bf16 accumulation would have produced is measurably worse
+        run = to_bf16(per_rank[0][1][i])
+        for r in range(1, 8):
+            run = (run.float() + to_bf16(per_rank[r][1][i]).float()).to(torch.bfloat16)
+        rel_ring = np.linalg.norm(run.float().numpy() - ref[i]) / np.linalg.norm(ref[i])
+        assert rel < rel_ring, (rel, rel_ring)
+
+
+def test_direct_fp32_transport_equals_the_full_batch_at_world_size_8():
+    got, ref = _run(8, "global", B=100, dtype="f32", algo="direct")
+    for a, b in zip(got, ref):
+        assert np.linalg.norm(a - b) <= 3e-6 * np.linalg.norm(b)

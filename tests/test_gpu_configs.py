@@ -98,3 +98,70 @@ def test_full_size_step_matches_oracle_elementwise(case, prec):
         name, prec, sc["dec_ce"], ref["ce"], sc["rec_mse"], ref["mse"], max(v[0] for v in worst.values()),
         max(worst, key=lambda k: worst[k][0])))
     assert not bad, (name, prec, bad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ALL eight shards of C4 / C5: the tests above hold ONE rank's shard against the oracle; an offset
+# or normaliser bug that only shows on another rank would pass them.  Here the 8 per-rank steps run one after the other
+# on this GPU (each with its own caption offset, the global normalisers and the global caption index in the dropout
+# masks), their gradients are summed — what the SUM all-reduce does — and the sum is held against the oracle's
+# gradients of the WHOLE batch of 256 / 512 captions (train.py:17-131 on the full batch, regulariser aside: it is
+# applied once after the reduction, and its float32-norm problem is described above).
+ALL_SHARDS = {"C4": ("local", 40, 2048, 256), "C5": ("local", 28, 3584, 512)}
+
+
+@pytest.fixture(scope="module", params=list(ALL_SHARDS))
+def full_batch_case(request):
+    name = request.param
+    kind, F, D, Bg = ALL_SHARDS[name]
+    torch.set_num_threads(min(32, torch.get_num_threads() * 4))
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 31)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 32)
+    tg_g = synthetic_targets(Bg, V, seed=77)
+    enc_g = synthetic_features(Bg, F, D, seed=79)
+    st = O.TrainState(decP, recP, kind)
+    drop = O.Dropper("hash", seed=5, B_global=Bg, b_offset=0)
+    dl, hid, _, ce, _ = O.forward_decoder(st.dec, enc_g, tg_g, tg_g > 0, drop=drop, lambda_reg=0.0, return_parts=True)
+    rl, mse, _ = O.forward_local_reconstructor(st.rec, hid, enc_g, drop=drop, lambda_reg=0.0, return_parts=True)
+    (dl + rl).backward()
+    ref = dict(ce=float(ce.detach()), mse=float(mse.detach()), dec={k: v.grad.numpy() for k, v in st.dec.items()},
+               rec={k: v.grad.numpy() for k, v in st.rec.items()})
+    return name, decP, recP, enc_g, tg_g, ref
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+def test_all_eight_shards_sum_to_the_full_batch(full_batch_case, prec):
+    name, decP, recP, enc_g, tg_g, ref = full_batch_case
+    kind, F, D, Bg = ALL_SHARDS[name]
+    if prec == "f32" and name == "C5":
+        pytest.skip("C5's exact-fp32 shard is covered by test_full_size_step_matches_oracle_elementwise; 8 of them take minutes")
+    world = 8
+    acc, ce, mse = None, 0.0, 0.0
+    dec = rec = None
+    for rank in range(world):
+        lo, hi = R.shard_bounds(Bg, world, rank)
+        if dec is None:
+            _, dec, rec = make_models([hi - lo, F, D, V, E, H, A, RA], kind, prec, decP, recP)
+        step = R.TrainStep(dec, rec, batch_size=hi - lo, n_frames=F, global_batch=Bg, batch_offset=lo)
+        T, w = step.prepare(tg_g.numpy())
+        step.fwd_bwd(enc_g[lo:hi].cuda(), tg_g[:, lo:hi].contiguous().cuda(), T, w, seed=5)
+        torch.cuda.synchronize()
+        assert step.engine.chain_status() == 0
+        sc = step.engine.scalar_dict()
+        ce += sc["dec_ce"]; mse += sc["rec_mse"]
+        g = {grp: {k: v.double().cpu().numpy() for k, v in md["_state"].flat()["grad"].views.items()} for grp, md in (("dec", dec), ("rec", rec))}
+        if acc is None:
+            acc = g
+        else:
+            for grp in g:
+                for k in g[grp]:
+                    acc[grp][k] += g[grp][k]
+        del step
+    tol = TOL[prec]
+    assert abs(ce - ref["ce"]) <= tol["loss"] * abs(ref["ce"]), (name, prec, ce, ref["ce"])
+    assert abs(mse - ref["mse"]) <= tol["loss"] * abs(ref["mse"]), (name, prec, mse, ref["mse"])
+    worst = {grp + "." + k: (rel_err(acc[grp][k], ref[grp][k]), cosine(acc[grp][k], ref[grp][k])) for grp in acc for k in acc[grp]}
+    bad = {k: v for k, v in worst.items() if v[0] > tol["grad"] or v[1] < tol["cos"]}
+    print("%s %s all shards: ce %.6f/%.6f mse %.6f/%.6f worst grad rel err %.2e (%s)" % (
+        name, prec, ce, ref["ce"], mse, ref["mse"], max(v[0] for v in worst.values()), max(worst, key=lambda k: worst[k][0])))
+    assert not bad, (name, prec, bad)

@@ -1,0 +1,148 @@
+"""First-contact checks of the multi-GPU path on ONE GPU — what the driver's 8-GPU scaling run
+would otherwise be the first to execute:
+
+  * the real data-parallel step — three hipGraphs with the gradient collectives between them (api.GraphedStep) — on the
+    RCCL backend ("nccl") with world size 1, for the global and the local reconstructor and every gradient transport,
+    against the one-graph single-rank step;
+  * co-residency of the decoder's BPTT chain kernel with a resident "collective" kernel (recnet_debug_occupy: CU-filling
+    workgroups spinning on a second stream): with the CU reserve dp.py sets (RN_RESERVE_CUS=64) the chain is not
+    disturbed; with MORE CUs taken than the chain can spare it waits — bounded — until they free up, and completes with
+    the same gradients and no give-up.
+Reference semantics: train.py:248-273 (one optimiser step), SURVEY.md section 8e."""
+import os
+import socket
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# a shape every persistent chain kernel takes (H % 32, R % 32, B <= 112) so that the BPTT chain really is the persistent launch
+DIMS = [24, 6, 64, 61, 16, 32, 16, 16]
+LENS = [5, 2, 7, 3, 1, 4, 9, 6] * 3
+
+
+def _models(kind, prec):
+    import recnet_amd as R
+    from tests import golden_util as GU
+    from tests.gpu_util import make_models
+    B, F, D, V, E, H, A, RA = DIMS
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 3)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 4)
+    enc, targets = GU.make_batch(B, F, D, V, LENS, 9)
+    C, dec, rec = make_models(list(DIMS), kind, prec, decP, recP, device="cuda:0")
+    return R, dec, rec, enc, targets
+
+
+def _worker_nccl(port, kind, prec, grad_dtype, grad_algo, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    R, dec, rec, enc, targets = _models(kind, prec)
+    step = R.DataParallelTrainStep(dec, rec, DIMS[0], 0, 1, n_frames=DIMS[1], always_reduce=True, grad_dtype=grad_dtype,
+                                   grad_algo=grad_algo)
+    T, w = step.prepare(targets.numpy())
+    run = R.GraphedStep(step, enc.cuda(), targets.cuda(), T, w, warmup=1)
+    assert run.split and len(run.graphs) == 3
+    for _ in range(2):
+        sc = run()
+    torch.cuda.synchronize()
+    st = step.step_impl.engine.chain_status()
+    q.put((sc.cpu().numpy(), {k: v.detach().cpu().numpy() for k, v in dec["model"].state_dict().items()},
+           {k: v.detach().cpu().numpy() for k, v in rec["model"].state_dict().items()}, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grad_dtype,grad_algo", [("f32", None), ("f32", "direct"), ("bf16", None)])
+@pytest.mark.parametrize("kind,prec", [("global", "bf16"), ("local", "bf16"), ("global", "f32")])
+def test_three_graph_step_on_rccl_world_size_one_matches_the_one_graph_step(kind, prec, grad_dtype, grad_algo):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl, args=(port, kind, prec, grad_dtype, grad_algo, q))
+    p.start()
+    sc3, dec3, rec3, status = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and status == 0
+    # the single-rank step: one graph, no collective
+    R, dec, rec, enc, targets = _models(kind, prec)
+    step = R.DataParallelTrainStep(dec, rec, DIMS[0], 0, 1, n_frames=DIMS[1])
+    T, w = step.prepare(targets.numpy())
+    run = R.GraphedStep(step, enc.cuda(), targets.cuda(), T, w, warmup=1)
+    assert not run.split and len(run.graphs) == 1
+    for _ in range(2):
+        sc1 = run()
+    torch.cuda.synchronize()
+    sc1 = sc1.cpu().numpy()
+    for i in (0, 3, 6):
+        assert abs(sc3[i] - sc1[i]) <= 2e-6 * max(abs(sc1[i]), 1e-3), (i, sc3[i], sc1[i])
+    # 3 Adam steps of lr 1e-5: fp32 transport reproduces the one-graph parameters to fp32 rounding; bf16 transport rounds
+    # the gradients to 2^-9, which can flip the sign of a near-zero first-step update (2 * lr)
+    tol = 2e-6 if grad_dtype == "f32" else 6e-5
+    for k, v in dec["model"].state_dict().items():
+        assert np.abs(dec3[k] - v.cpu().numpy()).max() <= tol, (k, np.abs(dec3[k] - v.cpu().numpy()).max())
+    for k, v in rec["model"].state_dict().items():
+        assert np.abs(rec3[k] - v.cpu().numpy()).max() <= tol, (k, np.abs(rec3[k] - v.cpu().numpy()).max())
+
+
+def _grads(md):
+    return {k: v.detach().clone() for k, v in md["_state"].flat()["grad"].views.items()}
+
+
+def _bptt_beside(occupy_cus, occupy_us, reserve):
+    """One train step as its two data-parallel parts; the second part (decoder BPTT chain + deferred gradients) runs while
+    `occupy_cus` CU-filling workgroups spin on a side stream.  Returns (gradients, chain status, ms of part 2)."""
+    os.environ["RN_RESERVE_CUS"] = str(reserve)
+    try:
+        R, dec, rec, enc, targets = _models("global", "bf16")
+        step = R.TrainStep(dec, rec)
+    finally:
+        os.environ.pop("RN_RESERVE_CUS", None)
+    eng = step.engine
+    T, w = step.prepare(targets.numpy())
+    e, t = enc.cuda(), targets.cuda()
+    side = torch.cuda.Stream()
+    out = None
+    for it in range(2):                       # first pass warms the modules up
+        eng.set_step(1)
+        eng.train_step_part_dev(1, e, t, T, w, 7)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if occupy_cus:
+            eng.debug_occupy(occupy_cus, occupy_us, stream=side)
+            time.sleep(0.002 if occupy_us >= 4000 else 0.0003)     # let the occupier become resident first
+        ev0.record()
+        eng.train_step_part_dev(2, e, t, T, w, 7)
+        ev1.record()
+        torch.cuda.synchronize()
+        out = ({"dec": _grads(dec), "rec": _grads(rec)}, eng.chain_status(), ev0.elapsed_time(ev1))
+    return out
+
+
+def test_bptt_chain_beside_a_resident_collective_kernel():
+    from tests.gpu_util import rel_err
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    g0, st0, ms0 = _bptt_beside(0, 0, 64)
+    assert st0 == 0
+    # (1) what dp.py arranges: 64 CUs held by the "collective" for 6 ms, the chain's residency check reserved them
+    g1, st1, ms1 = _bptt_beside(64, 6000, 64)
+    assert st1 == 0, "chain gave up beside a 64-CU resident kernel (status 0x%x)" % st1
+    for grp in g0:
+        for k in g0[grp]:
+            assert rel_err(g1[grp][k].cpu().numpy(), g0[grp][k].cpu().numpy()) <= 1e-6, (grp, k)
+    assert ms1 < 3.0, "the chain waited for the 6 ms occupier although 64 CUs were reserved for it: %.2f ms" % ms1
+    # (2) no reserve and MORE CUs taken than the chain can spare (it needs ~H/16*4+1 of them; all but 16 are held for 6 ms):
+    # the resident part of the chain spins — bounded — until the occupier leaves, then the step completes, same gradients
+    g2, st2, ms2 = _bptt_beside(ncu - 16, 6000, 0)
+    assert st2 == 0, "chain gave up instead of waiting for the CUs to free up (status 0x%x)" % st2
+    for grp in g0:
+        for k in g0[grp]:
+            assert rel_err(g2[grp][k].cpu().numpy(), g0[grp][k].cpu().numpy()) <= 1e-6, (grp, k)
+    assert ms2 > 3.0, "the occupier did not overlap the chain (%.2f ms): the test did not exercise the wait" % ms2
+    print("BPTT part alone %.2f ms, beside 64 reserved CUs %.2f ms, waiting for %d CUs %.2f ms" % (ms0, ms1, ncu - 16, ms2))
