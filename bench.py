@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the fp32_exact sub-record (the same workload on the exact-fp32 path)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--defer", type=int, default=0, help="1: deferred reconstructor update (one rank, graph mode, global reconstructor): the "
+                    "update of step n runs under the decoder forward chain of step n + 1; flushed inside the timed region.  Measured "
+                    "slower (2.34 against 1.95 ms at C2, DESIGN.md section 5): not the default")
     ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"], help="recurrent cell of decoder and reconstructor "
                     "(the north-star workload is LSTM; GRU is config.py:31's literal default)")
     ap.add_argument("--lengths", default="uniform", choices=["uniform", "msvd"], help="caption lengths: the benchmark's "
@@ -241,8 +244,11 @@ def main():
             torch.cuda.synchronize()
 
     runner = lambda: step(enc, targets, T, w)
+    graphed = None
     if args.graph:
-        runner = R.GraphedStep(step, enc, targets, T, w)
+        # one rank: the reconstructor's weight-gradient products + Adam step of replay n run under the decoder forward
+        # chain of replay n + 1 (api.GraphedStep: defer_reconstructor_update); the last one is flushed INSIDE the timed region
+        runner = graphed = R.GraphedStep(step, enc, targets, T, w, defer_reconstructor_update=bool(args.defer))
     if args.feed:
         # PCIe-inclusive variant: host batches -> pinned staging -> H2D (side stream) -> the step's input buffers
         import itertools
@@ -263,6 +269,8 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         runner()
+    if graphed is not None:
+        graphed.flush()                                 # every timed step's optimiser work is inside the timed region
     ev1.record()
     sync_all()
     el = time.perf_counter() - t0
@@ -316,7 +324,7 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
                                    "D=R=%d, V=4188, E=468, H=512, A=128, T=%d, dropout 0.5, %s cells" % (args.rec, hi - lo, F, D, T, args.cell),
-                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "deferred_reconstructor_update": bool(graphed is not None and graphed.deferred), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
                        "loss": round(sc["total_loss"], 5)},
             "roofline": prof, "whole_step": whole,
         }

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RECNET_ABI_VERSION 4
+#define RECNET_ABI_VERSION 5
 #define RECNET_ATTN_NONE 0
 #define RECNET_ATTN_SOFTMAX 1
 #define RECNET_OK 0
@@ -252,6 +252,21 @@ int recnet_train_step_fwd_bwd_dev(recnet_handle* h, const float* enc, const int6
 int recnet_train_step_part_dev(recnet_handle* h, int32_t part, const float* enc, const int64_t* targets, int32_t T,
                                const float* step_weight, uint32_t seed_base, recnet_scalars* scalars, void* stream);
 int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* scalars, void* stream);
+/* Deferred reconstructor update (opt-in; the fused single-rank step recnet_train_step[_dev] only).  train.py:272-273 steps
+ * the two optimisers one after the other at the end of an iteration; nothing reads the reconstructor's parameters again
+ * before the NEXT iteration's reconstructor forward (train.py:256).  With on != 0 a fused step therefore leaves the
+ * reconstructor's weight-gradient products + Adam update PENDING (its gate gradients and saved activations stay in the
+ * workspace), and the next fused step runs them on a third stream under its decoder forward chain — CUs that chain leaves
+ * idle — instead of under / behind this step's decoder BPTT.  Same arithmetic in the same order: parameters after
+ * recnet_flush are bit-identical to the non-deferred step's.  recnet_flush completes a pending update on `stream` (a no-op
+ * on the device when nothing is pending); every other entry point of the handle that reads the reconstructor's parameters,
+ * gradients or Adam state flushes first, callers that read them through their own pointers (state_dict, checkpoints)
+ * call recnet_flush themselves. */
+int recnet_set_deferred_reconstructor_update(recnet_handle* h, int32_t on, void* stream);
+int recnet_flush(recnet_handle* h, void* stream);
+/* A hipGraph that captured a deferred fused step was replayed (replays run no host code): tells the handle that an update
+ * may be pending, so that its other entry points flush before they touch the reconstructor. */
+int recnet_mark_pending(recnet_handle* h);
 
 /* ---- plumbing exposed for tests and profiling */
 /* Between begin and end every recurrent-step GEMM launch of one site (the dependent-chain kernels: one

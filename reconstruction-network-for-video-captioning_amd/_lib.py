@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RN_LIB_PROBE=1: the probe build (in-kernel time stamps); RN_LIB_VARIANT=acqinv: the cross-check build with acquire fences
 _VARIANT = "_probe" if os.environ.get("RN_LIB_PROBE") == "1" else ("_" + os.environ["RN_LIB_VARIANT"] if os.environ.get("RN_LIB_VARIANT") else "")
 LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip%s.so" % _VARIANT)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 REC_NONE, REC_GLOBAL, REC_LOCAL = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
@@ -147,3 +147,6 @@ EXPORTS["recnet_probe_read"] = (_i, [C.c_void_p, C.c_void_p, _i])
 EXPORTS["recnet_debug_poison_lds"] = (_i, [C.c_void_p, C.c_void_p])
 EXPORTS["recnet_debug_raise_give_up"] = (_i, [C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_debug_occupy"] = (_i, [C.c_void_p, _i, _i, C.c_void_p])
+EXPORTS["recnet_set_deferred_reconstructor_update"] = (_i, [C.c_void_p, _i, C.c_void_p])
+EXPORTS["recnet_flush"] = (_i, [C.c_void_p, C.c_void_p])
+EXPORTS["recnet_mark_pending"] = (_i, [C.c_void_p])

@@ -497,7 +497,13 @@ class GraphedStep:
         all-reduce(rest of the decoder bucket)  ->  wait all  ->  graph C (regulariser, clip, Adam, re-pack)
     so only the all-reduce of the decoder's recurrent / attention / embedding gradients is exposed."""
 
-    def __init__(self, dp_step, enc, targets, T, step_weight, warmup=2):
+    def __init__(self, dp_step, enc, targets, T, step_weight, warmup=2, defer_reconstructor_update=False):
+        """defer_reconstructor_update (one rank, global reconstructor; opt-in — measured slower at the benchmark shape, see
+        DESIGN.md section 5): every replay leaves the reconstructor's weight-gradient products and
+        Adam step pending and the NEXT replay runs them under its decoder forward chain (recnet_hip.h:
+        recnet_set_deferred_reconstructor_update).  Call flush() before reading the reconstructor's parameters,
+        gradients or optimiser state from Python (state_dict, checkpoints, evaluation); parameters after flush() are
+        bit-identical to the non-deferred step's."""
         self.dp = dp_step
         st = dp_step.step_impl
         self.eng = st.engine
@@ -508,6 +514,9 @@ class GraphedStep:
         self.flags = _lib.OPT_REG | _lib.OPT_CLIP
         self.split = bool(dp_step.reduce)
         eng = self.eng
+        self.deferred = (bool(defer_reconstructor_update) and not self.split and self.rs is not None and
+                         st.reconstructor["model"].kind == "global")
+        eng.set_deferred_reconstructor_update(self.deferred)
         eng.set_step(self.ms.step)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -535,6 +544,10 @@ class GraphedStep:
             with torch.cuda.graph(g, **mode):
                 eng.optimizer_step_dev(self.flags)
             self.graphs.append(g)
+
+    def flush(self):
+        """Completes a pending deferred reconstructor update (stream-ordered, no host sync); a no-op otherwise."""
+        self.eng.flush()
 
     def _reduce_async(self, bufs):
         return [self.dp.transport.start(b) for b in bufs]
@@ -564,6 +577,8 @@ class GraphedStep:
     def __call__(self):
         if not self.split:
             self.graphs[0].replay()
+            if self.deferred:
+                self.eng.mark_pending()
         else:
             ga, gb, gc = self.graphs
             ga.replay()

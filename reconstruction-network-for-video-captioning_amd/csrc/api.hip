@@ -97,6 +97,9 @@ struct recnet_handle {
   int side_pending = 0, side_T = 0, side_phase = 0, side_err = 0;   // side_after_decoder_fwd (abi_step.inc)
   const int64_t* side_targets = nullptr; const float* side_stepw = nullptr; const float* side_enc = nullptr;
   int late_join = 0;
+  // deferred reconstructor update (recnet_set_deferred_reconstructor_update): ctrl[2] on the device says whether an update is
+  // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
+  int defer_rec = 0, defer_now = 0, defer_err = 0, maybe_pending = 0, def_rows = 0, defer_flags = 3; hipStream_t s3 = nullptr; float* gws3 = nullptr;
   int mp_done = 0;          // h->mp holds the mean-pooled decoder states of the last decoder forward (dec_chain_kernel)
   int ncu = 0;
   int ctx_done = 0;         // the attended features of all steps were computed early (fwd_bwd_impl)
@@ -193,6 +196,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->gws_floats = (size_t)16 << 20;   // 64 MiB of split-K slabs for the batched GEMMs
   h->gws = take(h->gws_floats);
   h->gws2 = take(h->gws_floats);
+  h->gws3 = take(h->gws_floats);
   {
     const size_t W = 8;
     h->sr_logits = take(B * V); h->sr_scores = take(W * B * V);
@@ -367,6 +371,7 @@ void recnet_destroy(recnet_handle* h) {
   for (auto e : h->prof_ev) hipEventDestroy(e);
   for (int i = 0; i < 16; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
   if (h->s2) hipStreamDestroy(h->s2);
+  if (h->s3) hipStreamDestroy(h->s3);
   delete h;
 }
 
@@ -434,6 +439,9 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   if (((uintptr_t)workspace) % 256) return fail(RECNET_EINVAL, "workspace must be 256-byte aligned");
   h->ws = (char*)workspace; h->ws_bytes = bytes;
   carve(h, h->ws);
+  // everything starts from zero: operand rows a step does not write (time steps beyond its T) are read — against zero
+  // gradients — by the fixed-shape products of a deferred reconstructor update, and 0 x NaN bit patterns would not be 0
+  HIPCHK(hipMemset(h->ws, 0, h->need));
   // stamped exchange buffers and the launch-epoch words start from zero (a stamp is never zero)
   HIPCHK(hipMemset(h->gbar, 0, (4096 + 64) * 4)); HIPCHK(hipMemset(h->scal, 0, 64 * 4)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
   HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * 4));
@@ -449,6 +457,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
       HIPCHK(hipStreamCreateWithPriority(&h->s2, hipStreamNonBlocking, lo));
     else
       HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
     for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
   }
   h->fwd_dec_done = h->fwd_rec_done = h->rec_bwd_done = 0;
@@ -546,8 +555,22 @@ int recnet_bind_reconstructor(recnet_handle* h, const recnet_reconstructor_tenso
 // ================================================================================================
 extern "C" {
 
+// A pending deferred reconstructor update (recnet_set_deferred_reconstructor_update) is completed before anything else
+// reads the reconstructor's parameters, packed images, gradients or Adam state.
+static int flush_pending(recnet_handle* h, hipStream_t st, int explicit_call = 0) {
+  // maybe_pending is the host's shadow of the device's pending word: set when a deferred step is enqueued or captured, and
+  // by recnet_mark_pending when a captured one is replayed.  An explicit recnet_flush also runs while the mode is on (the
+  // device word decides whether the Adam step happens; the products are recomputed from the step's own operands either way).
+  if (!h->maybe_pending && !(explicit_call && h->defer_rec)) return RECNET_OK;
+  h->maybe_pending = 0;
+  if (h->kind == RECNET_REC_NONE || !h->og[1].bound || !h->og[1].tab[0].m) return RECNET_OK;
+  return rec_pending_update(h, st, 0, h->defer_flags);
+}
+#define FLUSH_PENDING(h, st) do { int fr_ = flush_pending(h, (hipStream_t)(st)); if (fr_) return fr_; } while (0)
+
 int recnet_pack_weights(recnet_handle* h, void* stream) {
   REQUIRE_WS(h);
+  FLUSH_PENDING(h, stream);
   int r = pack_weights(h, (hipStream_t)stream); if (r) return r;
   LAUNCH_OK();
   return RECNET_OK;

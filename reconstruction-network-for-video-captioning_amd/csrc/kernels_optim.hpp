@@ -105,14 +105,18 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
                                                          AdamHyper hp, const float* __restrict__ pnorm,
                                                          const float* __restrict__ clip, const int32_t* __restrict__ step_ptr,
                                                          const PackDesc* __restrict__ pack, int lp,
-                                                         const float* __restrict__ poison) {
+                                                         const float* __restrict__ poison,
+                                                         const uint32_t* __restrict__ pending = nullptr, int step_off = 0) {
   // A persistent chain kernel of this step gave up waiting (rec_chain.hpp: rc_give_up) and marked the step: its gradients
   // are garbage, so parameters, moments and the packed images stay as they are (the host sees the flag through
   // recnet_chain_status and the NaN total loss).
   if (poison && *poison != 0.f) return;
+  // deferred reconstructor update (recnet_flush / the next fused step): nothing to do unless a step left one pending;
+  // step_off = -1 when the step counter has already been advanced for the step this launch runs beside
+  if (pending && *pending == 0u) return;
   __shared__ float sc[2];
   if (threadIdx.x == 0) {
-    const double st = (double)(*step_ptr);
+    const double st = (double)(*step_ptr + step_off);
     const double bc1 = 1.0 - pow(hp.beta1, st);
     const double bc2 = 1.0 - pow(hp.beta2, st);
     sc[0] = (float)(hp.lr / bc1);

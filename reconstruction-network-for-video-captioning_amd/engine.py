@@ -272,6 +272,18 @@ class Engine:
         """Test hook: raise chain `chain_bit`'s sticky word and the poison word the way a chain kernel that gives up does."""
         _lib.check(self.lib.recnet_debug_raise_give_up(self.handle, int(chain_bit), _stream()), "recnet_debug_raise_give_up")
 
+    def set_deferred_reconstructor_update(self, on):
+        """Opt in to / out of the deferred reconstructor update of the fused step (include/recnet_hip.h); completes a
+        pending update first."""
+        _lib.check(self.lib.recnet_set_deferred_reconstructor_update(self.handle, int(bool(on)), _stream()), "recnet_set_deferred_reconstructor_update")
+
+    def mark_pending(self):
+        _lib.check(self.lib.recnet_mark_pending(self.handle), "recnet_mark_pending")
+
+    def flush(self):
+        """Completes a pending deferred reconstructor update on the current stream (stream-ordered; no host sync)."""
+        _lib.check(self.lib.recnet_flush(self.handle, _stream()), "recnet_flush")
+
     def debug_occupy(self, n_workgroups, microseconds, stream=None):
         """Test hook: n_workgroups CU-filling workgroups spinning for `microseconds` on `stream` (a torch stream; default: the current one)."""
         st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()

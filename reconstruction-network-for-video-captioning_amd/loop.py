@@ -26,22 +26,32 @@ from .search import beam_search, greedy_search
 class Trainer:
     """decoder / reconstructor dicts as train.py:222-225 builds them, plus the step machinery."""
 
-    def __init__(self, C, n_vocabs, rank=0, world_size=1, group=None, use_graphs=True, eager_steps=2):
+    def __init__(self, C, n_vocabs, rank=0, world_size=1, group=None, use_graphs=True, eager_steps=2,
+                 defer_reconstructor_update=False):
         self.C, self.rank, self.world = C, rank, world_size
         self.decoder = build_decoder(n_vocabs, C)
         self.reconstructor = build_reconstructor(C) if C.use_recon else None
         self.global_batch = C.batch_size
         self.dp = DataParallelTrainStep(self.decoder, self.reconstructor, self.global_batch, rank, world_size, group=group)
         self.use_graphs, self.eager_steps = use_graphs, eager_steps
+        # opt-in (measured slower at the benchmark shape, DESIGN.md section 5): graph steps on one rank leave the
+        # reconstructor's update pending for the next step to run under its decoder forward chain (api.GraphedStep);
+        # flush() completes it wherever the parameters are read (validation, checkpoints, the end of fit)
+        self.defer = bool(defer_reconstructor_update) and world_size == 1 and use_graphs and self.reconstructor is not None
         self._graphs, self._static = {}, None
         self.iteration = 0
         self._eager_until = eager_steps       # optimiser step count up to which steps are launched eagerly
+
+    def flush(self):
+        """Completes a pending deferred reconstructor update (stream-ordered; a no-op when there is none)."""
+        self.dp.step_impl.engine.flush()
 
     def resume(self, path):
         """Continue a run from a checkpoint written by `fit` (or by the reference's train.py:398-420): parameters, Adam
         state, step count and iteration are restored, the packed operand images of every bound engine are refreshed
         (checkpoint.load_checkpoint), captured graphs are dropped and the next `eager_steps` steps run eagerly again
         (module loading, RCCL set-up) before a graph is captured."""
+        self.flush()
         ckpt = load_checkpoint(path, self.decoder, self.reconstructor)
         self.iteration = int(ckpt.get("iteration", self.decoder["_state"].step))
         self._graphs.clear()
@@ -109,7 +119,8 @@ class Trainer:
         senc.copy_(enc); stg.copy_(targets)
         g = self._graphs.get(T)
         if g is None:                                  # one graph per loop length T (<= 31 of them)
-            g = self._graphs[T] = (GraphedStep(self.dp, senc, stg, T, torch.empty_like(w), warmup=0))
+            g = self._graphs[T] = (GraphedStep(self.dp, senc, stg, T, torch.empty_like(w), warmup=0,
+                                               defer_reconstructor_update=self.defer))
         g.w.copy_(w)
         return g()
 
@@ -118,6 +129,7 @@ class Trainer:
     def validate(self, batches, idx2word=None):
         """batches: host (enc, targets) pairs of the GLOBAL batch size; single-rank evaluation of full batches."""
         C, dec, rec = self.C, self.decoder, self.reconstructor
+        self.flush()
         dec["model"].eval()
         if rec:
             rec["model"].eval()
@@ -184,6 +196,7 @@ class Trainer:
                 if not checked:
                     self.check_health(sc); checked = True   # never write weights of a step that went wrong
                 gl = self.global_scalars(sc)           # collective under data parallelism: every rank
+                self.flush()
                 if self.rank == 0:
                     os.makedirs(save_dpath, exist_ok=True)
                     save_checkpoint(os.path.join(save_dpath, "{}_checkpoint.tar".format(it)), it, self.decoder,
@@ -193,6 +206,7 @@ class Trainer:
                 self.check_health(sc)
             if it >= n_iterations:
                 break
+        self.flush()
         return hist
 
 

@@ -1,0 +1,132 @@
+"""The deferred reconstructor update of the fused step (include/recnet_hip.h: recnet_set_deferred_reconstructor_update;
+api.GraphedStep(defer_reconstructor_update=True)): step n leaves the reconstructor's weight-gradient products and Adam step
+pending, step n + 1 runs them on a third stream under its decoder forward chain.  train.py:272-273 steps the two optimisers
+at the end of the iteration; nothing reads the reconstructor's parameters before the next iteration's reconstructor
+forward (train.py:256), so the result has to be — and is held to be — BIT-IDENTICAL to the non-deferred step's once
+flushed: parameters, Adam moments, losses of every step."""
+import numpy as np
+import pytest
+import torch
+
+import recnet_amd as R
+from tests import golden_util as GU
+from tests.gpu_util import make_models
+
+pytestmark = pytest.mark.gpu
+
+# persistent-chain shape (H % 32, R % 32) and a ragged one that takes the per-step kernels
+SHAPES = {"chains": [24, 6, 64, 61, 16, 32, 16, 16], "per_step": [9, 5, 40, 61, 12, 24, 8, 8]}
+
+
+def _state(md):
+    st = md["_state"].flat()
+    out = {"p." + k: v.detach().clone() for k, v in md["model"].state_dict().items()}
+    for name in ("exp_avg", "exp_avg_sq"):
+        for k, v in st[name].views.items():
+            out[name + "." + k] = v.detach().clone()
+    return out
+
+
+def _atomic(name):
+    """Gradients summed with float atomics (column sums, the embedding scatter): reproducible to fp32 rounding only, with or
+    without deferral (tests/test_gpu_fullsize.py: the step is a pure function ... 'to fp32 rounding for the ones summed
+    with atomics')."""
+    return any(t in name for t in ("bias", "attn_b", "attn_w.", "embedding"))
+
+
+def _same(a, b, name, exact):
+    if exact and not _atomic(name):
+        return torch.equal(a, b)
+    return torch.allclose(a, b, rtol=2e-4, atol=2e-8)
+
+
+def _run(kind, prec, dims, deferred, lens_sets, order):
+    B, F, D, V, E, H, A, RA = dims
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 3)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 4)
+    _, dec, rec = make_models(list(dims), kind, prec, decP, recP)
+    step = R.DataParallelTrainStep(dec, rec, B, 0, 1, n_frames=F)
+    graphs, losses = [], []
+    for i, lens in enumerate(lens_sets):
+        enc, targets = GU.make_batch(B, F, D, V, lens, 9 + i)
+        T, w = step.prepare(targets.numpy())
+        graphs.append(R.GraphedStep(step, enc.cuda(), targets.cuda(), T, w, warmup=0, defer_reconstructor_update=deferred))
+        assert graphs[-1].deferred == (deferred and kind == "global")
+    for i in order:
+        losses.append(graphs[i]().clone())
+    graphs[0].flush()
+    torch.cuda.synchronize()
+    assert step.step_impl.engine.chain_status() == 0
+    return _state(dec), _state(rec), torch.stack(losses).cpu().numpy()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f32"])
+@pytest.mark.parametrize("kind", ["global"])
+@pytest.mark.parametrize("shape", list(SHAPES))
+@pytest.mark.parametrize("lengths", ["full", "alternating"])
+def test_deferred_update_equals_the_immediate_one_once_flushed(lengths, shape, kind, prec):
+    dims = SHAPES[shape]
+    B = dims[0]
+    rs = np.random.RandomState(1)
+    if lengths == "full":
+        # T = caption_max_len + 1 in every step: the deferred products have the shapes of the immediate ones, so every
+        # GEMM-produced gradient — and with it every parameter and Adam moment it feeds — is BIT-identical
+        sets = [[30] + [int(x) for x in rs.randint(1, 30, size=B - 1)]]
+        order = [0, 0, 0, 0]
+    else:
+        # two caption-length sets with DIFFERENT decode lengths T, replayed alternately: the deferred products of one graph
+        # run on the gate gradients the OTHER graph's step left.  The global reconstructor's deferred products always cover
+        # caption_max_len + 1 steps (zero gate gradients beyond T): another split of K, so equal to fp32 rounding
+        sets = [[int(x) for x in rs.randint(1, 6, size=B)], [int(x) for x in rs.randint(3, 12, size=B)]]
+        order = [0, 1, 1, 0, 1, 0]
+    exact = lengths == "full" or kind == "local"
+    d0, r0, l0 = _run(kind, prec, dims, False, sets, order)
+    d1, r1, l1 = _run(kind, prec, dims, True, sets, order)
+    assert np.allclose(l0[:, :7], l1[:, :7], rtol=1e-6, atol=0), (l0[:, 6], l1[:, 6])
+    for k in d0:
+        assert _same(d0[k], d1[k], k, True), ("decoder", k, float((d0[k] - d1[k]).abs().max()))
+    for k in r0:
+        assert _same(r0[k], r1[k], k, exact), ("reconstructor", k, float((r0[k] - r1[k]).abs().max()))
+    # and the update really happened (the Adam steps moved the reconstructor)
+    recP = GU.formula_params(GU.rec_shapes(kind, dims[5], dims[2], dims[7]), 4)
+    assert any(not torch.equal(r1["p." + k].cpu(), v) for k, v in recP.items())
+
+
+def test_without_flush_the_last_update_is_pending_and_entry_points_flush_themselves():
+    dims = SHAPES["chains"]
+    B, F, D, V, E, H, A, RA = dims
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 3)
+    recP = GU.formula_params(GU.rec_shapes("global", H, D, RA), 4)
+    enc, targets = GU.make_batch(B, F, D, V, [3] * B, 9)
+
+    def build(deferred):
+        _, dec, rec = make_models(list(dims), "global", "bf16", decP, recP)
+        step = R.DataParallelTrainStep(dec, rec, B, 0, 1, n_frames=F)
+        T, w = step.prepare(targets.numpy())
+        return dec, rec, step, R.GraphedStep(step, enc.cuda(), targets.cuda(), T, w, warmup=0, defer_reconstructor_update=deferred), T, w
+
+    dec0, rec0, step0, g0, T, w = build(False)
+    dec1, rec1, step1, g1, _, _ = build(True)
+    for _ in range(3):
+        g0(); g1()
+    torch.cuda.synchronize()
+    w0 = rec0["model"].state_dict()["rnn.weight_hh_l0"]
+    w1 = rec1["model"].state_dict()["rnn.weight_hh_l0"]
+    assert not torch.equal(w0, w1), "the third update should still be pending"
+    # an eager step through the ordinary entry points (fwd_bwd + optimizer_step) completes the pending update first
+    step0(enc.cuda(), targets.cuda(), T, w)
+    step1(enc.cuda(), targets.cuda(), T, w)
+    torch.cuda.synchronize()
+    for k, v in rec0["model"].state_dict().items():
+        assert _same(v, rec1["model"].state_dict()[k], k, True), k
+    for k, v in dec0["model"].state_dict().items():
+        assert _same(v, dec1["model"].state_dict()[k], k, True), k
+
+
+def test_local_reconstructor_keeps_the_immediate_update():
+    """The deferred form is implemented for the global reconstructor only; asking for it with the local one is ignored."""
+    dims = SHAPES["chains"]
+    a = _run("local", "bf16", dims, False, [[4] * dims[0]], [0, 0])
+    b = _run("local", "bf16", dims, True, [[4] * dims[0]], [0, 0])
+    for k in a[1]:
+        assert _same(a[1][k], b[1][k], k, True), k
