@@ -49,6 +49,7 @@ struct OptGroup {
 };
 
 static inline int pad8(int n) { return (n + 7) & ~7; }
+#define RN_MAX_ROW_GROUPS 4      // persistent chains up to 4 x 112 = 448 captions per GPU
 
 struct recnet_handle {
   recnet_config c;
@@ -97,6 +98,7 @@ struct recnet_handle {
   int side_pending = 0, side_T = 0, side_phase = 0, side_err = 0;   // side_after_decoder_fwd (abi_step.inc)
   const int64_t* side_targets = nullptr; const float* side_stepw = nullptr; const float* side_enc = nullptr;
   int late_join = 0;
+  int bgrp = 0;                  // rows per launch of the persistent chain kernels: B for B <= RC_PAN_ROWS, else B split evenly into ceil(B / 112) row groups
   // deferred reconstructor update (recnet_set_deferred_reconstructor_update): ctrl[2] on the device says whether an update is
   // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
   int defer_rec = 0, defer_now = 0, defer_err = 0, maybe_pending = 0, def_rows = 0, defer_flags = 3; hipStream_t s3 = nullptr; float* gws3 = nullptr;
@@ -301,6 +303,16 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
+  // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
+  // equal size (at most RN_MAX_ROW_GROUPS of them) and every chain runs once per group, one launch after the other: a group is
+  // an independent batch for a chain.  Everything batched (GEMMs, CE, optimiser) still sees the whole batch.
+  {
+    const char* eg = getenv("RN_ROW_GROUPS");      // 0: no grouping (batches above 112 captions take the per-step kernels)
+    int ng = (h->B + RC_PAN_ROWS - 1) / RC_PAN_ROWS;
+    if (eg && atoi(eg) == 0 && ng > 1) ng = 0;
+    h->bgrp = ng >= 1 && ng <= RN_MAX_ROW_GROUPS ? (h->B + ng - 1) / ng : h->B;
+  }
+  const int Bg = h->bgrp;     // rows of one chain launch
   {
     // rec_chain.hpp: every workgroup (8 hidden units) must be resident at once — one per CU
     const char* e = getenv("RN_PERSIST_REC");
@@ -310,22 +322,22 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     h->ncu = ncu;
     // Tm <= 60: stamped words carry epoch << 6 | step and barrier words epoch << 7 | phase (rec_chain.hpp) — a longer
     // caption limit would let one launch's values run into the next epoch's, so it takes the per-step kernels
-    h->persist_rec = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_GLOBAL && h->B <= 112 && h->Tm <= 60 &&
+    h->persist_rec = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_GLOBAL && Bg <= RC_PAN_ROWS && h->Tm <= 60 &&
                      (h->R & 7) == 0 && h->R <= 2048 && h->R / 8 <= ncu;   // <= 16 k-steps of resident weights per wave
     const char* ed = getenv("RN_PERSIST_DEC");
     const int N = 4 * h->H + h->A, NA = N / 16;
     h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && h->Tm <= 60 && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 + DC_XF && h->A <= 128 &&
-                     (N & 15) == 0 && h->B <= RC_PAN_ROWS && (NA > h->B ? NA : h->B) + 1 <= ncu;
+                     (N & 15) == 0 && Bg <= RC_PAN_ROWS && (NA > Bg ? NA : Bg) + 1 <= ncu;
     const char* eb = getenv("RN_PERSIST_REC_BWD");
     h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
   }
   {
     // loc_chain.hpp: the local reconstructor's forward chain as one launch (unit-owner + caption workgroups + relay)
     const char* e = getenv("RN_PERSIST_LOC");
-    h->lc_ms = h->B > 64 ? 2 : 1; h->lc_rb = (h->B <= 32) ? 2 : 4;
-    h->lc_ng = h->R / 16; h->lc_nc = (h->B + LC_CPW - 1) / LC_CPW;
+    h->lc_ms = Bg > 64 ? 2 : 1; h->lc_rb = (Bg <= 32) ? 2 : 4;
+    h->lc_ng = h->R / 16; h->lc_nc = (Bg + LC_CPW - 1) / LC_CPW;
     const int nwg = h->lc_ng * h->lc_ms + h->lc_nc + 1;
-    h->persist_loc = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && h->B <= RC_PAN_ROWS && (h->R & 31) == 0 &&
+    h->persist_loc = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && Bg <= RC_PAN_ROWS && (h->R & 31) == 0 &&
                      h->R <= 2048 && (h->H & 31) == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 3) == 0 && h->Tm <= 32 &&
                      h->F + 1 < LC_MAX_PHASE &&   // barrier words are epoch << 7 | phase, phase <= F + 1 (loc_chain.hpp)
 #ifdef LC_PROBE
@@ -334,20 +346,20 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
                      nwg <= h->ncu && nwg - 1 <= 256;
     // ... and its backward chain: U' all rows (RB 7) + X' two row parts above 64 captions, one part of 64 rows below
     const char* eb = getenv("RN_PERSIST_LOC_BWD");
-    h->lcb_msx = h->B > 64 ? 2 : 1; h->lcb_rbu = h->B > 64 ? 7 : (h->B > 32 ? 4 : 2);
+    h->lcb_msx = Bg > 64 ? 2 : 1; h->lcb_rbu = Bg > 64 ? 7 : (Bg > 32 ? 4 : 2);
     int nwb = h->lc_ng + (h->H / 16) * h->lcb_msx + h->lc_nc + 1;
     {   // X' with K split in parts of 2048 (64 columns x 32 rows x one part per workgroup) when those workgroups fit as well
       const char* ex = getenv("RN_LOC_XSPLIT");
-      const int ksx = (4 * h->R + 2047) / 2048, nwx = h->lc_ng + ((h->H + 63) / 64) * ((h->B + 31) / 32) * ksx + h->lc_nc + 1;
+      const int ksx = (4 * h->R + 2047) / 2048, nwx = h->lc_ng + ((h->H + 63) / 64) * ((Bg + 31) / 32) * ksx + h->lc_nc + 1;
       const int fx = ex ? atoi(ex) : 1;
       if (fx && ksx <= 4 && (h->R >= 512 || fx == 2) && nwx <= h->ncu && nwx - 1 <= 256) { h->lcb_xs = 16; nwb = nwx; }
     }
-    h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && (h->H & 15) == 0 && !(h->B > 64 && h->R > 1536) &&
+    h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && (h->H & 15) == 0 && !(Bg > 64 && h->R > 1536) &&
                          nwb <= h->ncu && nwb - 1 <= 256;
   }
   {
     const char* e = getenv("RN_DEC_BWD_NT");
-    h->use_wcomb_t = (e ? atoi(e) : 1) && h->lp && h->B <= 128;
+    h->use_wcomb_t = (e ? atoi(e) : 1) && h->lp && (h->B <= 128 || Bg < h->B);
     const char* eb = getenv("RN_PERSIST_DEC_BWD");
     int dev = 0, ncu = 0;
     hipGetDevice(&dev);
@@ -359,7 +371,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const char* er = getenv("RN_RESERVE_CUS");
     const int reserve = er ? atoi(er) : 0;
     h->persist_dec_bwd = (eb ? atoi(eb) : 1) && h->persist_dec && h->use_wcomb_t && (h->H & 15) == 0 && (h->ldWS & 7) == 0 &&
-                         (NAb > h->B ? NAb : h->B) + 1 + reserve <= ncu;
+                         (NAb > Bg ? NAb : Bg) + 1 + reserve <= ncu;
   }
   h->need = carve(h, nullptr);
   *out = h;

@@ -19,6 +19,7 @@
 
 struct DecChainArgs {
   int T, B, F, H, A, gru;
+  int Bs;                          // rows per time step of the saved [T][.][.] tensors (= batch size; B = rows of THIS launch, a row group; pointers pre-offset; exchange buffers are private to the launch and indexed with B)
   const bf16_t* W; int ldw;        // [4H + A ..][ldw] packed [W_hh ; attn_W] (Wcomb)
   const bf16_t* P; int ldp;        // [B][F][ldp]
   const float* Uv; const float* ab; const float* w;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   float* suvx = dc_dyn + 4 * 32 * 64 * 2;
   __shared__ __attribute__((aligned(16))) bf16_t hl[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = p.H, A = p.A, F = p.F, B = p.B, W4 = 4 * H, N = 4 * H + A;
+  const int H = p.H, A = p.A, F = p.F, B = p.B, Bs = p.Bs, W4 = 4 * H, N = 4 * H + A;
   const int NA = N >> 4;
   const int wg = blockIdx.x;
   const bool isA = wg < NA, isB = wg < B;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
     // input part of the gates of this step: independent of the chain, requested before any waiting
     f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
     if (live) {
-      const float* xe = p.Xe + ((size_t)t * B + b) * W4 + col;
+      const float* xe = p.Xe + ((size_t)t * Bs + b) * W4 + col;
       x0 = *reinterpret_cast<const f32x4*>(xe); x1 = *reinterpret_cast<const f32x4*>(xe + 4);
     }
     if (t > 0) {
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       // all 128 entries: the score threads read swh[k] for every k of their column range (w_k = 0 beyond A, but 0 x garbage
       // from uninitialised LDS could be NaN)
       if (tid < 128) swh[tid] = tid < A ? whv : 0.f;
-      if (tid < A) p.Wh[((size_t)t * B + b) * A + tid] = whv;
+      if (tid < A) p.Wh[((size_t)t * Bs + b) * A + tid] = whv;
       __syncthreads();
       DC_TS(4);
       {
@@ -281,17 +282,17 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       if (tid < 32) {
         const float sc = ((sps[tid] + sps[32 + tid]) + (sps[64 + tid] + sps[96 + tid])) + ((sps[128 + tid] + sps[160 + tid]) + (sps[192 + tid] + sps[224 + tid]));
         sa[tid] = tid < F ? sc : 0.f;
-        if (tid < F && !p.softmax) p.att[((size_t)t * B + b) * F + tid] = sc;
+        if (tid < F && !p.softmax) p.att[((size_t)t * Bs + b) * F + tid] = sc;
       } else if (XF && tid < 32 + DC_XF) {
         const int f2 = tid - 32;
         float sc = 0.f;
 #pragma unroll
         for (int kp = 0; kp < 16; ++kp) sc += sps[256 + kp * 16 + f2];
         sa[tid] = tid < F ? sc : 0.f;
-        if (tid < F && !p.softmax) p.att[((size_t)t * B + b) * F + tid] = sc;
+        if (tid < F && !p.softmax) p.att[((size_t)t * Bs + b) * F + tid] = sc;
       }
       __syncthreads();
-      if (p.softmax) { attn_softmax_lds(sa, F, p.att + ((size_t)t * B + b) * F); __syncthreads(); }
+      if (p.softmax) { attn_softmax_lds(sa, F, p.att + ((size_t)t * Bs + b) * F); __syncthreads(); }
       DC_TS(8);
       {
         // context of this wave's gate block: ctx[n] = sum_f a_f P[b, f, n] as MFMAs.  Rows 4i / 4i + 1 of the A operand are the
@@ -377,17 +378,17 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       if (t + 1 < p.T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // (the stores below are issued after the arrive, see the end of the loop body)
       if (t + 1 < p.T) { __syncthreads(); DC_TS(6); ++ph; rc_arrive(p.bar, fb + ph); }
-      bf16_t* Lt = p.Hlp + ((size_t)t * B + b) * p.ld_hlp;
+      bf16_t* Lt = p.Hlp + ((size_t)t * Bs + b) * p.ld_hlp;
       if (tid < (H >> 3)) *reinterpret_cast<bf16x8*>(Lt + tid * 8) = *reinterpret_cast<const bf16x8*>(hl + tid * 8);
       for (int j = H + tid; j < p.ld_hlp; j += 256) Lt[j] = (bf16_t)0.f;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int uu = tid + 256 * jj;
         if (uu < H) {
-          const size_t o = ((size_t)t * B + b) * H + uu;
+          const size_t o = ((size_t)t * Bs + b) * H + uu;
           p.Hs[o] = hv[jj];
           if (!p.gru) p.Cs[o] = cn[jj];
-          float* a = p.acts + ((size_t)t * B + b) * W4 + uu;
+          float* a = p.acts + ((size_t)t * Bs + b) * W4 + uu;
           a[0] = av[jj][0]; a[H] = av[jj][1]; a[2 * H] = av[jj][2]; a[3 * H] = av[jj][3];
         }
       }
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
 // weight-gradient GEMMs are unchanged.
 struct DecChainBwdArgs {
   int T, B, F, H, A, gru;
+  int Bs;                          // see DecChainArgs
   const bf16_t* Wt; int ldwt;      // [H][ldwt] WcombT: column n of [W_hh ; attn_W ..], K contiguous
   const bf16_t* P; int ldp;        // [B][F][ldp]
   const float* Uv; const float* ab; const float* w;
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
   float* suvx = dc_dyn + DC_XF * DCB_PLD / 2;
   float* sdux = suvx + DC_XF * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = p.H, A = p.A, F = p.F, B = p.B, W4 = 4 * H, KA = 4 * H + A;
+  const int H = p.H, A = p.A, F = p.F, B = p.B, Bs = p.Bs, W4 = 4 * H, KA = 4 * H + A;
   const int NU = H >> 4, NA = NU * DCB_PARTS;
   const int wg = blockIdx.x;
   const bool isA = wg < NA, isB = wg < B;
@@ -540,16 +542,16 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int u = tid + 256 * q;
-      const size_t o = ((size_t)t * B + b) * H + (u < H ? u : 0);
+      const size_t o = ((size_t)t * Bs + b) * H + (u < H ? u : 0);
       d1[q] = p.dHs[o];
       d2[q] = p.dHs2 ? p.dHs2[o] : 0.f;
-      const float* a = p.acts + ((size_t)t * B + b) * W4 + (u < H ? u : 0);
+      const float* a = p.acts + ((size_t)t * Bs + b) * W4 + (u < H ? u : 0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) av[q][j] = a[(size_t)j * H];
       cv[q] = p.Cs[o];
-      cpv[q] = t > 0 ? (p.gru ? p.Hs : p.Cs)[o - (size_t)B * H] : 0.f;
+      cpv[q] = t > 0 ? (p.gru ? p.Hs : p.Cs)[o - (size_t)Bs * H] : 0.f;
     }
-    whk = p.Wh[((size_t)t * B + b) * A + kk];
+    whk = p.Wh[((size_t)t * Bs + b) * A + kk];
   };
   if (isB) prefetch(p.T - 1);
 
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         if (tid < SPF) sda[tid] = (spartf[tid] + spartf[SPF + tid] + spartf[2 * SPF + tid] + spartf[3 * SPF + tid]) * (1.0f / (float)F);
       }
       __syncthreads();
-      if (p.softmax) { attn_softmax_bwd_lds(sda, p.att + ((size_t)t * B + b) * F, F); __syncthreads(); }
+      if (p.softmax) { attn_softmax_bwd_lds(sda, p.att + ((size_t)t * Bs + b) * F, F); __syncthreads(); }
       // (3) attention backward on the (f, k) plane
       DCB_TS(3);
       float dwh = 0.f;
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; rc_arrive(p.bar, fb + ph); }
       DCB_TS(5);
       // ---- off the critical path: the row-major copy [dgates | dWh | 0 ..] for the deferred GEMMs
-      bf16_t* Gt = p.dGx + ((size_t)t * B + b) * p.ld_dgx;
+      bf16_t* Gt = p.dGx + ((size_t)t * Bs + b) * p.ld_dgx;
       for (int kg = tid; kg < (p.ld_dgx >> 3); kg += 256)
         *reinterpret_cast<bf16x8*>(Gt + kg * 8) = kg < (KA >> 3) ? *reinterpret_cast<const bf16x8*>(srow + kg * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       if (more) { prefetch(t - 1); { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); } }
@@ -777,7 +779,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       for (int j = 0; j < G; ++j) a += spart[j * A + tid];
       p.dwacc[(size_t)b * A + tid] = a;
 #pragma unroll
-      for (int ch = 1; ch < RN_FCH; ++ch) p.dwacc[((size_t)ch * B + b) * A + tid] = 0.f;
+      for (int ch = 1; ch < RN_FCH; ++ch) p.dwacc[((size_t)ch * Bs + b) * A + tid] = 0.f;
     }
   }
   rc_epoch_bump(p.epoch, ep0);

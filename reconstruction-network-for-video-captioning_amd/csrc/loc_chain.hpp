@@ -22,6 +22,7 @@
 
 struct LocChainArgs {
   int F, T, B, R, H, A, gru;
+  int Bs;                             // rows per step of the saved [F][.][.] / [T][.][.] tensors (= batch size; B = rows of THIS launch, a row group; pointers pre-offset; Pw / panels are private to the launch)
   int NU, NG, MS, NC;                 // unit-owner workgroups = NG unit groups x MS row parts; caption workgroups
   const bf16_t* W; int ldw;           // [4R][ldw] packed [W_ih (H) | W_hh (R) | 0], gate-major rows
   const bf16_t* Wr; int ldwr;         // [A][ldwr] W_r
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
   constexpr int CG = 4, UW = 16, ROWS = RB * 16, RED_LD = CG * 16 + 1, NP = STEPS / 2, KG = UW / 8, SX = 4;
   extern __shared__ __attribute__((aligned(16))) float lc_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x, R = p.R, B = p.B, H = p.H, A = p.A, F = p.F, T = p.T;
+  const int wg = blockIdx.x, R = p.R, B = p.B, Bs = p.Bs, H = p.H, A = p.A, F = p.F, T = p.T;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
   unsigned* relU = p.bar + 256; unsigned* relC = p.bar + 256 + 16;
   const size_t pan_h = rc_pan_elems(R), pan_x = rc_pan_elems(H);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
         const int h = j + 128 * q;
-        hv[q][t] = (bok && t < T && h < H) ? p.Hs[((size_t)t * B + bb) * H + h] : 0.f;
+        hv[q][t] = (bok && t < T && h < H) ? p.Hs[((size_t)t * Bs + bb) * H + h] : 0.f;
       }
     // scores: thread = (decoder step tt = j % 32, attention columns [32 kq4, 32 kq4 + 32)): the sum over k is mostly inside a
     // thread (32 independent tanh), the four column quarters are added through LDS — no wavefront reductions
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       const int k = 32 * kq4 + i;
-      udr[i] = (bok && tt < T && k < A) ? p.Ud[((size_t)tt * B + bb) * A + k] : 0.f;
+      udr[i] = (bok && tt < T && k < A) ? p.Ud[((size_t)tt * Bs + bb) * A + k] : 0.f;
     }
     if (tid < 128) { swab[2 * tid] = tid < A ? p.w[tid] : 0.f; swab[2 * tid + 1] = tid < A ? p.ab[tid] : 0.f; }
     const uint32_t key = drop_key(p.dd);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
         whr = (spw[(c * 4 + 0) * 128 + j] + spw[(c * 4 + 1) * 128 + j]) + (spw[(c * 4 + 2) * 128 + j] + spw[(c * 4 + 3) * 128 + j]);
       }
       swh[c * 128 + j] = whr;
-      if (bok && j < A) p.Whr[((size_t)s * B + b) * A + j] = whr;
+      if (bok && j < A) p.Whr[((size_t)s * Bs + b) * A + j] = whr;
       __syncthreads();
       if (ci == 0) LC_TS(1, s, 1);
       {
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       if (kq4 == 0) {
         const float sc = (spb[(c * 4) * 32 + tt] + spb[(c * 4 + 1) * 32 + tt]) + (spb[(c * 4 + 2) * 32 + tt] + spb[(c * 4 + 3) * 32 + tt]);
         sbeta[c * 32 + tt] = sc;
-        if (bok && tt < T) p.beta[((size_t)s * B + b) * T + tt] = sc;
+        if (bok && tt < T) p.beta[((size_t)s * Bs + b) * T + tt] = sc;
       }
       __syncthreads();
 #pragma unroll
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       __syncthreads();
       lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(s + 1));
       if (ci == 0) LC_TS(1, s, 3);
-      if (pon) *reinterpret_cast<bf16x8*>(p.Xcat + ((size_t)s * B + pb) * p.ld_xcat + kg * 8) = *reinterpret_cast<const bf16x8*>(xl + pc * 512 + kg * 8);
+      if (pon) *reinterpret_cast<bf16x8*>(p.Xcat + ((size_t)s * Bs + pb) * p.ld_xcat + kg * 8) = *reinterpret_cast<const bf16x8*>(xl + pc * 512 + kg * 8);
     }
     __syncthreads();
     lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(F + 1));
@@ -390,10 +391,10 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       if (wg == 0) LC_TS(0, s, 4);
     }
     // ---- off the critical path: what the backward and the output layer read
-    float* Ht = p.Hr + (size_t)s * B * R;
-    float* Ct = p.Cr + (size_t)s * B * R;
-    float* At = p.acts + (size_t)s * B * 4 * R;
-    bf16_t* Lt = p.Hlp + (size_t)s * B * p.ld_hlp;
+    float* Ht = p.Hr + (size_t)s * Bs * R;
+    float* Ct = p.Cr + (size_t)s * Bs * R;
+    float* At = p.acts + (size_t)s * Bs * 4 * R;
+    bf16_t* Lt = p.Hlp + (size_t)s * Bs * p.ld_hlp;
     if (it_on) *reinterpret_cast<bf16x8*>(Lt + (size_t)it_rg * p.ld_hlp + u0 + it_j * 8) = *reinterpret_cast<const bf16x8*>(it_src);
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
@@ -470,6 +471,7 @@ template <int RB> constexpr size_t lc_smem_bytes() {
 // The panels are indexed by chain step (fresh addresses every step, rec_chain.hpp).
 struct LocChainBwdArgs {
   int F, T, B, R, H, A, gru;
+  int Bs;                            // see LocChainArgs (Dx / panels are private to the launch)
   int NGU, MSU, NGX, MSX, NC;        // U' = NGU unit groups x MSU row parts, X' = NGX column groups x MSX row parts, C'
   int KSX;                           // X' parts of the contraction (1: the whole of K = 4R per workgroup; > 1: lcb_xsplit_role)
   const bf16_t* WT; int ldwt;        // [H + R][ldwt]: rows [0,H) = W_ih^T (x columns), rows [H, H+R) = W_hh^T; K = 4R contiguous
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
   constexpr int UW = 16, RED_LD = UW + 1, KG = UW / 8;
   extern __shared__ __attribute__((aligned(16))) float lc_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = blockIdx.x, R = p.R, B = p.B, H = p.H, A = p.A, F = p.F, T = p.T, K = 4 * R;
+  const int wg = blockIdx.x, R = p.R, B = p.B, Bs = p.Bs, H = p.H, A = p.A, F = p.F, T = p.T, K = 4 * R;
   const int NU = p.NGU * p.MSU, NX = p.NGX * p.MSX * p.KSX;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
   unsigned* relG = p.bar + 256; unsigned* relX = p.bar + 256 + 8; unsigned* relW = p.bar + 256 + 16;
@@ -690,12 +692,12 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 #pragma unroll
     for (int i = 0; i < 128; ++i) {
       const int h = 128 * hq + i;
-      hv[i] = (bok && tt < T && h < H) ? p.Hs[((size_t)tt * B + bb) * H + h] : 0.f;
+      hv[i] = (bok && tt < T && h < H) ? p.Hs[((size_t)tt * Bs + bb) * H + h] : 0.f;
       dhs[i] = 0.f;
     }
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
-      ud[t] = (kon && t < T) ? p.Ud[((size_t)t * B + bb) * A + j] : 0.f;
+      ud[t] = (kon && t < T) ? p.Ud[((size_t)t * Bs + bb) * A + j] : 0.f;
       dud[t] = 0.f;
     }
     const float wk = kon ? p.w[j] : 0.f, abk = kon ? p.ab[j] : 0.f;
@@ -704,8 +706,8 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
     for (int q = 0; q < F; ++q) {
       const int s = F - 1 - q;
       // saved tensors of step s: independent of the chain, requested before waiting
-      const float whk = (kon ? p.Whr[((size_t)s * B + b) * A + j] : 0.f) + abk;
-      const float bt = (bok && tt < T) ? p.beta[((size_t)s * B + b) * T + tt] * invT : 0.f;
+      const float whk = (kon ? p.Whr[((size_t)s * Bs + b) * A + j] : 0.f) + abk;
+      const float bt = (bok && tt < T) ? p.beta[((size_t)s * Bs + b) * T + tt] * invT : 0.f;
       // tanh(W hr_s + U h_t + b) of the (t, k) plane: saved operands only, so it is formed while this workgroup waits for dx_s
       float tzr[32];
 #pragma unroll
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       lc_arrive(p.bar + NU + NX + ci, fb + (unsigned)(q + 1));
       if (ci == 0) LC_TS(6, q, 2);
       if (pon && kg < (p.ld_dwhr >> 3) && kg < 16)
-        *reinterpret_cast<bf16x8*>(p.dWhrs + ((size_t)s * B + pb) * p.ld_dwhr + kg * 8) = *reinterpret_cast<const bf16x8*>(swl + pc * 128 + kg * 8);
+        *reinterpret_cast<bf16x8*>(p.dWhrs + ((size_t)s * Bs + pb) * p.ld_dwhr + kg * 8) = *reinterpret_cast<const bf16x8*>(swl + pc * 128 + kg * 8);
     }
     // ---- the accumulators
     if (bok) {
@@ -774,19 +776,19 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
 #pragma unroll
         for (int i = 0; i < 128; i += 4) {
           const int h = 128 * hq + i;
-          if (h < H) *reinterpret_cast<f32x4*>(p.dHs + ((size_t)tt * B + b) * H + h) = f32x4{dhs[i], dhs[i + 1], dhs[i + 2], dhs[i + 3]};
+          if (h < H) *reinterpret_cast<f32x4*>(p.dHs + ((size_t)tt * Bs + b) * H + h) = f32x4{dhs[i], dhs[i + 1], dhs[i + 2], dhs[i + 3]};
         }
       }
 #pragma unroll
       for (int t = 0; t < 32; ++t) {
         if (t < T) {
-          if (j < A) { p.dUd[((size_t)t * B + b) * A + j] = dud[t]; p.dUd_lp[((size_t)t * B + b) * p.ld_dUd + j] = (bf16_t)dud[t]; }
-          else if (j < p.ld_dUd) p.dUd_lp[((size_t)t * B + b) * p.ld_dUd + j] = (bf16_t)0.f;
+          if (j < A) { p.dUd[((size_t)t * Bs + b) * A + j] = dud[t]; p.dUd_lp[((size_t)t * Bs + b) * p.ld_dUd + j] = (bf16_t)dud[t]; }
+          else if (j < p.ld_dUd) p.dUd_lp[((size_t)t * Bs + b) * p.ld_dUd + j] = (bf16_t)0.f;
         }
       }
       if (j < A) {
         p.dwacc[(size_t)b * A + j] = dwa;
-        for (int ch = 1; ch < p.nch; ++ch) p.dwacc[((size_t)ch * B + b) * A + j] = 0.f;
+        for (int ch = 1; ch < p.nch; ++ch) p.dwacc[((size_t)ch * Bs + b) * A + j] = 0.f;
       }
     }
     __syncthreads();
@@ -880,12 +882,12 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       const int cell = tid + c * 256;
       const size_t row = mine[c] ? r0 + cell / UW : 0;
       const int u = u0 + cell % UW;
-      const float* a = p.acts + ((size_t)s * B + row) * 4 * R + u;
+      const float* a = p.acts + ((size_t)s * Bs + row) * 4 * R + u;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) av[c][qq] = a[(size_t)qq * R];
-      cc[c] = p.gru ? 0.f : p.Cr[((size_t)s * B + row) * R + u];
-      cp[c] = s > 0 ? (p.gru ? p.Hr : p.Cr)[((size_t)(s - 1) * B + row) * R + u] : 0.f;
-      direct[c] = mine[c] ? p.dHr[((size_t)s * B + row) * R + u] : 0.f;
+      cc[c] = p.gru ? 0.f : p.Cr[((size_t)s * Bs + row) * R + u];
+      cp[c] = s > 0 ? (p.gru ? p.Hr : p.Cr)[((size_t)(s - 1) * Bs + row) * R + u] : 0.f;
+      direct[c] = mine[c] ? p.dHr[((size_t)s * Bs + row) * R + u] : 0.f;
     }
   };
   prefetch(F - 1);
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
     lc_arrive(p.bar + wg, fb + (unsigned)(q + 1));
     if (wg == 0) LC_TS(4, q, 4);
     // ---- off the critical path: the row-major copy for the deferred weight-gradient GEMMs
-    bf16_t* Gt = p.dG + (size_t)s * B * p.ld_dg;
+    bf16_t* Gt = p.dG + (size_t)s * Bs * p.ld_dg;
 #pragma unroll
     for (int jj = 0; jj < IPT; ++jj)
       if (it_on[jj]) *reinterpret_cast<bf16x8*>(Gt + (size_t)it_rg[jj] * p.ld_dg + it_col[jj]) = *reinterpret_cast<const bf16x8*>(it_src[jj]);

@@ -18,6 +18,7 @@
 
 struct RecChainArgs {
   int T, B, R, gru;
+  int Bs;                         // rows per time step of the [T][.][.] tensors (= batch size; B = rows of THIS launch: a row group of a batch above 112, pointers pre-offset)
   const bf16_t* W; int ldw;       // [4R][ldw]  packed W_hh, gate-major (GRU: 4-block layout, block 2 zero)
   bf16_t* Hlp; int ld_hlp;        // [T][B][ld_hlp] row-major operand copies of h_t (for the backward's batched GEMMs)
   bf16_t* Pan;                    // [T][R/8][RC_PAN_ROWS][8] k-group-major copies of h_t: what the next step reads
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   float* red = rc_smem;                                            // [4 waves][ROWS][RED_LD]
   bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD);   // [ROWS][UW] this step's columns of h_t (16-byte aligned: ROWS % 16 == 0)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
-  const int u0 = blockIdx.x * UW, R = p.R, B = p.B;
+  const int u0 = blockIdx.x * UW, R = p.R, B = p.B, Bs = p.Bs;
   // rows: this workgroup owns panel rows [own_lo, own_lo + own) and computes [r0, r0 + ROWS) (a superset)
   const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
   const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     cpv[c] = 0.f; hsum[c] = 0.f;
   }
   auto load_x = [&](int t) {
-    const float* X = p.Xg + (size_t)t * B * 4 * R;
+    const float* X = p.Xg + (size_t)t * Bs * 4 * R;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int cell = tid + c * 256;
@@ -333,10 +334,10 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
       rc_arrive_at(p.bar, widx, fb + (unsigned)(t + 1));
     }
     // ---- everything below is off the critical path of the chain
-    float* Ht = p.H + (size_t)t * B * R;
-    float* Ct = p.C + (size_t)t * B * R;
-    float* At = p.acts + (size_t)t * B * 4 * R;
-    bf16_t* Lt = p.Hlp + (size_t)t * B * p.ld_hlp;
+    float* Ht = p.H + (size_t)t * Bs * R;
+    float* Ct = p.C + (size_t)t * Bs * R;
+    float* At = p.acts + (size_t)t * Bs * 4 * R;
+    bf16_t* Lt = p.Hlp + (size_t)t * Bs * p.ld_hlp;
     if (it_on) *reinterpret_cast<bf16x8*>(Lt + (size_t)it_rg * p.ld_hlp + u0 + it_j * 8) = *reinterpret_cast<const bf16x8*>(it_src);
 #ifndef RC_PROBE_SKIP_STORE
 #pragma unroll
@@ -395,6 +396,7 @@ template <int RB, int CG> constexpr size_t rc_smem_bytes() { return (size_t)4 * 
 // GEMMs read is written off the critical path.
 struct RecChainBwdArgs {
   int T, B, R, gru;
+  int Bs;                          // see RecChainArgs
   const bf16_t* Wt; int ldwt;      // [R][ldwt]  W_hh^T, K (= gate row) contiguous
   bf16_t* Pan;                     // [T][4R/8][RC_PAN_ROWS][8] exchange copies of dG, indexed by chain step
   bf16_t* dG; int ld_dg;           // [T][B][ld_dg] row-major gate gradients, zero padded
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD + (4 - (4 * ROWS * RED_LD) % 4) % 4);   // [ROWS][4][UW]
   bf16x8* wl = reinterpret_cast<bf16x8*>(hl + (size_t)ROWS * 4 * UW);     // [KL][CG][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
-  const int u0 = blockIdx.x * UW, R = p.R, B = p.B, K = 4 * R;
+  const int u0 = blockIdx.x * UW, R = p.R, B = p.B, Bs = p.Bs, K = 4 * R;
   const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
   const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
   const int kw0 = wave * (STEPS * 32);
@@ -457,11 +459,11 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
       const int cell = tid + c * 256;
       const size_t row = mine[c] ? r0 + cell / UW : 0;
       const int u = u0 + cell % UW;
-      const float* a = p.acts + ((size_t)t * B + row) * 4 * R + u;
+      const float* a = p.acts + ((size_t)t * Bs + row) * 4 * R + u;
 #pragma unroll
       for (int q = 0; q < 4; ++q) av[c][q] = a[(size_t)q * R];
-      cc[c] = p.gru ? 0.f : p.C[((size_t)t * B + row) * R + u];
-      cp[c] = t > 0 ? (p.gru ? p.H : p.C)[((size_t)(t - 1) * B + row) * R + u] : 0.f;
+      cc[c] = p.gru ? 0.f : p.C[((size_t)t * Bs + row) * R + u];
+      cp[c] = t > 0 ? (p.gru ? p.H : p.C)[((size_t)(t - 1) * Bs + row) * R + u] : 0.f;
     }
   };
   prefetch(p.T - 1);
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
       rc_arrive_at(p.bar, widx, fb + (unsigned)(s + 1));
     }
     // ---- off the critical path: the row-major copy for the deferred weight-gradient GEMMs
-    bf16_t* Gt = p.dG + (size_t)t * B * p.ld_dg;
+    bf16_t* Gt = p.dG + (size_t)t * Bs * p.ld_dg;
 #pragma unroll
     for (int j = 0; j < IPT; ++j)
       if (it_on[j]) *reinterpret_cast<bf16x8*>(Gt + (size_t)it_rg[j] * p.ld_dg + it_col[j]) = *reinterpret_cast<const bf16x8*>(it_src[j]);

@@ -279,6 +279,11 @@ EDGE = {
     "LOC_R96_B40_RA128": ([40, 3, 96, 29, 8, 64, 16, 128], [(5 * i) % 8 for i in range(40)]),
     "LOC_R32_B20_RA8_T31": ([20, 2, 32, 29, 8, 32, 16, 8], [30] + [(3 * i) % 6 for i in range(19)]),
     "LOC_R128_B65_F1": ([65, 1, 128, 29, 8, 32, 16, 12], [(5 * i) % 7 for i in range(65)]),
+    # batches above the 112-row exchange panels (csrc/api.hip: row groups — every chain runs once per group of <= 112 captions):
+    # one caption over the limit (57 + 56), two full panels, three uneven groups (77 + 77 + 76); all six chain kernels
+    "GROUPS_B113_two_groups": ([113, 3, 64, 29, 8, 32, 16, 16], [(7 * i) % 9 for i in range(113)]),
+    "GROUPS_B224_two_full_panels": ([224, 2, 32, 29, 8, 32, 16, 8], [(5 * i) % 7 for i in range(224)]),
+    "GROUPS_B230_three_groups_T31": ([230, 2, 32, 29, 8, 32, 16, 8], [30] + [(3 * i) % 6 for i in range(229)]),
 }
 # K = 4R = 4096: two K parts in the backward chain's X' role (lcb_xsplit_role), second row part with two rows
 EDGE_KSPLIT = {"LOC_R1024_B34_two_k_parts": ([34, 2, 1024, 29, 8, 64, 16, 16], [(5 * i) % 6 for i in range(34)])}
@@ -317,6 +322,30 @@ def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
             if e > tol["grad"]:
                 bad.append((grp, k, e))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("kind", ["global", "local"])
+def test_batches_above_112_captions_stay_on_the_persistent_chains(kind, monkeypatch):
+    """RC_PAN_ROWS = 112 gated every chain kernel; now a larger batch runs each chain once per row group.
+    The results are held to the oracle by the GROUPS_* edge shapes above; this checks that the chain kernels really are what
+    ran (one bracketed launch per group for the reconstructor's chains, one bracket around the groups for the decoder's),
+    and that RN_ROW_GROUPS=0 restores the per-step kernels."""
+    dims, lens = EDGE["GROUPS_B224_two_full_panels"]
+    B, F, D, V, E, H, A, RA = dims
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 31)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 32)
+    enc, targets = GU.make_batch(B, F, D, V, lens, 78)
+
+    def launches():
+        C, dec, rec = make_models(dims, kind, "bf16", decP, recP)
+        step = R.TrainStep(dec, rec)
+        T, w = step.prepare(targets.numpy())
+        e, t = enc.cuda(), targets.cuda()
+        return [step.engine.profile_site(site, lambda: step.fwd_bwd(e, t, T, w, seed=6), 1)[0] for site in (7, 8, 9, 10)]
+
+    assert launches() == [2, 2, 1, 1]
+    monkeypatch.setenv("RN_ROW_GROUPS", "0")
+    assert launches() == [0, 0, 0, 0]
 
 
 @pytest.mark.parametrize("case", [c for c in sorted(EDGE) if c.startswith("LOC_")] + sorted(EDGE_KSPLIT))
