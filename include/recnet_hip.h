@@ -341,6 +341,9 @@ int recnet_debug_raise_give_up(recnet_handle* h, int32_t chain_bit, void* stream
 /* Test hook: a kernel of `n_workgroups` workgroups that each take a whole CU (160 KB of LDS) and spin for `microseconds` —
  * what a resident collective (RCCL) kernel looks like to the persistent chain kernels.  Launch it on another stream. */
 int recnet_debug_occupy(recnet_handle* h, int32_t n_workgroups, int32_t microseconds, void* stream);
+/* Test hook: byte offset inside the bound workspace of a saved tensor of the local reconstructor's forward pass
+ * (0: Whr [F][B][RA], 1: beta [F][B][T], 2: Hr [F][B][R], 3: acts [F][B][4R]); -1 if unknown. */
+int64_t recnet_debug_offset(const recnet_handle* h, int32_t which);
 /* Name / start / duration of the dominant kernel's launches inside the last train step are measured
  * by the caller with hipEvents; this returns the ALGORITHMIC bytes of one launch: loop invariants once, every input /
  * saved tensor once.  The step-to-step exchange blocks of a persistent chain kernel are not part of it. */

@@ -150,3 +150,4 @@ EXPORTS["recnet_debug_occupy"] = (_i, [C.c_void_p, _i, _i, C.c_void_p])
 EXPORTS["recnet_set_deferred_reconstructor_update"] = (_i, [C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_flush"] = (_i, [C.c_void_p, C.c_void_p])
 EXPORTS["recnet_mark_pending"] = (_i, [C.c_void_p])
+EXPORTS["recnet_debug_offset"] = (C.c_int64, [C.c_void_p, _i])

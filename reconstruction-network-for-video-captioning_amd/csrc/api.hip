@@ -79,6 +79,7 @@ struct recnet_handle {
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void* Hr_pan = nullptr;
+  void* Wst = nullptr; int lc_steps = 0, lc_sr = 0;   // hybrid forward chain (R > 2048): streamed fragments image, k-steps per wave / resident
   void *lc_panh = nullptr, *lc_panx = nullptr; _Float16* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
   void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
   int lcb_msx = 1, lcb_rbu = 4, lc_bwd_done = 0;
@@ -238,6 +239,11 @@ static size_t carve(recnet_handle* h, char* base) {
     h->lc_panh = takev(F * rc_pan_elems((int)R) / 2 + 64);
     h->lc_panx = takev(F * rc_pan_elems((int)H) / 2 + 64);
     h->lc_pw = (_Float16*)take(F * B * ((R + 15) / 16) * RA / 2 + 64);
+    {   // hybrid forward chain: 12 of the (R / 128 rounded up to even) k-steps per wave resident, the others streamed from this image
+      int steps = (int)(R + 127) / 128; steps += steps & 1;
+      h->lc_steps = steps > 16 ? (steps <= 28 ? 28 : 32) : 0; h->lc_sr = LC_HYB_SR;
+      if (h->lc_steps) h->Wst = takev((R / 16) * 4 * (size_t)(h->lc_steps - h->lc_sr) * 4 * 512 / 2 + 64);
+    }
     h->lc_pang = takev(F * rc_pan_elems((int)(4 * R)) / 2 + 64);
     h->lc_panw = takev(F * rc_pan_elems((int)RA) / 2 + 64);
     h->lc_dx = take(F * 4 * B * H);     // up to 4 K parts (lcb_xsplit_role)
@@ -336,9 +342,14 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const char* e = getenv("RN_PERSIST_LOC");
     h->lc_ms = Bg > 64 ? 2 : 1; h->lc_rb = (Bg <= 32) ? 2 : 4;
     h->lc_ng = h->R / 16; h->lc_nc = (Bg + LC_CPW - 1) / LC_CPW;
-    const int nwg = h->lc_ng * h->lc_ms + h->lc_nc + 1;
+    // (the relay workgroup is dropped when there is no CU left for it: nwg - 1 == CU count, R = 3584 with 64 captions)
+    int nwg = h->lc_ng * h->lc_ms + h->lc_nc + 1;
+    if (nwg - 1 == h->ncu) nwg -= 1;
+    // R above 2048 (a multiple of 256): the hybrid form of loc_chain_kernel (12 k-steps per wave resident in registers, the
+    // rest streamed every step), forward chain only; the backward runs the per-step kernels
+    const int f_hyb = getenv("RN_LOC_HYBRID") ? atoi(getenv("RN_LOC_HYBRID")) : 1;   // (read per handle: the tests switch it)
     h->persist_loc = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && Bg <= RC_PAN_ROWS && (h->R & 31) == 0 &&
-                     h->R <= 2048 && (h->H & 31) == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 3) == 0 && h->Tm <= 32 &&
+                     (h->R <= 2048 || (f_hyb && h->R <= 4096 && (h->R & 255) == 0)) && h->lc_ng <= 256 && (h->H & 31) == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 3) == 0 && h->Tm <= 32 &&
                      h->F + 1 < LC_MAX_PHASE &&   // barrier words are epoch << 7 | phase, phase <= F + 1 (loc_chain.hpp)
 #ifdef LC_PROBE
                      h->F <= 64 &&                // LC_TS indexes [role][step < 64][8]
@@ -354,7 +365,9 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
       const int fx = ex ? atoi(ex) : 1;
       if (fx && ksx <= 4 && (h->R >= 512 || fx == 2) && nwx <= h->ncu && nwx - 1 <= 256) { h->lcb_xs = 16; nwb = nwx; }
     }
-    h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && (h->H & 15) == 0 && !(Bg > 64 && h->R > 1536) &&
+    // (R <= 2048: its kernels hold at most 64 k-steps of K = 4R per wave; the hybrid forward chain above that runs with the
+    // per-step backward)
+    h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && h->R <= 2048 && (h->H & 15) == 0 && !(Bg > 64 && h->R > 1536) &&
                          nwb <= h->ncu && nwb - 1 <= 256;
   }
   {

@@ -24,8 +24,11 @@ struct LocChainArgs {
   int F, T, B, R, H, A, gru;
   int Bs;                             // rows per step of the saved [F][.][.] / [T][.][.] tensors (= batch size; B = rows of THIS launch, a row group; pointers pre-offset; Pw / panels are private to the launch)
   int NU, NG, MS, NC;                 // unit-owner workgroups = NG unit groups x MS row parts; caption workgroups
+  int relay;                          // 1: workgroup NU + NC relays the barriers; 0 (no CU left for it, NU + NC = CU count): every waiter polls the arrival flags itself
   const bf16_t* W; int ldw;           // [4R][ldw] packed [W_ih (H) | W_hh (R) | 0], gate-major rows
   const bf16_t* Wr; int ldwr;         // [A][ldwr] W_r
+  const bf16_t* Wst;                  // hybrid form: the streamed k-steps of W_hh as MFMA B fragments in consumption order,
+                                      // [NG][4 waves][STEPS - SR][4][64 lanes][8] (lc_pack_stream_kernel): every wave load is 1 KB contiguous
   const float* bias;                  // [4R] b_ih + b_hh in the 4-block layout
   const float* Hs; const float* Ud;   // [T][B][H] decoder states, [T][B][A] their projections U_r h_t
   const float* ab; const float* w;    // [A], [A]
@@ -48,6 +51,7 @@ struct LocChainArgs {
 #define LC_TS(role, step, i) do { } while (0)
 #endif
 #define LC_CPW 2              // captions per C workgroup
+#define LC_HYB_SR 12            // hybrid forward chain: k-steps per wave resident in registers (16 spill next to the streaming ring)
 #define LC_MAX_PHASE 128       // barrier words are (launch epoch << 7) + phase: every phase number of a launch stays below this
 __device__ __forceinline__ void lc_poll(const unsigned* flags, int n, unsigned target, unsigned* bar, unsigned& spin) {
   // wave 0 of the relay workgroup: all n <= 256 flags have reached `target`
@@ -79,6 +83,17 @@ __device__ __forceinline__ void lc_wait(const unsigned* rel, unsigned target, un
   }
   __syncthreads();
 }
+// wait for "all n workgroups behind `flags` have arrived with `target`": through the relay's release word, or — when the launch
+// has no relay workgroup — by polling the arrival flags (wave 0; 224 + 32 pollers instead of one: ~+0.7 us per barrier)
+__device__ __forceinline__ void lc_wait_all(int relay, const unsigned* rel, const unsigned* flags, int n, unsigned target, unsigned* bar) {
+  if (relay) { lc_wait(rel, target, bar); return; }
+  if (threadIdx.x < 64) {
+    unsigned spin = 0;
+    lc_poll(flags, n, target, bar, spin);
+    if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
 __device__ __forceinline__ void lc_arrive(unsigned* flag, unsigned v) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -95,9 +110,17 @@ typedef _Float16 lc_h4 __attribute__((ext_vector_type(4)));
 // Flag / release values are fb + phase, fb = launch epoch << 7 (rec_chain.hpp).  Phases: U arrives with s + 1 after
 // publishing hr_s, C arrives with s + 1 after publishing x_s; both arrive with F + 1 when they are done, after which the
 // relay bumps the launch epoch (every workgroup has read it by then).
-template <int STEPS, int PF, int RB>
+// SR < STEPS (R above 2048, BASELINE configs[4]: R = 3584): the hybrid form.  64 gate rows x (H + R) of [W_ih | W_hh] are
+// 512 KB per unit-owner workgroup at R = 3584 — more than a CU's register file.  The fragments of the first SR k-steps of
+// every wave stay resident in registers as before (SR = 16: 256 registers per lane, 57 % of W_hh at R = 3584), the other
+// STEPS - SR k-steps are STREAMED from memory every step through a register ring, inside the recurrent product that runs
+// off the critical path (their addresses do not depend on the chain: the first ring slots are requested before the wait).
+// Per step the chip then streams 43 MB instead of the 117 MB the per-step GEMM reads.  NQ = groups of four unit groups the
+// caption workgroups sum (NG <= 4 NQ).
+template <int STEPS, int PF, int RB, int SR = STEPS, int NQ = 32>
 __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
-  constexpr int CG = 4, UW = 16, ROWS = RB * 16, RED_LD = CG * 16 + 1, NP = STEPS / 2, KG = UW / 8, SX = 4;
+  constexpr int CG = 4, UW = 16, ROWS = RB * 16, RED_LD = CG * 16 + 1, NP = STEPS / 2, KG = UW / 8, SX = 4, NPR = SR / 2;
+  static_assert(SR % 2 == 0 && SR <= STEPS && SR >= 2 * PF, "resident k-steps: whole pairs, at least the prefetch distance");
   extern __shared__ __attribute__((aligned(16))) float lc_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x, R = p.R, B = p.B, Bs = p.Bs, H = p.H, A = p.A, F = p.F, T = p.T;
@@ -106,7 +129,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
   const size_t pan_h = rc_pan_elems(R), pan_x = rc_pan_elems(H);
 
   // ================================================================================== relay workgroup
-  if (wg == p.NU + p.NC) {
+  if (p.relay && wg == p.NU + p.NC) {
     if (tid < 64) {
       unsigned spin = 0;
       for (int s = 0; s < F; ++s) {
@@ -161,21 +184,21 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       // ---- Whr_s[b][j] = sum over the unit groups' rank-16 contributions (fixed order; zero at s = 0: hr_{-1} = 0)
       float whr = 0.f;
       if (s >= 1) {
-        lc_wait(relU, fb + (unsigned)s, p.bar);
+        lc_wait_all(p.relay, relU, p.bar, p.NU, fb + (unsigned)s, p.bar);
         if (ci == 0) LC_TS(1, s, 0);
         // thread = (attention columns 4 aq .. 4 aq + 3, unit groups gg, gg + 4, ..): every load of the step is issued before
         // the first use (one memory round trip; the blocks were written by other XCDs a moment ago and come from memory)
         const int aq = j & 31, gg = j >> 5;
-        lc_h4 v[32];
+        lc_h4 v[NQ];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           const int g = gg + 4 * q;
           v[q] = (bok && 4 * aq < A && g < p.NG) ? *reinterpret_cast<const lc_h4*>(p.Pw + (((size_t)s * B + b) * p.NG + g) * A + 4 * aq)
                                                : lc_h4{0, 0, 0, 0};
         }
         f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 32; q += 4) {
+        for (int q = 0; q < NQ; q += 4) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) a4[e] += ((float)v[q][e] + (float)v[q + 1][e]) + ((float)v[q + 2][e] + (float)v[q + 3][e]);
         }
@@ -231,6 +254,14 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     }
     __syncthreads();
     lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(F + 1));
+    if (!p.relay && ci == 0 && tid < 64) {      // no relay workgroup: this one closes the launch (everybody is done and has read the epoch)
+      unsigned spin = 0;
+      lc_poll(p.bar, p.NU + p.NC, fb + (unsigned)(F + 1), p.bar, spin);
+      if (tid == 0) {
+        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
+      }
+    }
     return;
   }
 
@@ -248,13 +279,15 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
   // ---- residents: W_hh (registers), W_ih (LDS, each lane keeps its own fragments), W_r columns of the own units
-  bf16x8 wb[STEPS][CG];
+  bf16x8 wb[SR][CG];
+  // streamed k-steps (SR < STEPS): this wave's fragments in the pre-packed image, this lane's 16 bytes of each
+  const bf16_t* wst = (SR < STEPS) ? p.Wst + ((size_t)(ug * 4 + wave) * (STEPS - SR) * CG * 64 + lane) * 8 : nullptr;
 #pragma unroll
   for (int g = 0; g < CG; ++g) {
     const int col = g * 16 + (lane & 15), gate = col / UW, ul = col % UW;
     const bf16_t* wrow = p.W + (size_t)(gate * R + u0 + ul) * p.ldw;
 #pragma unroll
-    for (int pr = 0; pr < NP; ++pr)
+    for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         const int k = k_of(pr, hh);
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
 
   for (int s = 0; s < F; ++s) {
     // ---- x_s . W_ih^T on top of the recurrent part (this wave's K slice of both)
-    lc_wait(relC, fb + (unsigned)(s + 1), p.bar);
+    lc_wait_all(p.relay, relC, p.bar + p.NU, p.NC, fb + (unsigned)(s + 1), p.bar);
     if (wg == 0) LC_TS(0, s, 0);
     {
       const bf16_t* Ax = p.PanX + (size_t)s * pan_x + lane_off;
@@ -413,7 +446,28 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     if (more) {
       // ---- the recurrent product of the NEXT step, hr_s . W_hh^T, as soon as every workgroup has published hr_s; the
       // attention of step s + 1 runs in the caption workgroups meanwhile
-      lc_wait(relU, fb + (unsigned)(s + 1), p.bar);
+      // streamed weight fragments (SR < STEPS): ring slot = pair mod PF, like the activations.  Pairs are consumed in the order
+      // streamed first, resident last, so that the resident MFMAs cover the tail of the stream; the first PF streamed pairs
+      // are requested BEFORE the wait (their addresses do not depend on the chain).
+      bf16x8 fw[PF][2][CG];
+      // (the row pointers are laundered through an empty asm every step: as loop invariants the compiler materialised all
+      // 4 (STEPS - SR) 64-bit addresses ahead of the time loop — 128 registers — and spilled them)
+      const bf16_t* wsl = wst;
+      if constexpr (SR < STEPS) asm volatile("" : "+v"(wsl));
+      auto issue_w = [&](int slot, int i) {        // i = streamed pair, in consumption order (= the image's order)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int g = 0; g < CG; ++g) fw[slot][hh][g] = *reinterpret_cast<const bf16x8*>(wsl + (size_t)(((i * 2 + hh) * CG + g) * 512));
+      };
+      constexpr int NPS = NP - NPR;                       // streamed pairs; iteration i < NPS -> pair NPR + i, then the resident pairs
+      auto pair_of = [&](int i) { return i < NPS ? NPR + i : i - NPS; };
+      if constexpr (NPS > 0) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+          if (i < NPS) issue_w(i % PF, i);
+      }
+      lc_wait_all(p.relay, relU, p.bar, p.NU, fb + (unsigned)(s + 1), p.bar);
       if (wg == 0) LC_TS(0, s, 5);
       const bf16_t* Ah = p.PanH + (size_t)s * pan_h + lane_off;
       bf16x8 fa[PF][2][RB];
@@ -423,28 +477,32 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
 #pragma unroll
           for (int i = 0; i < RB; ++i) {
             const int k = k_of(pr, hh);
-            fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(Ah + ((k < R ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+            const int kg = k < R ? (k >> 3) : 0;      // (k-steps beyond R meet zero weights; wave-uniform)
+            fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(Ah + (kg * RC_PAN_ROWS + i * 16) * 8);
           }
       };
 #pragma unroll
-      for (int pr = 0; pr < PF; ++pr)
-        if (pr < NP) issue_pair(pr, pr);
+      for (int i = 0; i < PF; ++i)
+        if (i < NP) issue_pair(i, pair_of(i));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pr = 0; pr < NP; ++pr) {
-        const int slot = pr % PF;
+      for (int it = 0; it < NP; ++it) {
+        const int slot = it % PF;
+        const int pr = pair_of(it);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          const int ks = pr * 2 + hh;
 #pragma unroll
           for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int g = 0; g < CG; ++g)
-              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], wb[ks][g], acc[i][g], 0, 0, 0);
+            for (int g = 0; g < CG; ++g) {
+              const bf16x8 w = it < NPS ? fw[slot][hh][g] : wb[(it < NPS ? 0 : pr * 2 + hh)][g];
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], w, acc[i][g], 0, 0, 0);
+            }
         }
-        if (pr + PF < NP) {
+        if (it + PF < NP) {
           __builtin_amdgcn_sched_barrier(0);
-          issue_pair(slot, pr + PF);
+          issue_pair(slot, pair_of(it + PF));
+          if (it + PF < NPS) issue_w(slot, it + PF);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -453,6 +511,23 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
   }
   __syncthreads();
   lc_arrive(p.bar + wg, fb + (unsigned)(F + 1));
+}
+// The streamed k-steps of the hybrid forward chain as MFMA B fragments, in the order loc_chain_kernel<STEPS, ., ., SR> consumes
+// them (pair NPR + i of its rotated sequence, i = 0 ..): dst[ug][wave][js][g][lane][8].  Run after every update of W_hh.
+__global__ __launch_bounds__(256) void lc_pack_stream_kernel(const bf16_t* __restrict__ W, int ldw, int R, int H, int STEPS, int SR, bf16_t* __restrict__ dst, size_t n_frag) {
+  const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;       // one 16-byte fragment piece per thread
+  if (f >= n_frag) return;
+  const int NS = STEPS - SR, NP = STEPS / 2, NPR = SR / 2;
+  const int lane = (int)(f & 63), g = (int)((f >> 6) & 3);
+  const size_t r = f >> 8;
+  const int js = (int)(r % NS), wave = (int)((r / NS) & 3), ug = (int)(r / NS / 4);
+  const int col = g * 16 + (lane & 15), gate = col / 16, ul = col % 16, kq = (lane >> 4) * 8;
+  int prr = NPR + js / 2 + ug % NP; prr = prr >= NP ? prr - NP : prr;
+  const int k = wave * (STEPS * 32) + (prr * 2 + (js & 1)) * 32;
+  const bf16_t* src = W + (size_t)(gate * R + ug * 16 + ul) * ldw + H + k + kq;
+  bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (k + kq < R) v = *reinterpret_cast<const bf16x8*>(src);
+  *reinterpret_cast<bf16x8*>(dst + f * 8) = v;
 }
 template <int RB> constexpr size_t lc_smem_bytes() {
   return (size_t)4 * RB * 16 * 65 * 4 + (size_t)RB * 16 * 16 * 2 + (size_t)4 * 4 * 4 * 64 * 16;

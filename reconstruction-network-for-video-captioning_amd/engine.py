@@ -284,6 +284,13 @@ class Engine:
         """Completes a pending deferred reconstructor update on the current stream (stream-ordered; no host sync)."""
         _lib.check(self.lib.recnet_flush(self.handle, _stream()), "recnet_flush")
 
+    def debug_tensor(self, which, n):
+        """Test hook: n floats of a saved tensor of the local reconstructor's forward pass (recnet_debug_offset)."""
+        off = self.lib.recnet_debug_offset(self.handle, int(which))
+        assert off >= 0
+        base = (self._ws_ptr - self.workspace.data_ptr()) + off
+        return self.workspace[base:base + 4 * n].view(torch.float32).clone()
+
     def debug_occupy(self, n_workgroups, microseconds, stream=None):
         """Test hook: n_workgroups CU-filling workgroups spinning for `microseconds` on `stream` (a torch stream; default: the current one)."""
         st = C.c_void_p(stream.cuda_stream) if stream is not None else _stream()
