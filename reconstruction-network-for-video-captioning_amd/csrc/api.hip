@@ -241,7 +241,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->lc_pw = (_Float16*)take(F * B * ((R + 15) / 16) * RA / 2 + 64);
     {   // hybrid forward chain: 12 of the (R / 128 rounded up to even) k-steps per wave resident, the others streamed from this image
       int steps = (int)(R + 127) / 128; steps += steps & 1;
-      h->lc_steps = steps > 16 ? (steps <= 28 ? 28 : 32) : 0; h->lc_sr = LC_HYB_SR;
+      h->lc_steps = steps > 16 ? (steps <= 28 ? 28 : 32) : 0; h->lc_sr = LC_HYB_SR(h->lc_steps);
       if (h->lc_steps) h->Wst = takev((R / 16) * 4 * (size_t)(h->lc_steps - h->lc_sr) * 4 * 512 / 2 + 64);
     }
     h->lc_pang = takev(F * rc_pan_elems((int)(4 * R)) / 2 + 64);

@@ -24,7 +24,7 @@ struct LocChainArgs {
   int F, T, B, R, H, A, gru;
   int Bs;                             // rows per step of the saved [F][.][.] / [T][.][.] tensors (= batch size; B = rows of THIS launch, a row group; pointers pre-offset; Pw / panels are private to the launch)
   int NU, NG, MS, NC;                 // unit-owner workgroups = NG unit groups x MS row parts; caption workgroups
-  int relay;                          // 1: workgroup NU + NC relays the barriers; 0 (no CU left for it, NU + NC = CU count): every waiter polls the arrival flags itself
+  int relay;                          // 1: workgroup NU + NC relays the barriers; 0 (no CU left for it, NU + NC = CU count): the last caption workgroup does (lc_wait_or_relay)
   const bf16_t* W; int ldw;           // [4R][ldw] packed [W_ih (H) | W_hh (R) | 0], gate-major rows
   const bf16_t* Wr; int ldwr;         // [A][ldwr] W_r
   const bf16_t* Wst;                  // hybrid form: the streamed k-steps of W_hh as MFMA B fragments in consumption order,
@@ -51,7 +51,9 @@ struct LocChainArgs {
 #define LC_TS(role, step, i) do { } while (0)
 #endif
 #define LC_CPW 2              // captions per C workgroup
-#define LC_HYB_SR 12            // hybrid forward chain: k-steps per wave resident in registers (16 spill next to the streaming ring)
+// hybrid forward chain: k-steps per wave resident in registers for STEPS k-steps in all — as many as compile without scratch
+// next to the streaming ring (28: 14; 32: 12; 16 resident spill 132 bytes per lane)
+#define LC_HYB_SR(STEPS) ((STEPS) == 28 ? 14 : 12)
 #define LC_MAX_PHASE 128       // barrier words are (launch epoch << 7) + phase: every phase number of a launch stays below this
 __device__ __forceinline__ void lc_poll(const unsigned* flags, int n, unsigned target, unsigned* bar, unsigned& spin) {
   // wave 0 of the relay workgroup: all n <= 256 flags have reached `target`
@@ -83,13 +85,16 @@ __device__ __forceinline__ void lc_wait(const unsigned* rel, unsigned target, un
   }
   __syncthreads();
 }
-// wait for "all n workgroups behind `flags` have arrived with `target`": through the relay's release word, or — when the launch
-// has no relay workgroup — by polling the arrival flags (wave 0; 224 + 32 pollers instead of one: ~+0.7 us per barrier)
-__device__ __forceinline__ void lc_wait_all(int relay, const unsigned* rel, const unsigned* flags, int n, unsigned target, unsigned* bar) {
-  if (relay) { lc_wait(rel, target, bar); return; }
+// A launch without a CU for the relay workgroup (NU + NC = CU count) folds the relay into the LAST caption workgroup, in
+// the time it would spend waiting anyway: where the others wait for a release word it polls the arrival flags itself and
+// then writes the release words (`me` = this workgroup is that relay).  One poller, as with the dedicated relay — with every
+// waiter polling the 224 flags the U -> C hand-over took 4.3 us instead of ~2.
+__device__ __forceinline__ void lc_wait_or_relay(bool me, unsigned* rel, const unsigned* flags, int n, unsigned target, unsigned* bar) {
+  if (!me) { lc_wait(rel, target, bar); return; }
   if (threadIdx.x < 64) {
     unsigned spin = 0;
     lc_poll(flags, n, target, bar, spin);
+    lc_release(rel, target);
     if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
@@ -180,11 +185,12 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     if (tid < 128) { swab[2 * tid] = tid < A ? p.w[tid] : 0.f; swab[2 * tid + 1] = tid < A ? p.ab[tid] : 0.f; }
     const uint32_t key = drop_key(p.dd);
     const float invT = 1.0f / (float)T;
+    const bool fold = !p.relay && ci == p.NC - 1;          // this workgroup relays the barriers (no dedicated relay workgroup)
     for (int s = 0; s < F; ++s) {
       // ---- Whr_s[b][j] = sum over the unit groups' rank-16 contributions (fixed order; zero at s = 0: hr_{-1} = 0)
       float whr = 0.f;
       if (s >= 1) {
-        lc_wait_all(p.relay, relU, p.bar, p.NU, fb + (unsigned)s, p.bar);
+        lc_wait_or_relay(fold, relU, p.bar, p.NU, fb + (unsigned)s, p.bar);
         if (ci == 0) LC_TS(1, s, 0);
         // thread = (attention columns 4 aq .. 4 aq + 3, unit groups gg, gg + 4, ..): every load of the step is issued before
         // the first use (one memory round trip; the blocks were written by other XCDs a moment ago and come from memory)
@@ -251,6 +257,11 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(s + 1));
       if (ci == 0) LC_TS(1, s, 3);
       if (pon) *reinterpret_cast<bf16x8*>(p.Xcat + ((size_t)s * Bs + pb) * p.ld_xcat + kg * 8) = *reinterpret_cast<const bf16x8*>(xl + pc * 512 + kg * 8);
+      if (fold && tid < 64) {      // "every caption workgroup has published x_s": release the unit owners
+        unsigned spin = 0;
+        lc_poll(p.bar + p.NU, p.NC, fb + (unsigned)(s + 1), p.bar, spin);
+        lc_release(relC, fb + (unsigned)(s + 1));
+      }
     }
     __syncthreads();
     lc_arrive(p.bar + p.NU + ci, fb + (unsigned)(F + 1));
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
 
   for (int s = 0; s < F; ++s) {
     // ---- x_s . W_ih^T on top of the recurrent part (this wave's K slice of both)
-    lc_wait_all(p.relay, relC, p.bar + p.NU, p.NC, fb + (unsigned)(s + 1), p.bar);
+    lc_wait(relC, fb + (unsigned)(s + 1), p.bar);
     if (wg == 0) LC_TS(0, s, 0);
     {
       const bf16_t* Ax = p.PanX + (size_t)s * pan_x + lane_off;
@@ -467,7 +478,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
         for (int i = 0; i < PF; ++i)
           if (i < NPS) issue_w(i % PF, i);
       }
-      lc_wait_all(p.relay, relU, p.bar, p.NU, fb + (unsigned)(s + 1), p.bar);
+      lc_wait(relU, fb + (unsigned)(s + 1), p.bar);
       if (wg == 0) LC_TS(0, s, 5);
       const bf16_t* Ah = p.PanH + (size_t)s * pan_h + lane_off;
       bf16x8 fa[PF][2][RB];
