@@ -65,6 +65,7 @@ struct recnet_handle {
   float* scal;           // [0] dec_ce [1] dec_reg [2] dec_loss [3] rec_mse [4] rec_reg [5] rec_loss [6] total [7] gnorm [8] clip
   // ---- decoder: fp32 state
   float *slab2 = nullptr;   // second slab buffer (local reconstructor backward: dWhr . W_r)
+  float *slab3 = nullptr;   // third: the dx part of the per-step backward product when it runs as its own branch (bwd_rec_local)
   float *bsum4 = nullptr, *bsum4r = nullptr;   // [4H], [4R] column sums of the gate gradients (source of both bias gradients)
   int prezeroed = 0;        // the step's atomic-sum targets were zeroed by one hoisted kernel (fwd_bwd)
   float *bsum_d, *Uv, *Xe, *Hs, *Cs, *acts, *Wh, *att, *logits, *rowloss, *slab, *gws, *dHs, *dHsrec, *dc_carry, *dUv,
@@ -235,7 +236,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->dGr = takev(F * B * ld4R); h->dUd_lp = takev(Tm * B * ldRA); h->dWhr = takev(F * B * (size_t)h->ldRA4);
     h->dWhrs = takev(F * B * ldRA); h->Wr4_w = takev(RN_TCH * RA * ldR);
     h->Ur_w = takev(RA * ldH); h->Wr_w = takev(RA * ldR); h->Wihh_w = takev(4 * R * ldHR);
-    h->slab2 = take(16 * B * R);
+    h->slab2 = take(16 * B * R); h->slab3 = take(16 * B * H);
     h->lc_panh = takev(F * rc_pan_elems((int)R) / 2 + 64);
     h->lc_panx = takev(F * rc_pan_elems((int)H) / 2 + 64);
     h->lc_pw = (_Float16*)take(F * B * ((R + 15) / 16) * RA / 2 + 64);

@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void loc_attn_fwd_kernel(const LocAttnArgs p) 
 #define RN_TCH 4
 struct LocBwdArgs {
   int s, B, T, H, R, A, S;
-  const float* slab;      // [S][B][H+R]
+  int slab_w;             // row width of the slabs: 0 = H + R (dx in columns [0, H) of the [dx | dhr] product), else the width given (H: dx only)
+  const float* slab;      // [S][B][slab width]
   const float* Hs; const float* Ud; const float* ab; const float* w;
   const float* Whr;       // [B][A] of step s
   const float* beta;      // [B][T] of step s
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void loc_attn_bwd_kernel(const LocBwdArgs p) {
   float* spart = sbt + p.T;     // [2][G][A]
   const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, R = p.R, A = p.A, T = p.T;
-  const int W2 = H + R;
+  const int W2 = p.slab_w ? p.slab_w : H + R;
   const size_t zs = (size_t)p.B * W2;
   const uint32_t key = drop_key(p.dd);
   const float invT = 1.0f / (float)T;
