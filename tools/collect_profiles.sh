@@ -1,39 +1,62 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): bench lines, rocprofv3 kernel statistics and PMC traffic passes of the four GPU
-# configurations of BASELINE.json, written under gpurun_out/r02/ (copied into profiles/ afterwards).
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
+# Runs on the GPU box (gpurun): bench lines, rocprofv3 kernel statistics, step timelines and PMC traffic passes of the GPU
+# configurations of BASELINE.json, written under gpurun_out/r03/ (copied into profiles/ afterwards).
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02; mkdir -p $O
-run() {  # name rec batch frames feat extra
-  local n=$1 args="--rec $2 --batch $3 --frames $4 --feat $5"
-  python3 bench.py $args $6 > $O/bench_$n.json 2> $O/bench_$n.err
-  rocprofv3 --kernel-trace --stats -d $O/prof_$n -o $n -- python3 bench.py $args --no-cpu-baseline --steps 30 > $O/bench_under_rocprof_$n.json 2>/dev/null
+RND=r03
+O=gpurun_out/$RND; mkdir -p $O
+run() {  # name "bench args" extra
+  local n=$1 args="$2"
+  python3 bench.py $args $3 > $O/bench_$n.json 2> $O/bench_$n.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_$n -o $n -- python3 bench.py $args --no-cpu-baseline --no-fp32-exact --steps 30 > $O/bench_under_rocprof_$n.json 2>/dev/null
   python3 tools/rocpd_stats.py $O/prof_$n/${n}_results.db > $O/kernel_stats_$n.csv
   python3 tools/step_timeline.py $O/prof_$n/${n}_results.db 5 > $O/timeline_$n.txt
 }
-pmc() {  # name rec batch frames feat kind kernel-pattern...   (one pair of counter passes per configuration, parsed per kernel)
-  local n=$1 args="--rec $2 --batch $3 --frames $4 --feat $5" kind=$6 B=$3 F=$4 D=$5
+pmc() {  # name "bench args" kind B F D  kernel-pattern...   (one pair of counter passes per configuration, parsed per kernel)
+  local n=$1 args="$2" kind=$3 B=$4 F=$5 D=$6
   shift 6
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${n}_$c -- python3 bench.py $args --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${n}_$c -- python3 bench.py $args --no-cpu-baseline --no-fp32-exact --steps 10 --warmup 3 > /dev/null 2>&1
   done
   for pat in "$@"; do
+    local fn=$(echo "$pat" | tr -c 'A-Za-z0-9_' '_' | sed 's/__*/_/g; s/_$//')
     python3 tools/pmc_traffic.py $O/pmc_${n}_FETCH_SIZE $O/pmc_${n}_WRITE_SIZE "$pat" | python3 -c "
-import json,sys; d=json.load(sys.stdin); d.update(B=$B, F=$F, D=$D, kind='$kind', T=31, cell='LSTM'); print(json.dumps(d))" > $O/pmc_traffic_${kind}_$pat.json
+import json,sys; d=json.load(sys.stdin); d.update(B=$B, F=$F, D=$D, kind='$kind', T=31, cell='LSTM', config='$n'); print(json.dumps(d))" > $O/pmc_traffic_${n}_$fn.json
   done
 }
-# counter passes first: the bench lines below read the traffic of their dominant kernel from profiles/r02_pmc_traffic_*.json
-pmc c2 global 100 28 1536 global dec_chain_kernel dec_chain_bwd_kernel rec_chain_kernel rec_chain_bwd_kernel
-pmc c3 local 100 28 1536 local loc_chain_kernel loc_chain_bwd_kernel
-for f in $O/pmc_traffic_*.json; do cp $f profiles/r02_$(basename $f); done
-run c2 global 100 28 1536 ""
-run c3 local 100 28 1536 "--no-cpu-baseline"
-run c4 local 32 40 2048 "--no-cpu-baseline"
-run c5 local 64 28 3584 "--no-cpu-baseline"
-python3 bench.py --rec global --precision f32 --no-cpu-baseline > $O/bench_c2_f32.json 2>/dev/null
-python3 bench.py --rec local --precision f32 --no-cpu-baseline > $O/bench_c3_f32.json 2>/dev/null
-python3 bench.py --rec none --no-cpu-baseline > $O/bench_decoder_only.json 2>/dev/null
-python3 bench.py --rec global --lengths msvd --no-cpu-baseline > $O/bench_c2_msvd_lengths.json 2>/dev/null
-python3 bench.py --rec global --cell GRU --no-cpu-baseline > $O/bench_c2_gru.json 2>/dev/null
+C2=""; C3="--rec local"; C4="--rec local --batch 32 --frames 40 --feat 2048"; C5="--rec local --batch 64 --frames 28 --feat 3584"
+# counter passes first: the bench lines below read the traffic of their dominant kernel from profiles/${RND}_pmc_traffic_*.json
+pmc c2 "$C2" global 100 28 1536 dec_chain_kernel dec_chain_bwd_kernel rec_chain_kernel rec_chain_bwd_kernel
+pmc c3 "$C3" local 100 28 1536 loc_chain_kernel loc_chain_bwd_kernel
+pmc c4 "$C4" local 32 40 2048 loc_chain_kernel loc_chain_bwd_kernel dec_chain_kernel dec_chain_bwd_kernel
+pmc c5 "$C5" local 64 28 3584 loc_chain_kernel "gemm_lds_kernel<false, true, 4, 4, 128>" dec_chain_bwd_kernel
+for f in $O/pmc_traffic_*.json; do cp $f profiles/${RND}_$(basename $f); done
+run c2 "$C2" ""
+run c3 "$C3" "--no-cpu-baseline"
+run c4 "$C4" "--no-cpu-baseline --no-fp32-exact"
+run c5 "$C5" "--no-cpu-baseline --no-fp32-exact"
+x="--no-cpu-baseline --no-fp32-exact"
+python3 bench.py --precision f32 $x > $O/bench_c2_f32.json 2>/dev/null
+python3 bench.py --rec local --precision f32 $x > $O/bench_c3_f32.json 2>/dev/null
+python3 bench.py --rec none $x > $O/bench_decoder_only.json 2>/dev/null
+python3 bench.py --lengths msvd $x > $O/bench_c2_msvd_lengths.json 2>/dev/null
+python3 bench.py --cell GRU $x > $O/bench_c2_gru.json 2>/dev/null
+# batches above the 112-row panels (row groups): C2 at B = 200, C4's weak-scaling variant (256 captions per GPU, 40 x 2048), and
+# the same on the per-step kernels (RN_ROW_GROUPS=0)
+python3 bench.py --batch 200 $x > $O/bench_c2_B200.json 2>/dev/null
+RN_ROW_GROUPS=0 python3 bench.py --batch 200 $x > $O/bench_c2_B200_per_step_kernels.json 2>/dev/null
+python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c4_weak_B256.json 2>/dev/null
+RN_ROW_GROUPS=0 python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c4_weak_B256_per_step_kernels.json 2>/dev/null
+RN_LOC_HYBRID=0 python3 bench.py $C5 $x > $O/bench_c5_per_step_forward.json 2>/dev/null
+# PCIe-inclusive rate (never `value`): every step takes a fresh host batch through feed.DeviceFeeder
+python3 bench.py --feed 1 $x > $O/bench_c2_host_feed.json 2>/dev/null
+python3 bench.py --defer 1 $x > $O/bench_c2_deferred_reconstructor_update.json 2>/dev/null
+python3 tools/rccl_bucket_bench.py > $O/rccl_buckets_1rank_c2.json 2>/dev/null
+for cfg in c2 c5; do
+  a="$C2"; [ $cfg = c5 ] && a="$C5"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$cfg -- python3 bench.py $a $x --steps 10 --warmup 3 > /dev/null 2>&1
+  python3 tools/pmc_mfma.py $O/pmc_mfma_$cfg > $O/pmc_mfma_$cfg.json 2>/dev/null
+  rm -rf $O/pmc_mfma_$cfg
+done
 rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/prof_*
 ls -la $O
