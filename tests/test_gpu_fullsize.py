@@ -1,5 +1,6 @@
 """Size-independent properties of the train step at the benchmark's FULL size (BASELINE.json configs[1]/[2]: B=100,
-28x1536 features, V=4188, E=468, H=512, A=128, R=1536, T=31), where the CPU oracle is too slow to be the checker:
+28x1536 features, V=4188, E=468, H=512, A=128, R=1536, T=31).  (Element-wise comparison with the oracle at these sizes is
+tests/test_gpu_configs.py; these are the properties that hold whatever the checker.)
 
   * caption order does not matter: permuting the batch (dropout off) leaves the losses and every gradient unchanged;
   * the batch shards exactly: a 60 + 40 split with the GLOBAL normalisers and the global caption index in the dropout
