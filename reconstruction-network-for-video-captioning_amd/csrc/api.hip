@@ -29,6 +29,7 @@
 #include "rec_chain.hpp"
 #include "dec_chain.hpp"
 #include "loc_chain.hpp"
+#include "loc_big.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& m) { g_err = m; return code; }
@@ -80,6 +81,8 @@ struct recnet_handle {
   float *bsum_r, *mp, *Xg, *Hr, *Cr, *acts_r, *hrmean, *outm, *encmean, *dhrmean, *dmpd, *dmp, *dcr_carry;
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void* Hr_pan = nullptr;
+  // backward chain for R > 2048 (loc_big.hpp): K partials, per-step masked dx / dbeta for the post-chain sums, streamed fragments of W^T
+  float *lb_part = nullptr, *lb_dxm = nullptr, *lb_dbeta = nullptr; void* WstT = nullptr; int persist_big_bwd = 0, lb_steps = 0, lb_sr = 0, lb_ncb = 0;
   void* Wst = nullptr; int lc_steps = 0, lc_sr = 0;   // hybrid forward chain (R > 2048): streamed fragments image, k-steps per wave / resident
   void *lc_panh = nullptr, *lc_panx = nullptr; _Float16* lc_pw = nullptr;   // loc_chain.hpp exchange buffers
   void *lc_pang = nullptr, *lc_panw = nullptr; float* lc_dx = nullptr; void* WihhT = nullptr;   // ... of the backward chain; [W_ih | W_hh]^T
@@ -249,6 +252,13 @@ static size_t carve(recnet_handle* h, char* base) {
     h->lc_panw = takev(F * rc_pan_elems((int)RA) / 2 + 64);
     h->lc_dx = take(F * 4 * B * H);     // up to 4 K parts (lcb_xsplit_role)
     h->WihhT = takev((H + R) * (size_t)h->ld4R);
+    if (R > 2048 && R % 128 == 0 && B <= 64) {     // the large-R backward chain (loc_big.hpp; eligibility: recnet_create)
+      const int steps = (int)R / 128;
+      h->lb_steps = steps; h->lb_sr = LB_SR(steps); h->lb_ncb = (int)(H + R) / 64;
+      h->lb_part = take(F * 4 * 64 * (H + R));
+      h->lb_dxm = take(F * B * H); h->lb_dbeta = take(F * B * Tm);
+      h->WstT = takev((size_t)h->lb_ncb * 4 * 4 * (size_t)(steps - h->lb_sr) * 4 * 512 / 2 + 64);
+    }
   }
   // optimiser tables (sizes are upper bounds; filled at bind time)
   for (int g = 0; g < 2; ++g) {
@@ -368,6 +378,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     }
     // (R <= 2048: its kernels hold at most 64 k-steps of K = 4R per wave; the hybrid forward chain above that runs with the
     // per-step backward)
+    {   // R above 2048: the phased backward chain of loc_big.hpp (P / C / L phases of (H + R) / 64 * 4 workgroups)
+      const int ebig = getenv("RN_PERSIST_LOC_BIG") ? atoi(getenv("RN_PERSIST_LOC_BIG")) : 1;
+      const int steps = h->R / 128, nwg = (h->H + h->R) / 64 * 4;
+      h->persist_big_bwd = ebig && (eb ? atoi(eb) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && h->R > 2048 && h->R % 128 == 0 &&
+                           (steps == 24 || steps == 28 || steps == 32) && h->H % 64 == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 7) == 0 &&
+                           h->B <= 64 && Bg == h->B && h->Tm <= 32 && h->F <= 40 && nwg <= h->ncu && nwg <= 256 && h->R / 16 < nwg && h->B < nwg;
+    }
     h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && h->R <= 2048 && (h->H & 15) == 0 && !(Bg > 64 && h->R > 1536) &&
                          nwb <= h->ncu && nwb - 1 <= 256;
   }

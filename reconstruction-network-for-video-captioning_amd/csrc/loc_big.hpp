@@ -1,0 +1,425 @@
+// The local reconstructor's BACKWARD chain for R above 2048 (BASELINE configs[4]: R = 3584, 64 captions per GPU) as ONE launch —
+// the mirror of local_reconstructor.py:37-55 inside train.py:122-123, chain step q <-> s = F-1-q:
+//   dhr_s = dHr[s] + dG_{s+1} . W_hh + dWhr_{s+1} . W_r ;  (dG_s, dc) = cell backward
+//   dx_s  = dropmask(s) * (dG_s . W_ih) ;  attention backward of step s: dbeta_s, dWhr_s
+// loc_chain_bwd_kernel (loc_chain.hpp) keeps [W_ih | W_hh]^T register-resident in workgroups that own 16 output columns over the
+// whole contraction; at K = 4R = 14336 such a workgroup would read the whole 1.8 MB gate-gradient panel every step and hold
+// 458 KB of weights.  Here the product [dx | dhr] = dG . [W_ih | W_hh] is cut like the forward's hybrid chain, transposed:
+//   P  (every workgroup): 64 output columns x one K quarter (R gate rows).  Per wave STEPS k-steps of 32: SR resident in
+//      registers, the rest streamed every step from a fragment-major image (1 KB per wave load), through a register ring.
+//      Reads its 64-row slice of the panel (458 KB at R = 3584), writes a [64 x 64] fp32 partial (16 KB, written through).
+//   C  (workgroup b < B): caption b.  Stateless: sums the 4 K partials of dx_s, applies the dropout mask, dbeta_s = (1/T) dx . h_t
+//      (h_t re-read from L2: 63 KB), the (t, k) plane for dWhr_s.  What loc_chain_bwd_kernel accumulates in registers over the F
+//      steps (dHs, dUd, dw) is rebuilt AFTER the chain from the per-step dbeta_s and masked dx_s (lcbig_dhs_kernel,
+//      lcbig_dud_kernel): the sums over s commute with everything else.
+//   L  (workgroup j < R / 16): 16 hidden units x all rows.  dhr_{s} from the direct gradient, the 4 K partials of the step
+//      before and dWhr . W_r (K = A <= 128, MFMA); cell backward with the dc carry in registers; publishes dG_s.
+// The three stages of a step are strictly sequential, so they are PHASES of the same NWG = (H + R) / 64 * 4 workgroups (256 at
+// R = 3584, H = 512: every CU) between three grid barriers per step; the last workgroup relays the barriers (lc_wait_or_relay).
+// Limits (host-checked): bf16 path, B <= 64, R % 128 == 0 with R / 128 in {24, 28, 32} (even), H % 64 == 0, H <= 512, A <= 128,
+// T <= 32, F <= 40, NWG <= CU count.
+#pragma once
+#include "common.hpp"
+#include "rec_chain.hpp"
+#include "loc_chain.hpp"
+
+// resident k-steps per wave for STEPS k-steps in all (as many as compile without scratch next to the streaming ring)
+#define LB_SR(STEPS) ((STEPS) == 32 ? 12 : 14)
+
+struct LocBigBwdArgs {
+  int F, T, B, Bs, R, H, A, gru;
+  int NCB, NWG;                       // column blocks of 64 over [x | hr]; workgroups = 4 NCB (four K quarters)
+  const bf16_t* WT; int ldwt;         // [H + R][ldwt]: ([W_ih | W_hh])^T, K = 4R (gate-major) contiguous
+  const bf16_t* WstT;                 // streamed k-steps as MFMA B fragments in consumption order, [NWG][4 waves][STEPS - SR][4][64][8]
+  const bf16_t* Wr; int ldwr;         // [A][ldwr]
+  const float* dHr;                   // [F][B][R] d loss / d hr_s through the output layer
+  const float* acts; const float* Cr; const float* Hr;     // saved by the forward
+  const float* Hs; const float* Ud; const float* ab; const float* w; const float* Whr;
+  bf16_t* dG; int ld_dg;              // [F][B][ld_dg] row-major gate gradients (deferred weight-gradient GEMMs)
+  bf16_t* dWhrs; int ld_dwhr;         // [F][B][ld_dwhr] row-major dWhr_s
+  float* dxm; float* dbeta;           // [F][B][H] masked dx_s, [F][B][T] dbeta_s (by step s): what the post-chain kernels sum
+  bf16_t* PanG; bf16_t* PanW; float* Part;   // exchange, by chain step q: [F][rc_pan_elems(4R)], [F][rc_pan_elems(A)], [F][4][64][H + R]
+  unsigned* bar; unsigned* epoch; float* poison;
+  DropDesc dd;
+};
+
+template <int STEPS, int SR, int PF>
+__global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
+  constexpr int RB = 4, CG = 4, ROWS = 64, RED_LD = 65, NP = STEPS / 2, NPR = SR / 2, NPS = NP - NPR, UW = 16;
+  static_assert(SR % 2 == 0 && SR <= STEPS && SR >= 2 * PF, "resident k-steps: whole pairs, at least the prefetch distance");
+  extern __shared__ __attribute__((aligned(16))) float lb_smem[];
+  float* red = lb_smem;                                                      // [4 waves][ROWS][RED_LD]; phase C aliases it
+  bf16_t* hl = reinterpret_cast<bf16_t*>(lb_smem + 4 * ROWS * RED_LD);       // [ROWS][4 gates][UW]: dG_s of this workgroup's units
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = blockIdx.x, R = p.R, B = p.B, Bs = p.Bs, H = p.H, A = p.A, F = p.F, T = p.T, K = 4 * R, NT = H + R;
+  const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
+  unsigned* rel = p.bar + 256;
+  const size_t pan_g = rc_pan_elems(K), pan_w = rc_pan_elems(A);
+  const bool relay = wg == p.NWG - 1;
+  const int kq = (lane >> 4) * 8;
+  const uint32_t key = drop_key(p.dd);
+  const float invT = 1.0f / (float)T;
+  // every workgroup arrives at every barrier (idle ones at once); the write-through stores of the phase are acknowledged first
+  auto barrier = [&](unsigned phase) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lc_arrive(p.bar + wg, fb + phase);
+    lc_wait_or_relay(relay, rel, p.bar, p.NWG, fb + phase, p.bar);
+  };
+
+  // ---------------------------------------------------------------- P: residents
+  const int cb = wg % p.NCB, kqi = wg / p.NCB;
+  const int kw0 = kqi * R + wave * (STEPS * 32);            // this wave's K range inside the quarter (K quarter = R gate rows)
+  const int rot = wg % NP;
+  auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
+  bf16x8 wb[SR][CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) {
+    const bf16_t* wrow = p.WT + (size_t)(cb * 64 + g * 16 + (lane & 15)) * p.ldwt + kq;
+#pragma unroll
+    for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) wb[pr * 2 + hh][g] = *reinterpret_cast<const bf16x8*>(wrow + k_of(pr, hh));
+  }
+  const bf16_t* wst = p.WstT + ((size_t)(wg * 4 + wave) * (STEPS - SR) * CG * 64 + lane) * 8;
+  const int lane_off = ((lane >> 4) * RC_PAN_ROWS + (lane & 15)) * 8;          // k-group (lane / 16), row lane % 16
+
+  // ---------------------------------------------------------------- L: residents (workgroups j < R / 16)
+  const bool isL = wg < R / UW, isC = wg < B;
+  const int u0 = wg * UW;
+  const int lrow = tid >> 2, luq = (tid & 3) * 4;          // this thread's cells: row lrow, units u0 + luq .. + 4
+  bf16x8 wrt;                                               // W_r^T fragment of the small product: B[k = a][n = unit]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int a = wave * 32 + kq + e;
+    wrt[e] = (isL && a < A) ? p.Wr[(size_t)a * p.ldwr + u0 + (lane & 15)] : (bf16_t)0.f;
+  }
+  float carry[4] = {0.f, 0.f, 0.f, 0.f};
+
+  for (int q = 0; q < F; ++q) {
+    const int s = F - 1 - q;
+    // ============================================================ L(q): dhr_s, cell backward, dG_s
+    // streamed weight fragments of P(q): their addresses do not depend on the chain — the first ring slots are requested now
+    bf16x8 fw[PF][2][CG];
+    const bf16_t* wsl = wst;
+    asm volatile("" : "+v"(wsl));          // (laundered every step: as loop invariants the addresses were materialised ahead of the loop and spilled)
+    auto issue_w = [&](int slot, int i) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) fw[slot][hh][g] = *reinterpret_cast<const bf16x8*>(wsl + (size_t)(((i * 2 + hh) * CG + g) * 512));
+    };
+    if (isL) {
+      if (q > 0) {
+        // dWhr_{s+1} . W_r : K = A <= 128, one k-step per wave
+        f32x4 a1[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) a1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int k = wave * 32;
+        if (k < A) {
+          const bf16_t* Aw = p.PanW + (size_t)(q - 1) * pan_w + lane_off;
+#pragma unroll
+          for (int i = 0; i < RB; ++i) {
+            const bf16x8 fr = *reinterpret_cast<const bf16x8*>(Aw + ((k >> 3) * RC_PAN_ROWS + i * 16) * 8);
+            a1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, wrt, a1[i], 0, 0, 0);
+          }
+        }
+        float* prt = red + wave * (ROWS * RED_LD);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + (lane & 15)] = a1[i][r];
+      }
+      // saved activations, states, the direct gradient and the K partials of the step before: all in flight together
+      const size_t row = lrow < B ? lrow : 0;
+      const int u = u0 + luq;
+      f32x4 av[4], cc = {0.f, 0.f, 0.f, 0.f}, cp = {0.f, 0.f, 0.f, 0.f}, dh, pk[4];
+      const float* a = p.acts + ((size_t)s * Bs + row) * 4 * R + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) av[g] = *reinterpret_cast<const f32x4*>(a + (size_t)g * R);
+      if (!p.gru) cc = *reinterpret_cast<const f32x4*>(p.Cr + ((size_t)s * Bs + row) * R + u);
+      if (s > 0) cp = *reinterpret_cast<const f32x4*>((p.gru ? p.Hr : p.Cr) + ((size_t)(s - 1) * Bs + row) * R + u);
+      dh = *reinterpret_cast<const f32x4*>(p.dHr + ((size_t)s * Bs + row) * R + u);
+      if (q > 0) {
+#pragma unroll
+        for (int z = 0; z < 4; ++z) pk[z] = *reinterpret_cast<const f32x4*>(p.Part + (((size_t)(q - 1) * 4 + z) * ROWS + lrow) * NT + H + u);
+      }
+      __syncthreads();
+      if (q > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = (pk[0][e] + pk[1][e]) + (pk[2][e] + pk[3][e]);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + lrow * RED_LD + luq + e];
+          dh[e] += v;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const LstmGrad g = p.gru ? gru_point_bwd(dh[e] + carry[e], av[0][e], av[1][e], av[2][e], av[3][e], cp[e])
+                                 : lstm_point_bwd(dh[e], carry[e], av[0][e], av[1][e], av[2][e], av[3][e], cc[e], cp[e]);
+        carry[e] = g.dc_prev;
+        bf16_t* d = hl + (size_t)lrow * 4 * UW + luq + e;
+        d[0] = (bf16_t)g.di; d[UW] = (bf16_t)g.df; d[2 * UW] = (bf16_t)g.dg; d[3 * UW] = (bf16_t)g.d_o;
+      }
+      __syncthreads();
+      // publish dG_s: 4 gates x 2 k-groups x 64 rows items of 16 bytes (written through), and the row-major copy
+      bf16_t* Gt = p.dG + (size_t)s * Bs * p.ld_dg;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int idx = tid + jj * 256, gq = idx >> 7, kgi = (idx >> 6) & 1, rg = idx & 63;
+        const int col = gq * R + u0 + kgi * 8;
+        const bf16_t* src = hl + ((size_t)rg * 4 + gq) * UW + kgi * 8;
+        if (rg < B) {
+          lc_store16(p.PanG + (size_t)q * pan_g + ((size_t)(col >> 3) * RC_PAN_ROWS + rg) * 8, src);
+          *reinterpret_cast<bf16x8*>(Gt + (size_t)rg * p.ld_dg + col) = *reinterpret_cast<const bf16x8*>(src);
+        }
+      }
+      if (wg == 0 && p.ld_dg > K)
+        for (int jj = tid; jj < B * (p.ld_dg - K); jj += 256) Gt[(size_t)(jj / (p.ld_dg - K)) * p.ld_dg + K + jj % (p.ld_dg - K)] = (bf16_t)0.f;
+    }
+    if constexpr (NPS > 0) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i)
+        if (i < NPS) issue_w(i % PF, i);
+    }
+    barrier(3u * (unsigned)q + 1u);
+
+    // ============================================================ P(q): partial [dx | dhr] of this tile
+    {
+      auto pair_of = [&](int i) { return i < NPS ? NPR + i : i - NPS; };      // streamed pairs first, the resident ones cover their tail
+      const bf16_t* Ag = p.PanG + (size_t)q * pan_g + lane_off;
+      bf16x8 fa[PF][2][RB];
+      auto issue_pair = [&](int slot, int pr) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < RB; ++i) fa[slot][hh][i] = *reinterpret_cast<const bf16x8*>(Ag + ((size_t)(k_of(pr, hh) >> 3) * RC_PAN_ROWS + i * 16) * 8);
+      };
+      f32x4 acc[RB][CG];
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < CG; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < PF; ++i)
+        if (i < NP) issue_pair(i, pair_of(i));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int slot = it % PF;
+        const int pr = pair_of(it);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int g = 0; g < CG; ++g) {
+              const bf16x8 w = it < NPS ? fw[slot][hh][g] : wb[(it < NPS ? 0 : pr * 2 + hh)][g];
+              acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], w, acc[i][g], 0, 0, 0);
+            }
+        if (it + PF < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_pair(slot, pair_of(it + PF));
+          if (it + PF < NPS) issue_w(slot, it + PF);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      float* prt = red + wave * (ROWS * RED_LD);
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < CG; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + g * 16 + (lane & 15)] = acc[i][g][r];
+      __syncthreads();
+      // thread = (row tid / 4, 16 columns): the four waves' K parts summed, written through
+      const int prow = tid >> 2, pc0 = (tid & 3) * 16;
+      float* dst = p.Part + (((size_t)q * 4 + kqi) * ROWS + prow) * NT + cb * 64 + pc0;
+#pragma unroll
+      for (int c2 = 0; c2 < 16; c2 += 2) {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { v0 += red[w * (ROWS * RED_LD) + prow * RED_LD + pc0 + c2]; v1 += red[w * (ROWS * RED_LD) + prow * RED_LD + pc0 + c2 + 1]; }
+        union { float f[2]; uint64_t u; } pk2;
+        pk2.f[0] = v0; pk2.f[1] = v1;
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + c2), pk2.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // phase C's saved operands do not depend on the chain: requested before the barrier
+    const int tt = tid & 31, h8 = tid >> 5;                   // (decoder step, eighth of the hidden columns)
+    const int ck = tid & 127, cth = tid >> 7;                 // (attention column, half of the decoder steps)
+    float hv[64], udv[16], whk = 0.f, wk = 0.f;
+    if (isC) {
+      // (loop-invariant addresses: laundered, or the compiler keeps all 32 of them in registers across the whole step)
+      const float* hs0 = p.Hs + ((size_t)(tt < T ? tt : 0) * Bs + wg) * H + 64 * h8;
+      const float* ud0 = p.Ud + ((size_t)(cth * 16) * Bs + wg) * A + (ck < A ? ck : 0);
+      asm volatile("" : "+v"(hs0), "+v"(ud0));
+#pragma unroll
+      for (int i = 0; i < 64; i += 4) {
+        const int h = 64 * h8 + i;
+        const f32x4 v = (tt < T && h < H) ? *reinterpret_cast<const f32x4*>(hs0 + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        hv[i] = v[0]; hv[i + 1] = v[1]; hv[i + 2] = v[2]; hv[i + 3] = v[3];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = cth * 16 + i;
+        udv[i] = (t < T && ck < A) ? ud0[(size_t)i * Bs * A] : 0.f;
+      }
+      if (ck < A) { whk = p.Whr[((size_t)s * Bs + wg) * A + ck] + p.ab[ck]; wk = p.w[ck]; }
+    }
+    barrier(3u * (unsigned)q + 2u);
+
+    // ============================================================ C(q): attention backward of step s for caption wg
+    if (isC) {
+      float* sdx = red;                    // [512] masked dx_s
+      float* spd = sdx + 512;              // [8][32] partial dbeta
+      float* sdbt = spd + 256;             // [32] dbeta
+      float* sdw = sdbt + 32;              // [2][128] partial dWhr
+      bf16_t* swl = reinterpret_cast<bf16_t*>(sdw + 256);   // [128] dWhr_s (bf16)
+      const int b = wg;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int h = tid + 256 * qq;
+        if (h < H) {
+          float v[4];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) v[z] = p.Part[(((size_t)q * 4 + z) * ROWS + b) * NT + h];
+          const float d = ((v[0] + v[1]) + (v[2] + v[3])) * drop_at(p.dd, key, s, b, H, h);
+          sdx[h] = d;
+          p.dxm[((size_t)s * Bs + b) * H + h] = d;
+        } else if (h < 512) {
+          sdx[h] = 0.f;
+        }
+      }
+      __syncthreads();
+      {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) {
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(sdx + 64 * h8 + i);
+          v0 += d4[0] * hv[i] + d4[2] * hv[i + 2];
+          v1 += d4[1] * hv[i + 1] + d4[3] * hv[i + 3];
+        }
+        spd[h8 * 32 + tt] = v0 + v1;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        float v = 0.f;
+#pragma unroll
+        for (int z = 0; z < 8; ++z) v += spd[z * 32 + tid];
+        v *= invT;
+        sdbt[tid] = v;
+        if (tid < T) p.dbeta[((size_t)s * Bs + b) * T + tid] = v;
+      }
+      __syncthreads();
+      {
+        float dwh = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int t = cth * 16 + i;
+          if (t < T) {
+            const float tz = rn_tanh(whk + udv[i]);
+            dwh += sdbt[t] * wk * (1.f - tz * tz);
+          }
+        }
+        sdw[cth * 128 + ck] = dwh;
+      }
+      __syncthreads();
+      if (tid < 128) swl[tid] = (bf16_t)(tid < A ? sdw[tid] + sdw[128 + tid] : 0.f);
+      __syncthreads();
+      // publish dWhr_s[b] (k-groups up to the next multiple of 32 columns; swl holds zeros beyond A) + the row-major copy
+      if (tid < (((A + 31) >> 5) << 2)) lc_store16(p.PanW + (size_t)q * pan_w + ((size_t)tid * RC_PAN_ROWS + b) * 8, swl + tid * 8);
+      if (tid < (p.ld_dwhr >> 3) && tid < 16)
+        *reinterpret_cast<bf16x8*>(p.dWhrs + ((size_t)s * Bs + b) * p.ld_dwhr + tid * 8) = *reinterpret_cast<const bf16x8*>(swl + tid * 8);
+    }
+    barrier(3u * (unsigned)q + 3u);
+  }
+  // everybody has passed the last barrier (and read the epoch long ago)
+  if (relay && tid == 0) {
+    __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
+  }
+}
+constexpr size_t lcbig_smem_bytes() { return (size_t)4 * 64 * 65 * 4 + (size_t)64 * 4 * 16 * 2; }
+
+// The streamed k-steps of lcbig_bwd_kernel<STEPS, SR, .> as MFMA B fragments in the order it consumes them:
+// dst[wg][wave][js][g][lane][8] from WT = ([W_ih | W_hh])^T [H + R][ldwt].  Run after every update of the weights.
+__global__ __launch_bounds__(256) void lcbig_pack_stream_kernel(const bf16_t* __restrict__ WT, int ldwt, int R, int NCB, int STEPS, int SR,
+                                                                bf16_t* __restrict__ dst, size_t n_frag) {
+  const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= n_frag) return;
+  const int NS = STEPS - SR, NP = STEPS / 2, NPR = SR / 2;
+  const int lane = (int)(f & 63), g = (int)((f >> 6) & 3);
+  const size_t r = f >> 8;
+  const int js = (int)(r % NS), wave = (int)((r / NS) & 3), wg = (int)(r / NS / 4);
+  const int cb = wg % NCB, kqi = wg / NCB;
+  int prr = NPR + js / 2 + wg % NP; prr = prr >= NP ? prr - NP : prr;
+  const int k = kqi * R + wave * (STEPS * 32) + (prr * 2 + (js & 1)) * 32 + (lane >> 4) * 8;
+  *reinterpret_cast<bf16x8*>(dst + f * 8) = *reinterpret_cast<const bf16x8*>(WT + (size_t)(cb * 64 + g * 16 + (lane & 15)) * ldwt + k);
+}
+
+// After the chain: what loc_chain_bwd_kernel's caption workgroups accumulate over the F steps.
+//   dHs[t][b][h] = sum_s (beta_s[b][t] / T) dxm_s[b][h]          (attention path into the decoder's hidden states)
+__global__ __launch_bounds__(256) void lcbig_dhs_kernel(const float* __restrict__ beta, const float* __restrict__ dxm, float* __restrict__ dHs,
+                                                        int F, int T, int B, int H) {
+  __shared__ float sb[40 * 32];
+  const int b = blockIdx.x, h = blockIdx.y * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < F * 32; i += 256) { const int s = i >> 5, t = i & 31; sb[i] = t < T ? beta[((size_t)s * B + b) * T + t] : 0.f; }
+  __syncthreads();
+  if (h >= H) return;
+  float acc[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+  for (int s = 0; s < F; ++s) {
+    const float x = dxm[((size_t)s * B + b) * H + h];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc[t] += sb[s * 32 + t] * x;
+  }
+  const float invT = 1.0f / (float)T;
+  for (int t = 0; t < T; ++t) dHs[((size_t)t * B + b) * H + h] = acc[t] * invT;
+}
+//   dUd[t][b][k] = sum_s dbeta_s[b][t] w_k (1 - tanh^2(Whr_s[b][k] + Ud[t][b][k] + b_k)) ;  dw[b][k] = sum_{s,t} dbeta_s[b][t] tanh(.)
+__global__ __launch_bounds__(256) void lcbig_dud_kernel(const float* __restrict__ dbeta, const float* __restrict__ Whr, const float* __restrict__ Ud,
+                                                        const float* __restrict__ ab, const float* __restrict__ w, float* __restrict__ dUd,
+                                                        bf16_t* __restrict__ dUd_lp, int ld_dUd, float* __restrict__ dwacc, int nch,
+                                                        int F, int T, int B, int A) {
+  __shared__ float sdb[40 * 32];
+  __shared__ float sdw[2 * 128];
+  const int b = blockIdx.x, k = threadIdx.x & 127, th = threadIdx.x >> 7;
+  for (int i = threadIdx.x; i < F * 32; i += 256) { const int s = i >> 5, t = i & 31; sdb[i] = t < T ? dbeta[((size_t)s * B + b) * T + t] : 0.f; }
+  __syncthreads();
+  float dwa = 0.f;
+  if (k < A) {
+    const float wk = w[k], abk = ab[k];
+    float ud[16], dud[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int t = th * 16 + i; ud[i] = t < T ? Ud[((size_t)t * B + b) * A + k] : 0.f; dud[i] = 0.f; }
+    for (int s = 0; s < F; ++s) {
+      const float whk = Whr[((size_t)s * B + b) * A + k] + abk;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = th * 16 + i;
+        if (t < T) {
+          const float tz = rn_tanh(whk + ud[i]);
+          const float db = sdb[s * 32 + t];
+          dud[i] += db * wk * (1.f - tz * tz);
+          dwa += db * tz;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = th * 16 + i;
+      if (t < T) { dUd[((size_t)t * B + b) * A + k] = dud[i]; dUd_lp[((size_t)t * B + b) * ld_dUd + k] = (bf16_t)dud[i]; }
+    }
+  }
+  for (int t = th * 16; t < th * 16 + 16 && t < T; ++t)
+    for (int j = A + k; j < ld_dUd; j += 128) dUd_lp[((size_t)t * B + b) * ld_dUd + j] = (bf16_t)0.f;
+  sdw[th * 128 + k] = dwa;
+  __syncthreads();
+  if (th == 0 && k < A) {
+    dwacc[(size_t)b * A + k] = sdw[k] + sdw[128 + k];
+    for (int ch = 1; ch < nch; ++ch) dwacc[((size_t)ch * B + b) * A + k] = 0.f;
+  }
+}

@@ -330,6 +330,9 @@ def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
 HYBRID = {
     "LOC_R2560_B20_hybrid": ([20, 2, 2560, 29, 8, 32, 16, 8], [(3 * i) % 6 for i in range(20)]),
     "LOC_R3584_B64_hybrid_no_relay": ([64, 3, 3584, 29, 8, 32, 16, 12], [(5 * i) % 7 for i in range(64)]),
+    # H % 64 == 0: the backward runs the phased chain of csrc/loc_big.hpp too (P / C / L phases of (H + R) / 64 * 4 workgroups)
+    "LOC_R3584_H64_B64_big_backward": ([64, 3, 3584, 29, 8, 64, 16, 16], [(5 * i) % 7 for i in range(64)]),
+    "LOC_R3072_H128_B37_big_backward_T31": ([37, 2, 3072, 29, 8, 128, 16, 24], [30] + [(3 * i) % 6 for i in range(36)]),
 }
 
 
@@ -359,6 +362,11 @@ def test_hybrid_forward_chain_vs_oracle(case, prec, monkeypatch):
 
     sc, g, n_chain = run()
     assert n_chain == (1 if prec == "bf16" else 0), "the hybrid chain kernel is the bf16 path's forward for this shape"
+    if prec == "bf16" and "big_backward" in case:
+        C, dec, rec = make_models(dims, "local", prec, decP, recP)
+        st0 = R.TrainStep(dec, rec)
+        T0, w0 = st0.prepare(targets.numpy())
+        assert st0.engine.profile_site(8, lambda: st0.fwd_bwd(enc.cuda(), targets.cuda(), T0, w0, seed=6), 1)[0] == 1, "loc_big backward chain not taken"
     st = O.TrainState(decP, recP, "local")
     drop = O.Dropper("hash", seed=6)
     dl, hid, _, ce, _ = O.forward_decoder(st.dec, enc, targets, targets > 0, drop=drop, lambda_reg=0.0, return_parts=True)
@@ -376,6 +384,7 @@ def test_hybrid_forward_chain_vs_oracle(case, prec, monkeypatch):
     assert not bad, bad
     if prec == "bf16":
         monkeypatch.setenv("RN_LOC_HYBRID", "0")
+        monkeypatch.setenv("RN_PERSIST_LOC_BIG", "0")
         sc0, g0, n0 = run()
         assert n0 == 0
         for grp in g:
