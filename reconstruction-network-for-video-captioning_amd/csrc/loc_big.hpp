@@ -60,12 +60,14 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
   const uint32_t key = drop_key(p.dd);
   const float invT = 1.0f / (float)T;
   // every workgroup arrives at every barrier (idle ones at once); the write-through stores of the phase are acknowledged first
-  auto barrier = [&](unsigned phase) {
+  // (split in two so that the loads the NEXT phase can already request are issued between the arrival and the wait: in front
+  // of the arrival they would sit in the same vmcnt as the stores being acknowledged and delay everybody's barrier)
+  auto bar_arrive = [&](unsigned phase) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     lc_arrive(p.bar + wg, fb + phase);
-    lc_wait_or_relay(relay, rel, p.bar, p.NWG, fb + phase, p.bar);
   };
+  auto bar_wait = [&](unsigned phase) { lc_wait_or_relay(relay, rel, p.bar, p.NWG, fb + phase, p.bar); };
 
   // ---------------------------------------------------------------- P: residents
   const int cb = wg % p.NCB, kqi = wg / p.NCB;
@@ -95,6 +97,22 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
     wrt[e] = (isL && a < A) ? p.Wr[(size_t)a * p.ldwr + u0 + (lane & 15)] : (bf16_t)0.f;
   }
   float carry[4] = {0.f, 0.f, 0.f, 0.f};
+  // L's operands that do not depend on the chain (saved activations, cell states, the direct gradient) are requested one
+  // phase ahead — behind the arrival at the barrier that ends the previous step — and the K partials of the step before as
+  // soon as they are complete (behind barrier 2): behind barrier 3 only the dWhr fragments are still to come
+  const size_t lrow_c = lrow < B ? lrow : 0;
+  f32x4 av[4], cc = {0.f, 0.f, 0.f, 0.f}, cp = {0.f, 0.f, 0.f, 0.f}, dhd = {0.f, 0.f, 0.f, 0.f}, pk[4];
+  auto l_prefetch = [&](int s) {
+    const int u = u0 + luq;
+    const float* a = p.acts + ((size_t)s * Bs + lrow_c) * 4 * R + u;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) av[g] = *reinterpret_cast<const f32x4*>(a + (size_t)g * R);
+    if (!p.gru) cc = *reinterpret_cast<const f32x4*>(p.Cr + ((size_t)s * Bs + lrow_c) * R + u);
+    if (s > 0) cp = *reinterpret_cast<const f32x4*>((p.gru ? p.Hr : p.Cr) + ((size_t)(s - 1) * Bs + lrow_c) * R + u);
+    else cp = f32x4{0.f, 0.f, 0.f, 0.f};
+    dhd = *reinterpret_cast<const f32x4*>(p.dHr + ((size_t)s * Bs + lrow_c) * R + u);
+  };
+  if (isL) l_prefetch(F - 1);
 
   for (int q = 0; q < F; ++q) {
     const int s = F - 1 - q;
@@ -118,11 +136,11 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
         const int k = wave * 32;
         if (k < A) {
           const bf16_t* Aw = p.PanW + (size_t)(q - 1) * pan_w + lane_off;
+          bf16x8 fr[RB];
 #pragma unroll
-          for (int i = 0; i < RB; ++i) {
-            const bf16x8 fr = *reinterpret_cast<const bf16x8*>(Aw + ((k >> 3) * RC_PAN_ROWS + i * 16) * 8);
-            a1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, wrt, a1[i], 0, 0, 0);
-          }
+          for (int i = 0; i < RB; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(Aw + ((k >> 3) * RC_PAN_ROWS + i * 16) * 8);
+#pragma unroll
+          for (int i = 0; i < RB; ++i) a1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i], wrt, a1[i], 0, 0, 0);
         }
         float* prt = red + wave * (ROWS * RED_LD);
 #pragma unroll
@@ -130,20 +148,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + (lane & 15)] = a1[i][r];
       }
-      // saved activations, states, the direct gradient and the K partials of the step before: all in flight together
-      const size_t row = lrow < B ? lrow : 0;
-      const int u = u0 + luq;
-      f32x4 av[4], cc = {0.f, 0.f, 0.f, 0.f}, cp = {0.f, 0.f, 0.f, 0.f}, dh, pk[4];
-      const float* a = p.acts + ((size_t)s * Bs + row) * 4 * R + u;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) av[g] = *reinterpret_cast<const f32x4*>(a + (size_t)g * R);
-      if (!p.gru) cc = *reinterpret_cast<const f32x4*>(p.Cr + ((size_t)s * Bs + row) * R + u);
-      if (s > 0) cp = *reinterpret_cast<const f32x4*>((p.gru ? p.Hr : p.Cr) + ((size_t)(s - 1) * Bs + row) * R + u);
-      dh = *reinterpret_cast<const f32x4*>(p.dHr + ((size_t)s * Bs + row) * R + u);
-      if (q > 0) {
-#pragma unroll
-        for (int z = 0; z < 4; ++z) pk[z] = *reinterpret_cast<const f32x4*>(p.Part + (((size_t)(q - 1) * 4 + z) * ROWS + lrow) * NT + H + u);
-      }
+      f32x4 dh = dhd;
       __syncthreads();
       if (q > 0) {
 #pragma unroll
@@ -178,12 +183,13 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
       if (wg == 0 && p.ld_dg > K)
         for (int jj = tid; jj < B * (p.ld_dg - K); jj += 256) Gt[(size_t)(jj / (p.ld_dg - K)) * p.ld_dg + K + jj % (p.ld_dg - K)] = (bf16_t)0.f;
     }
+    bar_arrive(3u * (unsigned)q + 1u);
     if constexpr (NPS > 0) {
 #pragma unroll
       for (int i = 0; i < PF; ++i)
         if (i < NPS) issue_w(i % PF, i);
     }
-    barrier(3u * (unsigned)q + 1u);
+    bar_wait(3u * (unsigned)q + 1u);
 
     // ============================================================ P(q): partial [dx | dhr] of this tile
     {
@@ -246,7 +252,8 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
         __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + c2), pk2.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // phase C's saved operands do not depend on the chain: requested before the barrier
+    bar_arrive(3u * (unsigned)q + 2u);
+    // phase C's saved operands do not depend on the chain: requested while the barrier completes
     const int tt = tid & 31, h8 = tid >> 5;                   // (decoder step, eighth of the hidden columns)
     const int ck = tid & 127, cth = tid >> 7;                 // (attention column, half of the decoder steps)
     float hv[64], udv[16], whk = 0.f, wk = 0.f;
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
       }
       if (ck < A) { whk = p.Whr[((size_t)s * Bs + wg) * A + ck] + p.ab[ck]; wk = p.w[ck]; }
     }
-    barrier(3u * (unsigned)q + 2u);
+    bar_wait(3u * (unsigned)q + 2u);
 
     // ============================================================ C(q): attention backward of step s for caption wg
     if (isC) {
@@ -333,7 +340,13 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
       if (tid < (p.ld_dwhr >> 3) && tid < 16)
         *reinterpret_cast<bf16x8*>(p.dWhrs + ((size_t)s * Bs + b) * p.ld_dwhr + tid * 8) = *reinterpret_cast<const bf16x8*>(swl + tid * 8);
     }
-    barrier(3u * (unsigned)q + 3u);
+    bar_arrive(3u * (unsigned)q + 3u);
+    if (isL && q + 1 < F) {
+      l_prefetch(s - 1);
+#pragma unroll
+      for (int z = 0; z < 4; ++z) pk[z] = *reinterpret_cast<const f32x4*>(p.Part + (((size_t)q * 4 + z) * ROWS + lrow) * NT + H + u0 + luq);
+    }
+    bar_wait(3u * (unsigned)q + 3u);
   }
   // everybody has passed the last barrier (and read the epoch long ago)
   if (relay && tid == 0) {
