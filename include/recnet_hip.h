@@ -264,8 +264,10 @@ int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* s
  * call recnet_flush themselves. */
 int recnet_set_deferred_reconstructor_update(recnet_handle* h, int32_t on, void* stream);
 int recnet_flush(recnet_handle* h, void* stream);
-/* A hipGraph that captured a deferred fused step was replayed (replays run no host code): tells the handle that an update
- * may be pending, so that its other entry points flush before they touch the reconstructor. */
+/* A hipGraph that captured a fused step was replayed (replays run no host code): tells the handle that the reconstructor's
+ * derived weight images are stale again (the fused step refreshes them lazily, at the start of its next run) and — with the
+ * deferred update on — that an update may be pending, so that its other entry points catch up before they touch the
+ * reconstructor. */
 int recnet_mark_pending(recnet_handle* h);
 
 /* ---- plumbing exposed for tests and profiling */

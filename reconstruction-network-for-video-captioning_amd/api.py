@@ -577,8 +577,7 @@ class GraphedStep:
     def __call__(self):
         if not self.split:
             self.graphs[0].replay()
-            if self.deferred:
-                self.eng.mark_pending()
+            self.eng.mark_pending()          # (a replay runs no host code: the handle's lazily refreshed weight images / a deferred update)
         else:
             ga, gb, gc = self.graphs
             ga.replay()

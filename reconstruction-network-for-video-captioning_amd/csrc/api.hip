@@ -106,6 +106,9 @@ struct recnet_handle {
   int bgrp = 0;                  // rows per launch of the persistent chain kernels: B for B <= RC_PAN_ROWS, else B split evenly into ceil(B / 112) row groups
   // deferred reconstructor update (recnet_set_deferred_reconstructor_update): ctrl[2] on the device says whether an update is
   // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
+  // lazy refresh of the reconstructor's derived weight images (transposes, streamed fragments): the fused step leaves them stale
+  // at its end and refreshes them in its next run's hoisted side work, under the decoder forward chain (host_common.inc)
+  int lazy_images = 1, in_fused = 0, rec_images_stale = 0;
   int defer_rec = 0, defer_now = 0, defer_err = 0, maybe_pending = 0, def_rows = 0, defer_flags = 3; hipStream_t s3 = nullptr; float* gws3 = nullptr;
   int mp_done = 0;          // h->mp holds the mean-pooled decoder states of the last decoder forward (dec_chain_kernel)
   int ncu = 0;
@@ -319,6 +322,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->RA = c.reconstructor_type == RECNET_REC_LOCAL ? c.reconstructor_attn_size : 0;
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
+  h->lazy_images = getenv("RN_LAZY_IMAGES") ? atoi(getenv("RN_LAZY_IMAGES")) : 1;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
   // equal size (at most RN_MAX_ROW_GROUPS of them) and every chain runs once per group, one launch after the other: a group is
@@ -600,7 +604,10 @@ extern "C" {
 
 // A pending deferred reconstructor update (recnet_set_deferred_reconstructor_update) is completed before anything else
 // reads the reconstructor's parameters, packed images, gradients or Adam state.
-static int flush_pending(recnet_handle* h, hipStream_t st, int explicit_call = 0) {
+static void refresh_rec_images(recnet_handle* h, hipStream_t st);
+static int flush_pending(recnet_handle* h, hipStream_t st, int explicit_call = 0, int images = 1) {
+  // (images = 0: the fused step refreshes them itself, in its hoisted side work)
+  if (images && h->rec_images_stale && h->rec_bound) { refresh_rec_images(h, st); h->rec_images_stale = 0; }
   // maybe_pending is the host's shadow of the device's pending word: set when a deferred step is enqueued or captured, and
   // by recnet_mark_pending when a captured one is replayed.  An explicit recnet_flush also runs while the mode is on (the
   // device word decides whether the Adam step happens; the products are recomputed from the step's own operands either way).
