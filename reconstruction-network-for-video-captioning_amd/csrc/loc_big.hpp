@@ -25,6 +25,7 @@
 
 // resident k-steps per wave for STEPS k-steps in all (as many as compile without scratch next to the streaming ring)
 #define LB_SR(STEPS) ((STEPS) == 32 ? 12 : 14)
+#define LB_NL 4                // further k-steps per wave resident in LDS (64 KB per workgroup)
 
 struct LocBigBwdArgs {
   int F, T, B, Bs, R, H, A, gru;
@@ -43,13 +44,18 @@ struct LocBigBwdArgs {
   DropDesc dd;
 };
 
-template <int STEPS, int SR, int PF>
+// NL further k-steps per wave are resident in LDS (loaded once; the CU's 160 KB hold the reduction buffer, these and the dG
+// staging): of the STEPS k-steps per wave SR + NL never move again, STEPS - SR - NL are streamed every step.
+template <int STEPS, int SR, int PF, int NL>
 __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
   constexpr int RB = 4, CG = 4, ROWS = 64, RED_LD = 65, NP = STEPS / 2, NPR = SR / 2, NPS = NP - NPR, UW = 16;
+  constexpr int NPL = NL / 2, NPG = NPS - NPL;             // streamed-image pairs: the first NPG through the register ring every step, the last NPL resident in LDS
+  static_assert(NL % 2 == 0 && NPG >= 0, "LDS-resident k-steps: whole pairs, no more than the image holds");
   static_assert(SR % 2 == 0 && SR <= STEPS && SR >= 2 * PF, "resident k-steps: whole pairs, at least the prefetch distance");
   extern __shared__ __attribute__((aligned(16))) float lb_smem[];
   float* red = lb_smem;                                                      // [4 waves][ROWS][RED_LD]; phase C aliases it
-  bf16_t* hl = reinterpret_cast<bf16_t*>(lb_smem + 4 * ROWS * RED_LD);       // [ROWS][4 gates][UW]: dG_s of this workgroup's units
+  char* wl = reinterpret_cast<char*>(lb_smem + 4 * ROWS * RED_LD);           // LDS-resident fragments [4 waves][NL][CG][64 lanes][16 bytes]
+  bf16_t* hl = reinterpret_cast<bf16_t*>(wl + (size_t)4 * NL * CG * 1024);   // [ROWS][4 gates][UW]: dG_s of this workgroup's units
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x, R = p.R, B = p.B, Bs = p.Bs, H = p.H, A = p.A, F = p.F, T = p.T, K = 4 * R, NT = H + R;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
@@ -85,6 +91,15 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
   }
   const bf16_t* wst = p.WstT + ((size_t)(wg * 4 + wave) * (STEPS - SR) * CG * 64 + lane) * 8;
   const int lane_off = ((lane >> 4) * RC_PAN_ROWS + (lane & 15)) * 8;          // k-group (lane / 16), row lane % 16
+  if constexpr (NL > 0) {     // each wave copies (DMA) and later reads only its own fragments
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+#pragma unroll
+      for (int g = 0; g < CG; ++g)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wst + (size_t)(((2 * NPG + j) * CG + g) * 512)),
+                                         (__attribute__((address_space(3))) void*)(wl + (size_t)((wave * NL + j) * CG + g) * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 
   // ---------------------------------------------------------------- L: residents (workgroups j < R / 16)
   const bool isL = wg < R / UW, isC = wg < B;
@@ -184,10 +199,10 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
         for (int jj = tid; jj < B * (p.ld_dg - K); jj += 256) Gt[(size_t)(jj / (p.ld_dg - K)) * p.ld_dg + K + jj % (p.ld_dg - K)] = (bf16_t)0.f;
     }
     bar_arrive(3u * (unsigned)q + 1u);
-    if constexpr (NPS > 0) {
+    if constexpr (NPG > 0) {
 #pragma unroll
       for (int i = 0; i < PF; ++i)
-        if (i < NPS) issue_w(i % PF, i);
+        if (i < NPG) issue_w(i % PF, i);
     }
     bar_wait(3u * (unsigned)q + 1u);
 
@@ -221,13 +236,16 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
           for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int g = 0; g < CG; ++g) {
-              const bf16x8 w = it < NPS ? fw[slot][hh][g] : wb[(it < NPS ? 0 : pr * 2 + hh)][g];
+              bf16x8 w;
+              if (it < NPG) w = fw[slot][hh][g];
+              else if (it < NPS) w = *reinterpret_cast<const bf16x8*>(wl + ((size_t)((wave * NL + (it - NPG) * 2 + hh) * CG + g) * 64 + lane) * 16);
+              else w = wb[(it < NPS ? 0 : pr * 2 + hh)][g];
               acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[slot][hh][i], w, acc[i][g], 0, 0, 0);
             }
         if (it + PF < NP) {
           __builtin_amdgcn_sched_barrier(0);
           issue_pair(slot, pair_of(it + PF));
-          if (it + PF < NPS) issue_w(slot, it + PF);
+          if (it + PF < NPG) issue_w(slot, it + PF);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
     if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
   }
 }
-constexpr size_t lcbig_smem_bytes() { return (size_t)4 * 64 * 65 * 4 + (size_t)64 * 4 * 16 * 2; }
+template <int NL> constexpr size_t lcbig_smem_bytes() { return (size_t)4 * 64 * 65 * 4 + (size_t)4 * NL * 4 * 1024 + (size_t)64 * 4 * 16 * 2; }
 
 // The streamed k-steps of lcbig_bwd_kernel<STEPS, SR, .> as MFMA B fragments in the order it consumes them:
 // dst[wg][wave][js][g][lane][8] from WT = ([W_ih | W_hh])^T [H + R][ldwt].  Run after every update of the weights.
@@ -376,63 +394,67 @@ __global__ __launch_bounds__(256) void lcbig_pack_stream_kernel(const bf16_t* __
 //   dHs[t][b][h] = sum_s (beta_s[b][t] / T) dxm_s[b][h]          (attention path into the decoder's hidden states)
 __global__ __launch_bounds__(256) void lcbig_dhs_kernel(const float* __restrict__ beta, const float* __restrict__ dxm, float* __restrict__ dHs,
                                                         int F, int T, int B, int H) {
-  __shared__ float sb[40 * 32];
-  const int b = blockIdx.x, h = blockIdx.y * 256 + threadIdx.x;
-  for (int i = threadIdx.x; i < F * 32; i += 256) { const int s = i >> 5, t = i & 31; sb[i] = t < T ? beta[((size_t)s * B + b) * T + t] : 0.f; }
+  // grid (B, H / 256, 2): blockIdx.z = half of the decoder steps (16 accumulators per thread)
+  __shared__ float sb[40 * 16];
+  const int b = blockIdx.x, h = blockIdx.y * 256 + threadIdx.x, t0 = blockIdx.z * 16;
+  for (int i = threadIdx.x; i < F * 16; i += 256) { const int s = i >> 4, t = t0 + (i & 15); sb[i] = t < T ? beta[((size_t)s * B + b) * T + t] : 0.f; }
   __syncthreads();
   if (h >= H) return;
-  float acc[32];
+  float acc[16];
 #pragma unroll
-  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
   for (int s = 0; s < F; ++s) {
     const float x = dxm[((size_t)s * B + b) * H + h];
 #pragma unroll
-    for (int t = 0; t < 32; ++t) acc[t] += sb[s * 32 + t] * x;
+    for (int t = 0; t < 16; ++t) acc[t] += sb[s * 16 + t] * x;
   }
   const float invT = 1.0f / (float)T;
-  for (int t = 0; t < T; ++t) dHs[((size_t)t * B + b) * H + h] = acc[t] * invT;
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (t0 + t < T) dHs[((size_t)(t0 + t) * B + b) * H + h] = acc[t] * invT;
 }
 //   dUd[t][b][k] = sum_s dbeta_s[b][t] w_k (1 - tanh^2(Whr_s[b][k] + Ud[t][b][k] + b_k)) ;  dw[b][k] = sum_{s,t} dbeta_s[b][t] tanh(.)
+// grid (B, 4): blockIdx.y = a quarter of the decoder steps; its part of dw goes to chunk blockIdx.y of dwacc (nch = 4 chunks, summed
+// by the column sum that follows, like the per-step path's RN_TCH chunks)
 __global__ __launch_bounds__(256) void lcbig_dud_kernel(const float* __restrict__ dbeta, const float* __restrict__ Whr, const float* __restrict__ Ud,
                                                         const float* __restrict__ ab, const float* __restrict__ w, float* __restrict__ dUd,
                                                         bf16_t* __restrict__ dUd_lp, int ld_dUd, float* __restrict__ dwacc, int nch,
                                                         int F, int T, int B, int A) {
-  __shared__ float sdb[40 * 32];
+  __shared__ float sdb[40 * 8];
   __shared__ float sdw[2 * 128];
-  const int b = blockIdx.x, k = threadIdx.x & 127, th = threadIdx.x >> 7;
-  for (int i = threadIdx.x; i < F * 32; i += 256) { const int s = i >> 5, t = i & 31; sdb[i] = t < T ? dbeta[((size_t)s * B + b) * T + t] : 0.f; }
+  const int b = blockIdx.x, k = threadIdx.x & 127, th = threadIdx.x >> 7, t0 = blockIdx.y * 8;
+  for (int i = threadIdx.x; i < F * 8; i += 256) { const int s = i >> 3, t = t0 + (i & 7); sdb[i] = t < T ? dbeta[((size_t)s * B + b) * T + t] : 0.f; }
   __syncthreads();
   float dwa = 0.f;
   if (k < A) {
     const float wk = w[k], abk = ab[k];
-    float ud[16], dud[16];
+    float ud[4], dud[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int t = th * 16 + i; ud[i] = t < T ? Ud[((size_t)t * B + b) * A + k] : 0.f; dud[i] = 0.f; }
+    for (int i = 0; i < 4; ++i) { const int t = t0 + th * 4 + i; ud[i] = t < T ? Ud[((size_t)t * B + b) * A + k] : 0.f; dud[i] = 0.f; }
     for (int s = 0; s < F; ++s) {
       const float whk = Whr[((size_t)s * B + b) * A + k] + abk;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int t = th * 16 + i;
+      for (int i = 0; i < 4; ++i) {
+        const int t = t0 + th * 4 + i;
         if (t < T) {
           const float tz = rn_tanh(whk + ud[i]);
-          const float db = sdb[s * 32 + t];
+          const float db = sdb[s * 8 + th * 4 + i];
           dud[i] += db * wk * (1.f - tz * tz);
           dwa += db * tz;
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = th * 16 + i;
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + th * 4 + i;
       if (t < T) { dUd[((size_t)t * B + b) * A + k] = dud[i]; dUd_lp[((size_t)t * B + b) * ld_dUd + k] = (bf16_t)dud[i]; }
     }
   }
-  for (int t = th * 16; t < th * 16 + 16 && t < T; ++t)
-    for (int j = A + k; j < ld_dUd; j += 128) dUd_lp[((size_t)t * B + b) * ld_dUd + j] = (bf16_t)0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int t = t0 + th * 4 + i;
+    if (t < T) for (int j = A + k; j < ld_dUd; j += 128) dUd_lp[((size_t)t * B + b) * ld_dUd + j] = (bf16_t)0.f;
+  }
   sdw[th * 128 + k] = dwa;
   __syncthreads();
-  if (th == 0 && k < A) {
-    dwacc[(size_t)b * A + k] = sdw[k] + sdw[128 + k];
-    for (int ch = 1; ch < nch; ++ch) dwacc[((size_t)ch * B + b) * A + k] = 0.f;
-  }
+  if (th == 0 && k < A && (int)blockIdx.y < nch) dwacc[((size_t)blockIdx.y * B + b) * A + k] = sdw[k] + sdw[128 + k];
 }
