@@ -108,7 +108,7 @@ struct recnet_handle {
   // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
   // lazy refresh of the reconstructor's derived weight images (transposes, streamed fragments): the fused step leaves them stale
   // at its end and refreshes them in its next run's hoisted side work, under the decoder forward chain (host_common.inc)
-  int lazy_images = 1, in_fused = 0, rec_images_stale = 0;
+  int lazy_images = 1, in_fused = 0, rec_images_stale = 0, side_fork_recorded = 0;
   int defer_rec = 0, defer_now = 0, defer_err = 0, maybe_pending = 0, def_rows = 0, defer_flags = 3; hipStream_t s3 = nullptr; float* gws3 = nullptr;
   int mp_done = 0;          // h->mp holds the mean-pooled decoder states of the last decoder forward (dec_chain_kernel)
   int ncu = 0;
