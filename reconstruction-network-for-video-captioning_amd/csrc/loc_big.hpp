@@ -15,7 +15,8 @@
 //   L  (workgroup j < R / 16): 16 hidden units x all rows.  dhr_{s} from the direct gradient, the 4 K partials of the step
 //      before and dWhr . W_r (K = A <= 128, MFMA); cell backward with the dc carry in registers; publishes dG_s.
 // The three stages of a step are strictly sequential, so they are PHASES of the same NWG = (H + R) / 64 * 4 workgroups (256 at
-// R = 3584, H = 512: every CU) between three grid barriers per step; the last workgroup relays the barriers (lc_wait_or_relay).
+// R = 3584, H = 512: every CU) between two grid barriers (L -> P, C -> L; the last workgroup relays them, lc_wait_or_relay) and
+// one partial hand-over (P's dx tiles -> C) per step.
 // Limits (host-checked): bf16 path, B <= 64, R % 128 == 0 with R / 128 in {24, 28, 32} (even), H % 64 == 0, H <= 512, A <= 128,
 // T <= 32, F <= 40, NWG <= CU count.
 #pragma once
@@ -42,7 +43,14 @@ struct LocBigBwdArgs {
   bf16_t* PanG; bf16_t* PanW; float* Part;   // exchange, by chain step q: [F][rc_pan_elems(4R)], [F][rc_pan_elems(A)], [F][4][64][H + R]
   unsigned* bar; unsigned* epoch; float* poison;
   DropDesc dd;
+  unsigned long long* ts;             // probe builds only (LC_PROBE): roles 3 (workgroup 0: L + P + C) and 4 (a P-only workgroup)
 };
+#ifdef LC_PROBE
+#define LB_WTS(q, i) do { if ((q) == 10 && tid == 0) p.ts[5120 + (i) * 256 + wg] = wall_clock64(); } while (0)
+#else
+#define LB_WTS(q, i) do { } while (0)
+#endif
+#define LB_TS(q, i) do { if (wg == 0) LC_TS(3, q, i); else if (wg == p.NWG - 2) LC_TS(4, q, i); } while (0)
 
 // NL further k-steps per wave are resident in LDS (loaded once; the CU's 160 KB hold the reduction buffer, these and the dG
 // staging): of the STEPS k-steps per wave SR + NL never move again, STEPS - SR - NL are streamed every step.
@@ -68,15 +76,30 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
   // every workgroup arrives at every barrier (idle ones at once); the write-through stores of the phase are acknowledged first
   // (split in two so that the loads the NEXT phase can already request are issued between the arrival and the wait: in front
   // of the arrival they would sit in the same vmcnt as the stores being acknowledged and delay everybody's barrier)
+  // Arrival flags: the 4 NXB workgroups whose tiles are columns of dx come first — the caption phase needs only those, so the
+  // hand-over P -> C is a PARTIAL barrier (the caption workgroups poll these flags themselves) and the product's stragglers
+  // among the other 4 (NCB - NXB) workgroups finish under the caption phase; barriers 1 and 3 of a step are full and relayed.
+  const int cb = wg % p.NCB, kqi = wg / p.NCB, NXB = H >> 6;
+  unsigned* myflag = p.bar + (cb < NXB ? kqi * NXB + cb : 4 * NXB + kqi * (p.NCB - NXB) + (cb - NXB));
   auto bar_arrive = [&](unsigned phase) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    lc_arrive(p.bar + wg, fb + phase);
+    lc_arrive(myflag, fb + phase);
   };
   auto bar_wait = [&](unsigned phase) { lc_wait_or_relay(relay, rel, p.bar, p.NWG, fb + phase, p.bar); };
+  // wave-level wait for n <= 64 consecutive arrival flags (lane i polls flag i)
+  auto flags_wait = [&](const unsigned* f, int n, unsigned target) {
+    const unsigned* fl = f + (lane < n ? lane : 0);
+    unsigned spin = 0;
+    for (;;) {
+      const bool ok = (int)(__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+      if (__all(ok)) break;
+      if (rc_give_up(p.bar, spin)) break;
+    }
+    if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  };
 
   // ---------------------------------------------------------------- P: residents
-  const int cb = wg % p.NCB, kqi = wg / p.NCB;
   const int kw0 = kqi * R + wave * (STEPS * 32);            // this wave's K range inside the quarter (K quarter = R gate rows)
   const int rot = wg % NP;
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
@@ -131,6 +154,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
 
   for (int q = 0; q < F; ++q) {
     const int s = F - 1 - q;
+    LB_TS(q, 0);
     // ============================================================ L(q): dhr_s, cell backward, dG_s
     // streamed weight fragments of P(q): their addresses do not depend on the chain — the first ring slots are requested now
     bf16x8 fw[PF][2][CG];
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
       if (wg == 0 && p.ld_dg > K)
         for (int jj = tid; jj < B * (p.ld_dg - K); jj += 256) Gt[(size_t)(jj / (p.ld_dg - K)) * p.ld_dg + K + jj % (p.ld_dg - K)] = (bf16_t)0.f;
     }
+    LB_TS(q, 1);
     bar_arrive(3u * (unsigned)q + 1u);
     if constexpr (NPG > 0) {
 #pragma unroll
@@ -205,6 +230,8 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
         if (i < NPG) issue_w(i % PF, i);
     }
     bar_wait(3u * (unsigned)q + 1u);
+    LB_TS(q, 2);
+    LB_WTS(q, 0);
 
     // ============================================================ P(q): partial [dx | dhr] of this tile
     {
@@ -249,6 +276,8 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      LB_TS(q, 3);
+      LB_WTS(q, 1);
       float* prt = red + wave * (ROWS * RED_LD);
 #pragma unroll
       for (int i = 0; i < RB; ++i)
@@ -257,20 +286,23 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + g * 16 + (lane & 15)] = acc[i][g][r];
       __syncthreads();
-      // thread = (row tid / 4, 16 columns): the four waves' K parts summed, written through
-      const int prow = tid >> 2, pc0 = (tid & 3) * 16;
+      // thread = (row 16 rr + tid / 16, 4 columns): the four waves' K parts summed; a wave's store covers 4 rows x 256
+      // contiguous bytes, written through (as 8-byte stores 64 bytes apart the 16 KB took 6 us to be acknowledged)
+      const int prow = tid >> 4, pc0 = (tid & 15) * 4;
       float* dst = p.Part + (((size_t)q * 4 + kqi) * ROWS + prow) * NT + cb * 64 + pc0;
 #pragma unroll
-      for (int c2 = 0; c2 < 16; c2 += 2) {
-        float v0 = 0.f, v1 = 0.f;
+      for (int rr = 0; rr < 4; ++rr) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { v0 += red[w * (ROWS * RED_LD) + prow * RED_LD + pc0 + c2]; v1 += red[w * (ROWS * RED_LD) + prow * RED_LD + pc0 + c2 + 1]; }
-        union { float f[2]; uint64_t u; } pk2;
-        pk2.f[0] = v0; pk2.f[1] = v1;
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(dst + c2), pk2.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += red[w * (ROWS * RED_LD) + (rr * 16 + prow) * RED_LD + pc0 + e];
+        lc_store16f(dst + (size_t)rr * 16 * NT, v);
       }
     }
+    LB_TS(q, 4);
     bar_arrive(3u * (unsigned)q + 2u);
+    LB_WTS(q, 2);
     // phase C's saved operands do not depend on the chain: requested while the barrier completes
     const int tt = tid & 31, h8 = tid >> 5;                   // (decoder step, eighth of the hidden columns)
     const int ck = tid & 127, cth = tid >> 7;                 // (attention column, half of the decoder steps)
@@ -293,7 +325,11 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
       }
       if (ck < A) { whk = p.Whr[((size_t)s * Bs + wg) * A + ck] + p.ab[ck]; wk = p.w[ck]; }
     }
-    bar_wait(3u * (unsigned)q + 2u);
+    if (isC) {
+      if (tid < 64) flags_wait(p.bar, 4 * NXB, fb + 3u * (unsigned)q + 2u);
+      __syncthreads();
+    }
+    LB_TS(q, 5);
 
     // ============================================================ C(q): attention backward of step s for caption wg
     if (isC) {
@@ -358,13 +394,26 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
       if (tid < (p.ld_dwhr >> 3) && tid < 16)
         *reinterpret_cast<bf16x8*>(p.dWhrs + ((size_t)s * Bs + b) * p.ld_dwhr + tid * 8) = *reinterpret_cast<const bf16x8*>(swl + tid * 8);
     }
+    LB_TS(q, 6);
     bar_arrive(3u * (unsigned)q + 3u);
     if (isL && q + 1 < F) {
       l_prefetch(s - 1);
+      // the K partials of this workgroup's columns of dhr: their four producers finished P(q) a caption phase ago
+      {
+        const unsigned* f = p.bar + 4 * NXB + ((H + u0) >> 6) - NXB + (lane & 3) * (p.NCB - NXB);
+        unsigned spin = 0;
+        for (;;) {
+          const bool ok = (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (fb + 3u * (unsigned)q + 2u)) >= 0;
+          if (__all(ok)) break;
+          if (rc_give_up(p.bar, spin)) break;
+        }
+        if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
 #pragma unroll
       for (int z = 0; z < 4; ++z) pk[z] = *reinterpret_cast<const f32x4*>(p.Part + (((size_t)q * 4 + z) * ROWS + lrow) * NT + H + u0 + luq);
     }
     bar_wait(3u * (unsigned)q + 3u);
+    LB_TS(q, 7);
   }
   // everybody has passed the last barrier (and read the epoch long ago)
   if (relay && tid == 0) {

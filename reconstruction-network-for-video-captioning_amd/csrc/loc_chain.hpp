@@ -102,11 +102,16 @@ __device__ __forceinline__ void lc_wait_or_relay(bool me, unsigned* rel, const u
 __device__ __forceinline__ void lc_arrive(unsigned* flag, unsigned v) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void lc_store16(bf16_t* dst, const bf16_t* src) {     // 16 bytes, written through
-  const uint64_t* s = reinterpret_cast<const uint64_t*>(src);
-  uint64_t* d = reinterpret_cast<uint64_t*>(dst);
-  __hip_atomic_store(d, s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(d + 1, s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// 16 bytes per lane, written through to the agent's coherence point: the instruction an agent-scope relaxed atomic store compiles
+// to (global_store_dwordx2 ... sc1), in its 16-byte form — one request per lane instead of two
+// (the s_nop is the wait state a VMEM store of more than 8 bytes needs before a VALU instruction may overwrite its data registers:
+// the compiler's hazard recognizer inserts it behind its own stores and does not look inside inline asm — without it the next
+// loop iteration's adds corrupted the stored values)
+__device__ __forceinline__ void lc_store16f(float* dst, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lc_store16(bf16_t* dst, const bf16_t* src) {
+  lc_store16f(reinterpret_cast<float*>(dst), *reinterpret_cast<const f32x4*>(src));
 }
 typedef short lc_s4 __attribute__((ext_vector_type(4)));
 typedef _Float16 lc_h4 __attribute__((ext_vector_type(4)));

@@ -23,7 +23,8 @@ from recnet_amd.synthetic import synthetic_features, synthetic_targets
 from tests import golden_util as GU
 from tests.gpu_util import make_models
 kind, out = sys.argv[1], sys.argv[2]
-B, F, D, V, E, H, A, RA = 100, 28, 1536, 4188, 468, 512, 128, 128
+B, F, D = (int(x) for x in sys.argv[3:6])
+V, E, H, A, RA = 4188, 468, 512, 128, 128
 decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 21)
 recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 22)
 _, dec, rec = make_models([B, F, D, V, E, H, A, RA], kind, "bf16", decP, recP)
@@ -42,23 +43,26 @@ np.savez(out, **res)
 ''' % ROOT
 
 
-def _run(kind, variant, path):
+def _run(kind, variant, path, shape=(100, 28, 1536)):
     env = dict(os.environ)
     env.pop("RN_LIB_PROBE", None)
     if variant:
         env["RN_LIB_VARIANT"] = variant
     else:
         env.pop("RN_LIB_VARIANT", None)
-    subprocess.check_call([sys.executable, "-c", CHILD, kind, path], env=env, cwd=ROOT)
+    subprocess.check_call([sys.executable, "-c", CHILD, kind, path] + [str(x) for x in shape], env=env, cwd=ROOT)
     return np.load(path)
 
 
-@pytest.mark.parametrize("kind", ["global", "local"])
-def test_no_invalidate_build_equals_acquire_fence_build(kind, tmp_path):
+# BASELINE configs[1] / [2] at B = 100, the per-rank shards of configs[3] (40 frames: the decoder chains' LDS frames) and of
+# configs[4] (R = 3584: hybrid forward chain, phased backward chain of loc_big.hpp)
+@pytest.mark.parametrize("kind,shape", [("global", (100, 28, 1536)), ("local", (100, 28, 1536)), ("local", (32, 40, 2048)),
+                                        ("local", (64, 28, 3584))])
+def test_no_invalidate_build_equals_acquire_fence_build(kind, shape, tmp_path):
     lib = os.path.join(ROOT, "reconstruction-network-for-video-captioning_amd", "csrc", "librecnet_hip_acqinv.so")
     assert os.path.exists(lib), "build it with `make -C .../csrc acqinv` (__graft_entry__.build() does)"
-    a = _run(kind, None, str(tmp_path / "a.npz"))
-    b = _run(kind, "acqinv", str(tmp_path / "b.npz"))
+    a = _run(kind, None, str(tmp_path / "a.npz"), shape)
+    b = _run(kind, "acqinv", str(tmp_path / "b.npz"), shape)
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:
         x, y = a[k], b[k]

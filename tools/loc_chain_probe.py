@@ -63,6 +63,22 @@ names = {0: ("fwd U", ["x arrived", "x GEMM + red", "cell", "stores issued", "ac
          4: ("bwd U'", ["dG released", "big GEMM", "dWhr released", "small GEMM + cell", "ack + arrive"]),
          5: ("bwd X'", ["dG released", "GEMM + red", "ack + arrive"]),
          6: ("bwd C'", ["dx released", "attention bwd", "ack + arrive"])}
+if D > 2048:
+    # the phased backward chain of loc_big.hpp: role 3 = workgroup 0 (L + P + C phases), role 4 = a P-only workgroup
+    pts = ["step start", "L done", "barrier 1 passed", "P products done", "P partial stored", "barrier 2 passed", "C done", "barrier 3 passed"]
+    for role, nm in ((3, "big bwd, workgroup 0 (L, P, C)"), (4, "big bwd, a P-only workgroup")):
+        t = ts[role, 2:F - 2, :8]
+        print("%-32s period %.2f us" % (nm, np.median(np.diff(ts[role, 2:F - 2, 0]))))
+        for i in range(1, 8):
+            print("    %-22s +%.2f" % (pts[i], np.median(t[:, i] - t[:, i - 1])))
+    w = raw[5120:5120 + 768].reshape(3, 256)
+    t0 = w[0].min()
+    print("per workgroup at step 10 (us after the first release): released / products done / partial acknowledged")
+    for k in range(4):
+        print("  K quarter %d" % k)
+        for c0 in range(0, 64, 8):
+            print("    cb %2d..%2d  " % (c0, c0 + 7) + "  ".join("%4.1f/%4.1f/%4.1f" % tuple(w[i, k * 64 + c] - t0 for i in range(3)) for c in range(c0, c0 + 8)))
+    del names[3], names[4], names[5], names[6]
 for role, (nm, pts) in names.items():
     t = ts[role, 2:F - 2, :len(pts)]
     period = np.median(np.diff(ts[role, 2:F - 2, 0]))
@@ -70,6 +86,8 @@ for role, (nm, pts) in names.items():
     for i in range(1, len(pts)):
         print("    %-22s +%.2f" % (pts[i], np.median(t[:, i] - t[:, i - 1])))
     print("    %-22s +%.2f (to the next step's first stamp)" % ("...", np.median(ts[role, 3:F - 1, 0] - t[:, len(pts) - 1])))
+if D > 2048:
+    sys.exit(0)
 t4 = ts[4, 3:F - 2]
 print("bwd U': dWhr released -> partial sums in LDS %.2f, -> cells done %.2f" % (np.median(t4[:, 5] - t4[:, 2]), np.median(t4[:, 3] - t4[:, 5])))
 # cross-role offsets inside a step (forward): relay 'C all arrived' -> U 'x arrived', U 'ack + arrive' -> relay 'U all arrived'
