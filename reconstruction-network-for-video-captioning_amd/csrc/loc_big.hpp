@@ -24,9 +24,16 @@
 #include "rec_chain.hpp"
 #include "loc_chain.hpp"
 
-// resident k-steps per wave for STEPS k-steps in all (as many as compile without scratch next to the streaming ring)
-#define LB_SR(STEPS) ((STEPS) == 32 ? 12 : 14)
-#define LB_NL 4                // further k-steps per wave resident in LDS (64 KB per workgroup)
+// resident k-steps per wave for STEPS k-steps in all.  Measured at R = 3584 (C5, ms per train step): 14 resident 3.49, 12: 3.42,
+// 10: 3.365, 8: 3.39-3.48, 6: 3.47 — the compiler allocates MFMA operands to the VGPR half of the register file only, above 10
+// k-steps (160 registers beside the 128 of the two rings) it spills, and every reload from scratch is a wait for ALL loads in
+// flight: an honestly streamed fragment is cheaper than a "resident" one that lives in scratch.  Holding 10-12 k-steps in the
+// accumulation half through an inline-asm MFMA (B operand constraint "a") is correct and was slower (3.58-3.68).
+#define LB_SR(STEPS) 10
+#ifndef LB_PF
+#define LB_PF 2                // ring depth of the product's panel / streamed-fragment loads, in pairs of k-steps
+#endif
+#define LB_NL 6                // further k-steps per wave resident in LDS (96 KB per workgroup)
 
 struct LocBigBwdArgs {
   int F, T, B, Bs, R, H, A, gru;
@@ -56,13 +63,13 @@ struct LocBigBwdArgs {
 // staging): of the STEPS k-steps per wave SR + NL never move again, STEPS - SR - NL are streamed every step.
 template <int STEPS, int SR, int PF, int NL>
 __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
-  constexpr int RB = 4, CG = 4, ROWS = 64, RED_LD = 65, NP = STEPS / 2, NPR = SR / 2, NPS = NP - NPR, UW = 16;
+  constexpr int RB = 4, CG = 4, ROWS = 64, RED_LD = 65, RED_ROWS = 32, LRED_LD = 17, NP = STEPS / 2, NPR = SR / 2, NPS = NP - NPR, UW = 16;
   constexpr int NPL = NL / 2, NPG = NPS - NPL;             // streamed-image pairs: the first NPG through the register ring every step, the last NPL resident in LDS
   static_assert(NL % 2 == 0 && NPG >= 0, "LDS-resident k-steps: whole pairs, no more than the image holds");
   static_assert(SR % 2 == 0 && SR <= STEPS && SR >= 2 * PF, "resident k-steps: whole pairs, at least the prefetch distance");
   extern __shared__ __attribute__((aligned(16))) float lb_smem[];
-  float* red = lb_smem;                                                      // [4 waves][ROWS][RED_LD]; phase C aliases it
-  char* wl = reinterpret_cast<char*>(lb_smem + 4 * ROWS * RED_LD);           // LDS-resident fragments [4 waves][NL][CG][64 lanes][16 bytes]
+  float* red = lb_smem;                                                      // P: [4 waves][RED_ROWS][RED_LD], two passes of 32 rows; L: [4 waves][ROWS][LRED_LD]; phase C aliases it
+  char* wl = reinterpret_cast<char*>(lb_smem + 4 * RED_ROWS * RED_LD);       // LDS-resident fragments [4 waves][NL][CG][64 lanes][16 bytes]
   bf16_t* hl = reinterpret_cast<bf16_t*>(wl + (size_t)4 * NL * CG * 1024);   // [ROWS][4 gates][UW]: dG_s of this workgroup's units
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wg = blockIdx.x, R = p.R, B = p.B, Bs = p.Bs, H = p.H, A = p.A, F = p.F, T = p.T, K = 4 * R, NT = H + R;
@@ -127,7 +134,6 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
   // ---------------------------------------------------------------- L: residents (workgroups j < R / 16)
   const bool isL = wg < R / UW, isC = wg < B;
   const int u0 = wg * UW;
-  const int lrow = tid >> 2, luq = (tid & 3) * 4;          // this thread's cells: row lrow, units u0 + luq .. + 4
   bf16x8 wrt;                                               // W_r^T fragment of the small product: B[k = a][n = unit]
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -138,33 +144,41 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
   // L's operands that do not depend on the chain (saved activations, cell states, the direct gradient) are requested one
   // phase ahead — behind the arrival at the barrier that ends the previous step — and the K partials of the step before as
   // soon as they are complete (behind barrier 2): behind barrier 3 only the dWhr fragments are still to come
-  const size_t lrow_c = lrow < B ? lrow : 0;
   f32x4 av[4], cc = {0.f, 0.f, 0.f, 0.f}, cp = {0.f, 0.f, 0.f, 0.f}, dhd = {0.f, 0.f, 0.f, 0.f}, pk[4];
-  auto l_prefetch = [&](int s) {
-    const int u = u0 + luq;
-    const float* a = p.acts + ((size_t)s * Bs + lrow_c) * 4 * R + u;
+  // (Per-lane indices are re-derived from a laundered copy of the thread index in every step: as loop invariants every address
+  // built from them — 16 + 16 + 11 of them — was computed ahead of the time loop and kept in, i.e. spilled from, registers.)
+  auto l_prefetch = [&](int s, int tl) {     // (scalar bases + 32-bit lane offsets: see phase C's prefetch)
+    const int lrow = tl >> 2, luq = (tl & 3) * 4, lrow_c = lrow < B ? lrow : 0;
+    const unsigned lo4 = (unsigned)lrow_c * (unsigned)(4 * R) + (unsigned)luq, lo1 = (unsigned)lrow_c * (unsigned)R + (unsigned)luq;
+    const lc_gf32 ab_ = lc_launder_s(p.acts + (size_t)s * Bs * 4 * R + u0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) av[g] = *reinterpret_cast<const f32x4*>(a + (size_t)g * R);
-    if (!p.gru) cc = *reinterpret_cast<const f32x4*>(p.Cr + ((size_t)s * Bs + lrow_c) * R + u);
-    if (s > 0) cp = *reinterpret_cast<const f32x4*>((p.gru ? p.Hr : p.Cr) + ((size_t)(s - 1) * Bs + lrow_c) * R + u);
+    for (int g = 0; g < 4; ++g) av[g] = *(lc_gf32x4)(ab_ + lo4 + (unsigned)(g * R));
+    if (!p.gru) cc = *(lc_gf32x4)(lc_launder_s(p.Cr + (size_t)s * Bs * R + u0) + lo1);
+    if (s > 0) cp = *(lc_gf32x4)(lc_launder_s((p.gru ? p.Hr : p.Cr) + (size_t)(s - 1) * Bs * R + u0) + lo1);
     else cp = f32x4{0.f, 0.f, 0.f, 0.f};
-    dhd = *reinterpret_cast<const f32x4*>(p.dHr + ((size_t)s * Bs + lrow_c) * R + u);
+    dhd = *(lc_gf32x4)(lc_launder_s(p.dHr + (size_t)s * Bs * R + u0) + lo1);
   };
-  if (isL) l_prefetch(F - 1);
+  {
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    if (isL) l_prefetch(F - 1, tl);
+  }
 
   for (int q = 0; q < F; ++q) {
     const int s = F - 1 - q;
     LB_TS(q, 0);
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int lrow = tl >> 2, luq = (tl & 3) * 4;          // this thread's cells: row lrow, units u0 + luq .. + 4
     // ============================================================ L(q): dhr_s, cell backward, dG_s
     // streamed weight fragments of P(q): their addresses do not depend on the chain — the first ring slots are requested now
     bf16x8 fw[PF][2][CG];
-    const bf16_t* wsl = wst;
-    asm volatile("" : "+v"(wsl));          // (laundered every step: as loop invariants the addresses were materialised ahead of the loop and spilled)
+    const LC_GLOBAL bf16_t* wsl = lc_launder_v(wst);     // (laundered every step: as loop invariants the addresses were materialised ahead of the loop and spilled)
     auto issue_w = [&](int slot, int i) {
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int g = 0; g < CG; ++g) fw[slot][hh][g] = *reinterpret_cast<const bf16x8*>(wsl + (size_t)(((i * 2 + hh) * CG + g) * 512));
+        for (int g = 0; g < CG; ++g) fw[slot][hh][g] = *(lc_gbf16x8)(wsl + (size_t)(((i * 2 + hh) * CG + g) * 512));
     };
     if (isL) {
       if (q > 0) {
@@ -181,11 +195,11 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
 #pragma unroll
           for (int i = 0; i < RB; ++i) a1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[i], wrt, a1[i], 0, 0, 0);
         }
-        float* prt = red + wave * (ROWS * RED_LD);
+        float* prt = red + wave * (ROWS * LRED_LD);
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + (lane & 15)] = a1[i][r];
+          for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * LRED_LD + (lane & 15)] = a1[i][r];
       }
       f32x4 dh = dhd;
       __syncthreads();
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
         for (int e = 0; e < 4; ++e) {
           float v = (pk[0][e] + pk[1][e]) + (pk[2][e] + pk[3][e]);
 #pragma unroll
-          for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + lrow * RED_LD + luq + e];
+          for (int w = 0; w < 4; ++w) v += red[w * (ROWS * LRED_LD) + lrow * LRED_LD + luq + e];
           dh[e] += v;
         }
       }
@@ -278,55 +292,68 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
       }
       LB_TS(q, 3);
       LB_WTS(q, 1);
-      float* prt = red + wave * (ROWS * RED_LD);
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int g = 0; g < CG; ++g)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) prt[(i * 16 + (lane >> 4) * 4 + r) * RED_LD + g * 16 + (lane & 15)] = acc[i][g][r];
-      __syncthreads();
-      // thread = (row 16 rr + tid / 16, 4 columns): the four waves' K parts summed; a wave's store covers 4 rows x 256
+      // the four waves' K parts are summed through LDS in two passes of 32 rows (a 64-row buffer would take the room of two
+      // more LDS-resident k-steps per wave).  thread = (row 16 rr + tid / 16, 4 columns); a wave's store covers 4 rows x 256
       // contiguous bytes, written through (as 8-byte stores 64 bytes apart the 16 KB took 6 us to be acknowledged)
+      float* prt = red + wave * (RED_ROWS * RED_LD);
       const int prow = tid >> 4, pc0 = (tid & 15) * 4;
       float* dst = p.Part + (((size_t)q * 4 + kqi) * ROWS + prow) * NT + cb * 64 + pc0;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += red[w * (ROWS * RED_LD) + (rr * 16 + prow) * RED_LD + pc0 + e];
-        lc_store16f(dst + (size_t)rr * 16 * NT, v);
+          for (int g = 0; g < CG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) prt[(i2 * 16 + (lane >> 4) * 4 + r) * RED_LD + g * 16 + (lane & 15)] = acc[half * 2 + i2][g][r];
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += red[w * (RED_ROWS * RED_LD) + (rr * 16 + prow) * RED_LD + pc0 + e];
+          lc_store16f(dst + (size_t)(half * 32 + rr * 16) * NT, v);
+        }
       }
     }
     LB_TS(q, 4);
     bar_arrive(3u * (unsigned)q + 2u);
     LB_WTS(q, 2);
     // phase C's saved operands do not depend on the chain: requested while the barrier completes
-    const int tt = tid & 31, h8 = tid >> 5;                   // (decoder step, eighth of the hidden columns)
-    const int ck = tid & 127, cth = tid >> 7;                 // (attention column, half of the decoder steps)
+    int tc = tid;
+    asm volatile("" : "+v"(tc));
+    const int tt = tc & 31, h8 = tc >> 5;                     // (decoder step, eighth of the hidden columns)
+    const int ck = tc & 127, cth = wave >> 1;                 // (attention column, half of the decoder steps: wave-uniform)
     float hv[64], udv[16], whk = 0.f, wk = 0.f;
     if (isC) {
-      // (loop-invariant addresses: laundered, or the compiler keeps all 32 of them in registers across the whole step)
-      const float* hs0 = p.Hs + ((size_t)(tt < T ? tt : 0) * Bs + wg) * H + 64 * h8;
-      const float* ud0 = p.Ud + ((size_t)(cth * 16) * Bs + wg) * A + (ck < A ? ck : 0);
-      asm volatile("" : "+v"(hs0), "+v"(ud0));
+      // Scalar bases + 32-bit lane offsets, every load unconditional (clamped addresses: what lies beyond T / H / A meets zeros
+      // or a guard below).  As per-lane 64-bit pointers these addresses were loop invariants or induction variables, were
+      // spilled, and every reload from scratch waited for ALL loads in flight: the "prefetch" took 4.5 us.
+      const int ckc = ck < A ? ck : 0;
+      const lc_gf32 whb = lc_launder_s(p.Whr + ((size_t)s * Bs + wg) * A);
+      const lc_gf32 abb = lc_launder_s(p.ab);
+      const lc_gf32 wwb = lc_launder_s(p.w);
+      const lc_gf32 udb = lc_launder_s(p.Ud + (size_t)wg * A);
+      const lc_gf32 hsb = lc_launder_s(p.Hs + (size_t)wg * H);
+      whk = whb[ckc] + abb[ckc];
+      wk = wwb[ckc];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) udv[i] = (udb + (size_t)(cth * 16 + i < T ? cth * 16 + i : 0) * (size_t)(Bs * A))[ckc];     // (scalar row address + lane column)
+      const unsigned hoff = (unsigned)(tt < T ? tt : 0) * (unsigned)(Bs * H) + (unsigned)(64 * h8 < H ? 64 * h8 : 0);
 #pragma unroll
       for (int i = 0; i < 64; i += 4) {
-        const int h = 64 * h8 + i;
-        const f32x4 v = (tt < T && h < H) ? *reinterpret_cast<const f32x4*>(hs0 + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = *(lc_gf32x4)(hsb + hoff + i);
         hv[i] = v[0]; hv[i + 1] = v[1]; hv[i + 2] = v[2]; hv[i + 3] = v[3];
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int t = cth * 16 + i;
-        udv[i] = (t < T && ck < A) ? ud0[(size_t)i * Bs * A] : 0.f;
-      }
-      if (ck < A) { whk = p.Whr[((size_t)s * Bs + wg) * A + ck] + p.ab[ck]; wk = p.w[ck]; }
+      if (ck >= A) wk = 0.f;
     }
+    LB_WTS(q, 3);
     if (isC) {
       if (tid < 64) flags_wait(p.bar, 4 * NXB, fb + 3u * (unsigned)q + 2u);
+      LB_WTS(q, 4);
       __syncthreads();
     }
     LB_TS(q, 5);
@@ -397,7 +424,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
     LB_TS(q, 6);
     bar_arrive(3u * (unsigned)q + 3u);
     if (isL && q + 1 < F) {
-      l_prefetch(s - 1);
+      l_prefetch(s - 1, tl);
       // the K partials of this workgroup's columns of dhr: their four producers finished P(q) a caption phase ago
       {
         const unsigned* f = p.bar + 4 * NXB + ((H + u0) >> 6) - NXB + (lane & 3) * (p.NCB - NXB);
@@ -410,7 +437,15 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
         if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
 #pragma unroll
-      for (int z = 0; z < 4; ++z) pk[z] = *reinterpret_cast<const f32x4*>(p.Part + (((size_t)q * 4 + z) * ROWS + lrow) * NT + H + u0 + luq);
+      for (int z = 0; z < 4; ++z)
+        pk[z] = *(lc_gf32x4)(lc_launder_s(p.Part + ((size_t)q * 4 + z) * ROWS * NT + H + u0) + (unsigned)lrow * (unsigned)NT + (unsigned)luq);
+    } else {
+      // (defined on every path: assigned under the condition only, the values of the step before stay live through the P and
+      // C phases of every step — 44 registers the product's ring was spilled for)
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int z = 0; z < 4; ++z) { av[z] = z4; pk[z] = z4; }
+      cc = z4; cp = z4; dhd = z4;
     }
     bar_wait(3u * (unsigned)q + 3u);
     LB_TS(q, 7);
@@ -421,7 +456,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
     if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
   }
 }
-template <int NL> constexpr size_t lcbig_smem_bytes() { return (size_t)4 * 64 * 65 * 4 + (size_t)4 * NL * 4 * 1024 + (size_t)64 * 4 * 16 * 2; }
+template <int NL> constexpr size_t lcbig_smem_bytes() { return (size_t)4 * 32 * 65 * 4 + (size_t)4 * NL * 4 * 1024 + (size_t)64 * 4 * 16 * 2; }
 
 // The streamed k-steps of lcbig_bwd_kernel<STEPS, SR, .> as MFMA B fragments in the order it consumes them:
 // dst[wg][wave][js][g][lane][8] from WT = ([W_ih | W_hh])^T [H + R][ldwt].  Run after every update of the weights.

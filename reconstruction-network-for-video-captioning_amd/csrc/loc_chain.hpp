@@ -53,7 +53,10 @@ struct LocChainArgs {
 #define LC_CPW 2              // captions per C workgroup
 // hybrid forward chain: k-steps per wave resident in registers for STEPS k-steps in all — as many as compile without scratch
 // next to the streaming ring (28: 14; 32: 12; 16 resident spill 132 bytes per lane)
-#define LC_HYB_SR(STEPS) ((STEPS) == 28 ? 14 : 12)
+#ifndef LC_HYB_SR28
+#define LC_HYB_SR28 14
+#endif
+#define LC_HYB_SR(STEPS) ((STEPS) == 28 ? LC_HYB_SR28 : 12)
 #define LC_MAX_PHASE 128       // barrier words are (launch epoch << 7) + phase: every phase number of a launch stays below this
 __device__ __forceinline__ void lc_poll(const unsigned* flags, int n, unsigned target, unsigned* bar, unsigned& spin) {
   // wave 0 of the relay workgroup: all n <= 256 flags have reached `target`
@@ -113,6 +116,15 @@ __device__ __forceinline__ void lc_store16f(float* dst, f32x4 v) {
 __device__ __forceinline__ void lc_store16(bf16_t* dst, const bf16_t* src) {
   lc_store16f(reinterpret_cast<float*>(dst), *reinterpret_cast<const f32x4*>(src));
 }
+// A pointer that went through an empty asm (to keep its address arithmetic out of loop-invariant hoisting) has lost its address
+// space: loads through it are FLAT loads, which may return out of order with global loads, so every wait next to them becomes
+// vmcnt(0) and a register ring of loads drains at each use.  These put the address space back.
+#define LC_GLOBAL __attribute__((address_space(1)))
+typedef const LC_GLOBAL bf16x8* lc_gbf16x8;
+typedef const LC_GLOBAL f32x4* lc_gf32x4;
+typedef const LC_GLOBAL float* lc_gf32;
+template <typename T> __device__ __forceinline__ const LC_GLOBAL T* lc_launder_v(const T* ptr) { asm volatile("" : "+v"(ptr)); return (const LC_GLOBAL T*)ptr; }
+template <typename T> __device__ __forceinline__ const LC_GLOBAL T* lc_launder_s(const T* ptr) { asm volatile("" : "+s"(ptr)); return (const LC_GLOBAL T*)ptr; }
 typedef short lc_s4 __attribute__((ext_vector_type(4)));
 typedef _Float16 lc_h4 __attribute__((ext_vector_type(4)));
 
@@ -468,13 +480,13 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       bf16x8 fw[PF][2][CG];
       // (the row pointers are laundered through an empty asm every step: as loop invariants the compiler materialised all
       // 4 (STEPS - SR) 64-bit addresses ahead of the time loop — 128 registers — and spilled them)
-      const bf16_t* wsl = wst;
-      if constexpr (SR < STEPS) asm volatile("" : "+v"(wsl));
+      const LC_GLOBAL bf16_t* wsl = (const LC_GLOBAL bf16_t*)wst;
+      if constexpr (SR < STEPS) wsl = lc_launder_v(wst);
       auto issue_w = [&](int slot, int i) {        // i = streamed pair, in consumption order (= the image's order)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-          for (int g = 0; g < CG; ++g) fw[slot][hh][g] = *reinterpret_cast<const bf16x8*>(wsl + (size_t)(((i * 2 + hh) * CG + g) * 512));
+          for (int g = 0; g < CG; ++g) fw[slot][hh][g] = *(lc_gbf16x8)(wsl + (size_t)(((i * 2 + hh) * CG + g) * 512));
       };
       constexpr int NPS = NP - NPR;                       // streamed pairs; iteration i < NPS -> pair NPR + i, then the resident pairs
       auto pair_of = [&](int i) { return i < NPS ? NPR + i : i - NPS; };

@@ -71,6 +71,8 @@ if D > 2048:
         print("%-32s period %.2f us" % (nm, np.median(np.diff(ts[role, 2:F - 2, 0]))))
         for i in range(1, 8):
             print("    %-22s +%.2f" % (pts[i], np.median(t[:, i] - t[:, i - 1])))
+    w5 = raw[5120:5120 + 1280].reshape(5, 256)
+    print("caption workgroups 0..7 at step 10: acked / prefetch issued / x flags seen", "  ".join("%4.1f/%4.1f/%4.1f" % tuple(w5[i, c] - w5[0].min() for i in (2, 3, 4)) for c in range(8)))
     w = raw[5120:5120 + 768].reshape(3, 256)
     t0 = w[0].min()
     print("per workgroup at step 10 (us after the first release): released / products done / partial acknowledged")
