@@ -370,10 +370,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       DC_TS(5);
       // publish h_t[b]: 16 bytes per k-group, written through
       if (tid < (H >> 3)) {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(hl + tid * 8);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)t * pan_t + ((size_t)tid * RC_PAN_ROWS + b) * 8);
-        __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rc_store16(p.Pan + (size_t)t * pan_t + ((size_t)tid * RC_PAN_ROWS + b) * 8, hl + tid * 8);
       }
       if (t + 1 < p.T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // (the stores below are issued after the arrive, see the end of the loop body)
@@ -728,10 +725,7 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       DCB_TS(4);
       const bool more = s + 1 < p.T;
       for (int kg = tid; kg < (KA >> 3); kg += 256) {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(srow + kg * 8);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)s * pan_t + ((size_t)kg * RC_PAN_ROWS + b) * 8);
-        __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rc_store16(p.Pan + (size_t)s * pan_t + ((size_t)kg * RC_PAN_ROWS + b) * 8, srow + kg * 8);
       }
       if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; rc_arrive(p.bar, fb + ph); }
       DCB_TS(5);

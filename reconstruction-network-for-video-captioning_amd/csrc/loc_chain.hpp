@@ -105,17 +105,9 @@ __device__ __forceinline__ void lc_wait_or_relay(bool me, unsigned* rel, const u
 __device__ __forceinline__ void lc_arrive(unsigned* flag, unsigned v) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 16 bytes per lane, written through to the agent's coherence point: the instruction an agent-scope relaxed atomic store compiles
-// to (global_store_dwordx2 ... sc1), in its 16-byte form — one request per lane instead of two
-// (the s_nop is the wait state a VMEM store of more than 8 bytes needs before a VALU instruction may overwrite its data registers:
-// the compiler's hazard recognizer inserts it behind its own stores and does not look inside inline asm — without it the next
-// loop iteration's adds corrupted the stored values)
-__device__ __forceinline__ void lc_store16f(float* dst, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lc_store16(bf16_t* dst, const bf16_t* src) {
-  lc_store16f(reinterpret_cast<float*>(dst), *reinterpret_cast<const f32x4*>(src));
-}
+// (16-byte write-through stores: rc_store16f / rc_store16, rec_chain.hpp)
+__device__ __forceinline__ void lc_store16f(float* dst, f32x4 v) { rc_store16f(dst, v); }
+__device__ __forceinline__ void lc_store16(bf16_t* dst, const bf16_t* src) { rc_store16(dst, src); }
 // A pointer that went through an empty asm (to keep its address arithmetic out of loop-invariant hoisting) has lost its address
 // space: loads through it are FLAT loads, which may return out of order with global loads, so every wait next to them becomes
 // vmcnt(0) and a register ring of loads drains at each use.  These put the address space back.

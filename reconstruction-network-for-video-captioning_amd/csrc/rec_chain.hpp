@@ -73,6 +73,17 @@ __device__ __forceinline__ void rc_epoch_bump(unsigned* epoch, unsigned e) {
 // sticky word bar[257]; every wait of this and of later launches then falls through, and the kernel poisons the step's
 // total loss with NaN (rc_poison) — wrong loudly instead of hung.
 #define RC_SPIN_LIMIT (1u << 22)
+// 16 bytes per lane, written through to the agent's coherence point: the instruction an agent-scope relaxed atomic store compiles
+// to (global_store_dwordx2 ... sc1), in its 16-byte form — one request per lane instead of two
+// (the s_nop is the wait state a VMEM store of more than 8 bytes needs before a VALU instruction may overwrite its data registers:
+// the compiler's hazard recognizer inserts it behind its own stores and does not look inside inline asm — without it the next
+// loop iteration's adds corrupted the stored values)
+__device__ __forceinline__ void rc_store16f(float* dst, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void rc_store16(bf16_t* dst, const bf16_t* src) {
+  rc_store16f(reinterpret_cast<float*>(dst), *reinterpret_cast<const f32x4*>(src));
+}
 __device__ __forceinline__ bool rc_give_up(unsigned* bar, unsigned& spin) {
   if ((++spin & 0x3ffu) != 0) return false;
   if (spin <= RC_SPIN_LIMIT && __hip_atomic_load(bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return false;
@@ -322,10 +333,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     const bool it_on = tid < KG * own && it_rg < B;
     const bf16_t* it_src = hl + (it_rg - r0) * UW + it_j * 8;
     if (it_on) {
-      const uint64_t* src = reinterpret_cast<const uint64_t*>(it_src);
-      uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)t * pan_t + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8);
-      __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      rc_store16(p.Pan + (size_t)t * pan_t + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, it_src);
     }
     const bool more = t + 1 < p.T;
     if (more) {
@@ -558,10 +566,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
 #pragma unroll
     for (int j = 0; j < IPT; ++j)
       if (it_on[j]) {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(it_src[j]);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(p.Pan + (size_t)s * pan_t + ((size_t)(it_col[j] >> 3) * RC_PAN_ROWS + it_rg[j]) * 8);
-        __hip_atomic_store(dst, src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rc_store16(p.Pan + (size_t)s * pan_t + ((size_t)(it_col[j] >> 3) * RC_PAN_ROWS + it_rg[j]) * 8, it_src[j]);
       }
     const bool more = s + 1 < p.T;
     if (more) {
