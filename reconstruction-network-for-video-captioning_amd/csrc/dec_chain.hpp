@@ -14,6 +14,9 @@
 // A workgroup takes part in both phases (grid = max(NA, B) <= CU count, one workgroup per CU).
 // Limits: bf16 path, H % 8 == 0, H <= 512, F <= 32, A <= 128, (4H + A) % 16 == 0, B <= 112.
 #pragma once
+#ifndef DC_STAMP_PAIR
+#define DC_STAMP_PAIR 1
+#endif
 #include "common.hpp"
 #include "rec_chain.hpp"
 
@@ -196,8 +199,14 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
             if (p.ll) {
               uint64_t* L = reinterpret_cast<uint64_t*>(p.G1) + ((size_t)t * B + row) * N + wg * 16 + pc;
               const uint64_t st = (uint64_t)(ep | (unsigned)t) << 32;
-              __hip_atomic_store(L, st | __builtin_bit_cast(unsigned, v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(L + 1, st | __builtin_bit_cast(unsigned, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              // two stamped words = 16 contiguous, 16-byte-aligned bytes: one store (each 8-byte word lies inside one 32-byte
+              // sector, which is what its reader's 8-byte load observes as a unit — DC_STAMP_PAIR=0 restores two 8-byte atomics)
+              if (DC_STAMP_PAIR) {
+                rc_store16f(reinterpret_cast<float*>(L), f32x4{v0, __builtin_bit_cast(float, (unsigned)(st >> 32)), v1, __builtin_bit_cast(float, (unsigned)(st >> 32))});
+              } else {
+                __hip_atomic_store(L, st | __builtin_bit_cast(unsigned, v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(L + 1, st | __builtin_bit_cast(unsigned, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
             } else {
               union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
               __hip_atomic_store(reinterpret_cast<uint64_t*>(Gt + (size_t)row * N + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -594,8 +603,14 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
             if (p.ll) {
               uint64_t* L = reinterpret_cast<uint64_t*>(p.G2) + ((size_t)s * B + rg) * H + ug * 16 + pc;
               const uint64_t st = (uint64_t)(ep | (unsigned)s) << 32;
-              __hip_atomic_store(L, st | __builtin_bit_cast(unsigned, v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(L + 1, st | __builtin_bit_cast(unsigned, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              // two stamped words = 16 contiguous, 16-byte-aligned bytes: one store (each 8-byte word lies inside one 32-byte
+              // sector, which is what its reader's 8-byte load observes as a unit — DC_STAMP_PAIR=0 restores two 8-byte atomics)
+              if (DC_STAMP_PAIR) {
+                rc_store16f(reinterpret_cast<float*>(L), f32x4{v0, __builtin_bit_cast(float, (unsigned)(st >> 32)), v1, __builtin_bit_cast(float, (unsigned)(st >> 32))});
+              } else {
+                __hip_atomic_store(L, st | __builtin_bit_cast(unsigned, v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(L + 1, st | __builtin_bit_cast(unsigned, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
             } else {
               union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
               __hip_atomic_store(reinterpret_cast<uint64_t*>(p.G2 + ((size_t)s * B + rg) * H + ug * 16 + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
