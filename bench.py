@@ -105,7 +105,8 @@ def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
     # (site, `which` of recnet_recurrent_step_bytes, name)
     cands = [(9, 5, "dec_chain_kernel (decoder forward chain, T steps in one launch)"),
              (10, 6, "dec_chain_bwd_kernel (decoder BPTT chain, T steps in one launch)"),
-             (8, 4, "loc_chain_bwd_kernel (local reconstructor backward chain, F steps in one launch)" if local else
+             (8, 4, ("lcbig_bwd_kernel (local reconstructor backward chain for R > 2048: three phases per step, F steps in one launch)"
+                     if eng.dims["D"] > 2048 else "loc_chain_bwd_kernel (local reconstructor backward chain, F steps in one launch)") if local else
                     "rec_chain_bwd_kernel (reconstructor backward chain, T steps in one launch)"),
              (7, 3, "loc_chain_kernel (local reconstructor forward chain, F steps in one launch)" if local else
                     "rec_chain_kernel (reconstructor forward chain, T steps in one launch)"),

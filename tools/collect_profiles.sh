@@ -29,7 +29,7 @@ C2=""; C3="--rec local"; C4="--rec local --batch 32 --frames 40 --feat 2048"; C5
 pmc c2 "$C2" global 100 28 1536 dec_chain_kernel dec_chain_bwd_kernel rec_chain_kernel rec_chain_bwd_kernel
 pmc c3 "$C3" local 100 28 1536 loc_chain_kernel loc_chain_bwd_kernel
 pmc c4 "$C4" local 32 40 2048 loc_chain_kernel loc_chain_bwd_kernel dec_chain_kernel dec_chain_bwd_kernel
-pmc c5 "$C5" local 64 28 3584 loc_chain_kernel "gemm_lds_kernel<false, true, 4, 4, 128>" dec_chain_bwd_kernel
+pmc c5 "$C5" local 64 28 3584 loc_chain_kernel lcbig_bwd_kernel dec_chain_bwd_kernel
 for f in $O/pmc_traffic_*.json; do cp $f profiles/${RND}_$(basename $f); done
 run c2 "$C2" ""
 run c3 "$C3" "--no-cpu-baseline"
@@ -52,6 +52,10 @@ RN_LOC_HYBRID=0 python3 bench.py $C5 $x > $O/bench_c5_per_step_forward.json 2>/d
 python3 bench.py --feed 1 $x > $O/bench_c2_host_feed.json 2>/dev/null
 python3 bench.py --defer 1 $x > $O/bench_c2_deferred_reconstructor_update.json 2>/dev/null
 python3 tools/rccl_bucket_bench.py > $O/rccl_buckets_1rank_c2.json 2>/dev/null
+# in-kernel stamps of the chain kernels (probe build of the library)
+RN_LIB_PROBE=1 python3 tools/loc_chain_probe.py 100 28 1536 > $O/chain_probe_c3.txt 2>/dev/null
+RN_LIB_PROBE=1 python3 tools/loc_chain_probe.py 64 28 3584 > $O/chain_probe_c5.txt 2>/dev/null
+RN_LOC_HYBRID=0 RN_PERSIST_LOC_BIG=0 python3 bench.py $C5 $x > $O/bench_c5_per_step_kernels.json 2>/dev/null
 for cfg in c2 c5; do
   a="$C2"; [ $cfg = c5 ] && a="$C5"
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$cfg -- python3 bench.py $a $x --steps 10 --warmup 3 > /dev/null 2>&1
