@@ -716,18 +716,15 @@ __device__ __forceinline__ void lcb_xsplit_role(const LocChainBwdArgs& p, float*
     __syncthreads();
     if (xi == 0) LC_TS(5, q, 1);
     float* Dq = p.Dx + ((size_t)q * p.KSX + kp) * B * H;
-    // 4 columns per thread: one 16-byte write-through store, 256 contiguous bytes per row (H % 4 == 0: H % 32 is a launch condition)
-    for (int idx = tid; idx < OWN * (UWX / 4); idx += 256) {
-      const int rg = own_lo + idx / (UWX / 4), pc = (idx % (UWX / 4)) * 4, rl = rg - r0;
+    for (int idx = tid; idx < OWN * (UWX / 2); idx += 256) {
+      const int rg = own_lo + idx / (UWX / 2), pc = (idx % (UWX / 2)) * 2, rl = rg - r0;
       if (rg < B && j0 + pc < H) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += red[w * (ROWS * RED_LD) + rl * RED_LD + pc + e];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= drop_at(p.dd, key, s, rg, H, j0 + pc + e);
-        lc_store16f(Dq + (size_t)rg * H + j0 + pc, v);
+        for (int w = 0; w < 4; ++w) { v0 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc]; v1 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc + 1]; }
+        union { float f[2]; uint64_t u; } pk;
+        pk.f[0] = v0 * drop_at(p.dd, key, s, rg, H, j0 + pc); pk.f[1] = v1 * drop_at(p.dd, key, s, rg, H, j0 + pc + 1);
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(Dq + (size_t)rg * H + j0 + pc), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
