@@ -18,7 +18,7 @@ from bench import build_models  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 WIN = 2000
-CONFIGS = [("c2", "global", 100, 28, 1536), ("c3", "local", 100, 28, 1536), ("c4", "local", 32, 40, 2048)]
+CONFIGS = [("c2", "global", 100, 28, 1536), ("c3", "local", 100, 28, 1536), ("c4", "local", 32, 40, 2048), ("c5", "local", 64, 28, 3584)]
 V = 4188
 out = {}
 for name, kind, B, F, D in CONFIGS:
