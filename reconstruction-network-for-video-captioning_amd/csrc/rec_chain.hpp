@@ -30,6 +30,19 @@ struct RecChainArgs {
   int master;                     // 1: gridDim.x has one extra column; block (gridDim.x - 1, 0) is the barrier master
   float* poison;                  // see rc_give_up
   float* hmean; bf16_t* hmean_lp; int ld_hmean;   // mean_t h_t [B][R] (+ operand copy, zero padded): what the output layer reads
+  // Output-layer epilogue (epi = 1; global reconstructor, train.py:96-103): after the last step the launch also computes
+  //   out = mean_t h_t . W_o^T + b_o ;  d = out - target ;  partial sums of d^2 ;  dout = gcoef d (fp32) and lp_scale gcoef d (operand copy)
+  // one more barrier phase, its weights in the registers W_hh has left — instead of a split-K GEMM, its reduction and the MSE kernel
+  // between the two chains.
+  int epi;
+  const bf16_t* Wo; int ldwo;     // [R][ldwo] packed W_o (row = output column)
+  const float* obias;             // [R]
+  const float* target;            // [B][R] mean_f enc (rows of this launch)
+  float* dout;                    // [B][R] <- gcoef (out - target)
+  bf16_t* dout_lp;                // [B][R] <- lp_scale gcoef (out - target)   (leading dimension R: no padding columns)
+  bf16_t* PanM;                   // [R/8][RC_PAN_ROWS][8] exchange copy of mean_t h_t
+  float* mse_part;                // [workers] partial sums of d^2
+  float gcoef, lp_scale;
 };
 
 #define RC_MB 7               // 16-row blocks: B <= 112
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
   const int nwx = (int)gridDim.x - (p.master ? 1 : 0), widx = blockIdx.y * nwx + blockIdx.x;   // workers per row, my flag
   if (p.master && (int)blockIdx.x == nwx) {
-    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1);
+    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1 + (p.epi ? 1 : 0));
     return;
   }
   const int rot = blockIdx.x % NP;                       // workgroups start at different k: spreads the L2 channels
@@ -387,6 +400,100 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     if (blockIdx.x == 0 && blockIdx.y == 0)
       for (int j = tid; j < B * (p.ld_hmean - R); j += 256)
         p.hmean_lp[(size_t)(j / (p.ld_hmean - R)) * p.ld_hmean + R + j % (p.ld_hmean - R)] = (bf16_t)0.f;
+  }
+  if (p.epi) {
+    // ---- output-layer epilogue (UW == 16, master barrier: host-checked).  Publish this workgroup's columns of mean_t h_t like a step ...
+    __syncthreads();
+    const float sc = 1.0f / (float)p.T;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      if (cell < ROWS * UW) hl[cell] = (bf16_t)(hsum[c] * sc);
+    }
+    __syncthreads();
+    {
+      const int it_j = tid / own, it_rg = own_lo + tid % own;
+      if (tid < KG * own && it_rg < B)
+        rc_store16(p.PanM + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, hl + (it_rg - r0) * UW + it_j * 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    rc_arrive_at(p.bar, widx, fb + (unsigned)p.T);
+    // ... W_o rows of its 16 output columns into the registers W_hh has left, the target and the bias while the barrier completes
+    bf16x8 wo[STEPS];
+    {
+      const bf16_t* wrow = p.Wo + (size_t)(u0 + (lane & 15)) * p.ldwo + kq;
+#pragma unroll
+      for (int ks = 0; ks < STEPS; ++ks) {
+        const int k = kw0 + ks * 32;
+        wo[ks] = (k + kq < R) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    float tg[CPT], ob[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const int row = mine[c] ? r0 + cell / UW : 0, u = u0 + cell % UW;
+      tg[c] = p.target[(size_t)row * R + u];
+      ob[c] = p.obias[u];
+    }
+    rc_wait_release(p.bar + 256, fb + (unsigned)p.T);
+    {
+      const bf16_t* A = p.PanM + lane_off;
+      f32x4 acc[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int FB = STEPS <= 12 ? STEPS : 8, NFB = (STEPS + FB - 1) / FB;      // panel fragments: FB k-steps in flight (the registers of W_hh are free)
+      bf16x8 fa[FB][RB];
+#pragma unroll
+      for (int b4 = 0; b4 < NFB; ++b4) {
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+          const int ks = b4 * FB + j;
+          if (ks < STEPS) {
+            const int k = kw0 + ks * 32;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) fa[j][i] = *reinterpret_cast<const bf16x8*>(A + ((k < R ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < FB; ++j) {
+          const int ks = b4 * FB + j;
+          if (ks < STEPS) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][i], wo[ks], acc[i], 0, 0, 0);
+          }
+        }
+      }
+      float* part = red + wave * (ROWS * RED_LD);
+      const int rr = (lane >> 4) * 4, cc = lane & 15;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + cc] = acc[i][r];
+    }
+    __syncthreads();
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int cell = tid + c * 256;
+      const int rowl = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
+      float v = ob[c];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + rowl * RED_LD + ul];
+      if (mine[c]) {
+        const float d = v - tg[c], g = p.gcoef * d;
+        sq += d * d;
+        const size_t o = (size_t)(r0 + rowl) * R + u0 + ul;
+        p.dout[o] = g;
+        p.dout_lp[o] = (bf16_t)(p.lp_scale * g);
+      }
+    }
+    __syncthreads();
+    sq = wave_sum(sq);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (tid == 0) p.mse_part[widx] = (red[0] + red[1]) + (red[2] + red[3]);
   }
   rc_epoch_bump(p.epoch, ep);
   rc_poison(p.bar, p.poison);
