@@ -423,6 +423,14 @@ def test_local_backward_chain_with_k_split_forced(case, monkeypatch):
     test_fused_step_vs_oracle_edge_shapes(case, "local", "bf16")
 
 
+@pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 100, 1536), ("LSTM", 57, 1040), ("LSTM", 112, 2048)])
+def test_output_layer_epilogue_of_the_forward_chain_equals_the_separate_kernels(cell, B, R, monkeypatch):
+    """rec_chain_kernel's epilogue (out = mean_t h_t . W_o^T + b_o, squared-error partial sums, d out and its operand copy behind one more
+    barrier phase: train.py:96-103) against the split-K GEMM + reduction + MSE kernel it replaces (RN_REC_EPILOGUE=0): the headline size,
+    the GRU cells, the smallest batch that takes the two-row-part tiling with a ragged last unit group, every panel row at 16 k-steps."""
+    _chain_variants({"RN_REC_EPILOGUE": "0"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
+
+
 @pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 100, 1536), ("LSTM", 65, 1056), ("LSTM", 112, 1280)])
 def test_global_backward_chain_wide_tiling_equals_the_narrow_one(cell, B, R, monkeypatch):
     """rec_chain_bwd_kernel<48, 3, 2, 2, 16> (32 units x 32 rows, a third of the weights in LDS; B > 64, R in (1024, 1536]):
