@@ -115,6 +115,7 @@ struct recnet_handle {
   int ncu = 0;
   int ctx_done = 0;         // the attended features of all steps were computed early (fwd_bwd_impl)
   int hoist_pending = 0, hoist_par = 0, encmean_hoisted = 0; const float* hoist_enc = nullptr;   // see hoist_side_work (abi_step.inc)
+  int xcat_done = 0;        // dec_chain_kernel wrote the global reconstructor's input operand itself (host_decoder.inc)
   float* dc_G2 = nullptr; void* dc_pan2 = nullptr;
   void *Xcat_g, *Hr_lp, *hrmean_lp, *dout_lp, *dGr, *Xcat_r, *dUd_lp, *dWhr, *dWhrs, *Wr4_w;
   void *Wih_f, *Whh_w, *Wor_w, *Ur_w, *Wr_w, *Wihh_w;

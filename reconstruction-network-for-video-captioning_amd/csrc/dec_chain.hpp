@@ -32,6 +32,8 @@ struct DecChainArgs {
   int master;                      // 1: the last workgroup of the grid is the barrier master (rc_master_loop)
   float* poison;                   // see rc_give_up (rec_chain.hpp)
   float* mp; float mp_scale;       // optional: mp_scale * sum_t h_t [B][H] (the global reconstructor's mean-pooled input)
+  bf16_t* Xcat; int ld_xcat; DropDesc xdd;   // optional (global reconstructor, ld_xcat == 2H): its LSTM input operand [T][Bs][2H] = [h_t ; drop_t(mp)]
+                                   // (global_reconstructor.py:38-41) written by the chain itself instead of xcat_global_kernel behind it
   bf16_t* Pan;                     // [T][rc_pan_elems(H)] exchange: h_t, k-group-major
   float* Hs; float* Cs; float* acts;   // [T][B][H], [T][B][H], [T][B][4H]
   bf16_t* Hlp; int ld_hlp;         // [T][B][ld_hlp] row-major operand copy of h_t, zero padded
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       if (t + 1 < p.T) { __syncthreads(); DC_TS(6); ++ph; rc_arrive(p.bar, fb + ph); }
       bf16_t* Lt = p.Hlp + ((size_t)t * Bs + b) * p.ld_hlp;
       if (tid < (H >> 3)) *reinterpret_cast<bf16x8*>(Lt + tid * 8) = *reinterpret_cast<const bf16x8*>(hl + tid * 8);
+      if (p.Xcat && tid < (H >> 3)) *reinterpret_cast<bf16x8*>(p.Xcat + ((size_t)t * Bs + b) * p.ld_xcat + tid * 8) = *reinterpret_cast<const bf16x8*>(hl + tid * 8);
       for (int j = H + tid; j < p.ld_hlp; j += 256) Lt[j] = (bf16_t)0.f;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -410,6 +413,17 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   if (p.mp && isB) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) { const int uu = tid + 256 * jj; if (uu < H) p.mp[(size_t)b * H + uu] = hs_sum[jj] * p.mp_scale; }
+    if (p.Xcat) {       // the mean-pooled half of the reconstructor's input, one dropout mask per step
+      const uint32_t key = drop_key(p.xdd);
+      for (int t = 0; t < p.T; ++t) {
+        bf16_t* x = p.Xcat + ((size_t)t * Bs + b) * p.ld_xcat + H;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int uu = tid + 256 * jj;
+          if (uu < H) x[uu] = (bf16_t)(hs_sum[jj] * p.mp_scale * drop_at(p.xdd, key, t, b, H, uu));
+        }
+      }
+    }
   }
   rc_epoch_bump(p.epoch, ep0);
   rc_poison(p.bar, p.poison);

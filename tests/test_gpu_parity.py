@@ -423,6 +423,13 @@ def test_local_backward_chain_with_k_split_forced(case, monkeypatch):
     test_fused_step_vs_oracle_edge_shapes(case, "local", "bf16")
 
 
+@pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 37, 256)])
+def test_reconstructor_input_written_by_the_decoder_chain_equals_the_separate_kernel(cell, B, R, monkeypatch):
+    """dec_chain_kernel writes the global reconstructor's LSTM input [h_t ; drop_t(mp)] (global_reconstructor.py:38-41) itself
+    (RN_DEC_XCAT=0: xcat_global_kernel behind the chain)."""
+    _chain_variants({"RN_DEC_XCAT": "0"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
+
+
 @pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 100, 1536), ("LSTM", 57, 1040), ("LSTM", 112, 2048)])
 def test_output_layer_epilogue_of_the_forward_chain_equals_the_separate_kernels(cell, B, R, monkeypatch):
     """rec_chain_kernel's epilogue (out = mean_t h_t . W_o^T + b_o, squared-error partial sums, d out and its operand copy behind one more
