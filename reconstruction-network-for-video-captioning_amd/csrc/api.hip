@@ -82,6 +82,7 @@ struct recnet_handle {
   float *Ud, *beta, *Whr, *outl, *dHr, *dUd, *dwacc_r;
   void* Hr_pan = nullptr;
   void* hm_pan = nullptr;   // exchange copy of mean_t hr_t (rec_chain_kernel's output-layer epilogue)
+  void* hd_pan = nullptr; void* WoT = nullptr; int dhr_done = 0;   // ... of the scaled dout; W_o^T image; dhrmean computed by the epilogue
   // backward chain for R > 2048 (loc_big.hpp): K partials, per-step masked dx / dbeta for the post-chain sums, streamed fragments of W^T
   float *lb_part = nullptr, *lb_dxm = nullptr, *lb_dbeta = nullptr; void* WstT = nullptr; int persist_big_bwd = 0, lb_steps = 0, lb_sr = 0, lb_ncb = 0;
   void* Wst = nullptr; int lc_steps = 0, lc_sr = 0;   // hybrid forward chain (R > 2048): streamed fragments image, k-steps per wave / resident
@@ -232,6 +233,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->Xcat_g = takev(Tm * B * (size_t)h->ld2H); h->Hr_lp = takev(Tm * B * ldR); h->hrmean_lp = takev(B * ldR);
     h->Hr_pan = takev(Tm * rc_pan_elems((int)R) / 2 + 64);       // bf16: k-group-major copies of h_t for rec_chain_kernel
     h->hm_pan = takev(rc_pan_elems((int)R) / 2 + 64);
+    h->hd_pan = takev(rc_pan_elems((int)R) / 2 + 64); h->WoT = takev(R * (size_t)h->ldR);
     h->dG_pan = takev(Tm * rc_pan_elems((int)(4 * R)) / 2 + 64);
     h->WhhT = takev(R * (size_t)h->ld4R);
     h->dout_lp = takev(B * ldR); h->dGr = takev(Tm * B * ld4R);

@@ -43,6 +43,10 @@ struct RecChainArgs {
   bf16_t* PanM;                   // [R/8][RC_PAN_ROWS][8] exchange copy of mean_t h_t
   float* mse_part;                // [workers] partial sums of d^2
   float gcoef, lp_scale;
+  // epi = 2: ... and, behind one more barrier phase, d loss / d mean_t h_t = dout . W_o  (what the backward chain starts from)
+  const bf16_t* WoT; int ldwot;   // [R][ldwot] W_o^T (row = hidden unit, output column contiguous)
+  bf16_t* PanD;                   // [R/8][RC_PAN_ROWS][8] exchange copy of the scaled dout
+  float* dhr;                     // [B][R]
 };
 
 #define RC_MB 7               // 16-row blocks: B <= 112
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
   const int nwx = (int)gridDim.x - (p.master ? 1 : 0), widx = blockIdx.y * nwx + blockIdx.x;   // workers per row, my flag
   if (p.master && (int)blockIdx.x == nwx) {
-    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1 + (p.epi ? 1 : 0));
+    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1 + p.epi);
     return;
   }
   const int rot = blockIdx.x % NP;                       // workgroups start at different k: spreads the L2 channels
@@ -474,6 +478,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     }
     __syncthreads();
     float sq = 0.f;
+    bf16_t gl[CPT];                       // this thread's cells of the scaled dout (operand copy)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int cell = tid + c * 256;
@@ -481,12 +486,14 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
       float v = ob[c];
 #pragma unroll
       for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + rowl * RED_LD + ul];
+      gl[c] = (bf16_t)0.f;
       if (mine[c]) {
         const float d = v - tg[c], g = p.gcoef * d;
         sq += d * d;
         const size_t o = (size_t)(r0 + rowl) * R + u0 + ul;
         p.dout[o] = g;
-        p.dout_lp[o] = (bf16_t)(p.lp_scale * g);
+        gl[c] = (bf16_t)(p.lp_scale * g);
+        p.dout_lp[o] = gl[c];
       }
     }
     __syncthreads();
@@ -494,6 +501,78 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     if (lane == 0) red[wave] = sq;
     __syncthreads();
     if (tid == 0) p.mse_part[widx] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (p.epi > 1) {
+      // ---- d loss / d mean_t h_t = dout . W_o: publish this workgroup's 16 columns of dout like a step, then the product over
+      // ALL output columns against the W_o^T rows of its 16 hidden units
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int cell = tid + c * 256;
+        if (cell < ROWS * UW) hl[cell] = gl[c];
+      }
+      __syncthreads();
+      {
+        const int it_j = tid / own, it_rg = own_lo + tid % own;
+        if (tid < KG * own && it_rg < B)
+          rc_store16(p.PanD + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, hl + (it_rg - r0) * UW + it_j * 8);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      rc_arrive_at(p.bar, widx, fb + (unsigned)p.T + 1u);
+      bf16x8 wt[STEPS];
+      {
+        const bf16_t* wrow = p.WoT + (size_t)(u0 + (lane & 15)) * p.ldwot + kq;
+#pragma unroll
+        for (int ks = 0; ks < STEPS; ++ks) {
+          const int k = kw0 + ks * 32;
+          wt[ks] = (k + kq < R) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+      }
+      rc_wait_release(p.bar + 256, fb + (unsigned)p.T + 1u);
+      {
+        const bf16_t* A = p.PanD + lane_off;
+        f32x4 acc[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int FB = STEPS <= 12 ? STEPS : 8, NFB = (STEPS + FB - 1) / FB;
+        bf16x8 fa[FB][RB];
+#pragma unroll
+        for (int b4 = 0; b4 < NFB; ++b4) {
+#pragma unroll
+          for (int j = 0; j < FB; ++j) {
+            const int ks = b4 * FB + j;
+            if (ks < STEPS) {
+              const int k = kw0 + ks * 32;
+#pragma unroll
+              for (int i = 0; i < RB; ++i) fa[j][i] = *reinterpret_cast<const bf16x8*>(A + ((k < R ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < FB; ++j) {
+            const int ks = b4 * FB + j;
+            if (ks < STEPS) {
+#pragma unroll
+              for (int i = 0; i < RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][i], wt[ks], acc[i], 0, 0, 0);
+            }
+          }
+        }
+        float* part = red + wave * (ROWS * RED_LD);
+        const int rr = (lane >> 4) * 4, cc = lane & 15;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + cc] = acc[i][r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int cell = tid + c * 256;
+        const int rowl = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + rowl * RED_LD + ul];
+        if (mine[c]) p.dhr[(size_t)(r0 + rowl) * R + u0 + ul] = v;
+      }
+    }
   }
   rc_epoch_bump(p.epoch, ep);
   rc_poison(p.bar, p.poison);
