@@ -127,10 +127,9 @@ def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
             meas.append((n_, ms_, s_id, wh, nm))
     if not meas:
         return None
-    # the kernels of the benchmark shape are within a few percent of each other: the first in the list above that is
-    # within 5 % of the largest time per step is reported, so that the choice does not flip from run to run
-    top = max(m[0] * m[1] for m in meas)
-    n, ms_raw, site, which, kname = next(m for m in meas if m[0] * m[1] >= 0.95 * top)
+    ranked = sorted(meas, key=lambda m: -m[0] * m[1])
+    n, ms_raw, site, which, kname = ranked[0]                 # the true maximum; the runner-up is listed beside it
+    runner_up = ranked[1][4].split(" (")[0] if len(ranked) > 1 else None
     # What the two event records add to a bracket (E), from brackets around 1 and around 17 empty kernels in the same
     # mode (graph nodes / eager): b(c) = E + c * f.  The kernel's dispatch-to-completion time — what rocprofv3 reports as
     # its duration — is its bracket minus E.
@@ -146,10 +145,36 @@ def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
     traffic, traffic_src = stored_traffic(kname.split(" (")[0], kind, eng.dims, T, cell) if precision == "bf16" else (None, None)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": kname, "launches_per_step": n, "us_per_step": round(n * ms * 1e3, 1), "exchange_bytes_per_launch": int(exchange),
+            "kernel": kname, "runner_up": runner_up, "launches_per_step": n, "us_per_step": round(n * ms * 1e3, 1), "exchange_bytes_per_launch": int(exchange),
             "avg_launch_us": round(ms * 1e3, 3), "bracket_us": round(ms_raw * 1e3, 3),
             "event_pair_overhead_us": round(ms_null * 1e3, 3), "empty_kernel_us": round(f_empty * 1e3, 3), "algorithmic_bytes_per_launch": int(bytes_launch),
             "chain_kernel_brackets_us": chains, "recurrent_kernels": per_step}
+
+
+def phase_table(eng, run, replays=12):
+    """Untraced decomposition of the replayed step: the chain kernels stamp the 100 MHz wall clock when their first workgroup
+    starts and when it leaves, the step's first / last kernels stamp its start / end (Engine.read_stamps) — medians over
+    `replays` replays, microseconds.  prologue = start -> first chain; gaps = between consecutive chains; tail = last chain ->
+    end of the step's last kernel; between_steps = ms_per_step - span (graph launch + the ungraphed part of the replay)."""
+    import statistics
+    rows = []
+    for _ in range(replays):
+        run()
+        rows.append(eng.read_stamps())
+    rows = [r for r in rows if r["end"] and r["chains"]]
+    if not rows:
+        return None
+    order = sorted(rows[0]["chains"], key=lambda k: rows[0]["chains"][k][0])
+    med = lambda xs: round(statistics.median(xs), 1)
+    out = {"prologue_us": med([r["chains"][order[0]][0] for r in rows])}
+    for i, nm in enumerate(order):
+        out["chain_%s_us" % nm] = med([r["chains"][nm][1] - r["chains"][nm][0] for r in rows])
+        if i + 1 < len(order):
+            out["gap_%s_to_%s_us" % (nm, order[i + 1])] = med([r["chains"][order[i + 1]][0] - r["chains"][nm][1] for r in rows])
+    out["tail_us"] = med([r["end"] - r["chains"][order[-1]][1] for r in rows])
+    out["span_us"] = med([r["end"] for r in rows])
+    out["outside_chains_us"] = round(out["span_us"] - sum(v for k, v in out.items() if k.startswith("chain_")), 1)
+    return out
 
 
 def fp32_exact(R, cfg_over, V, enc, targets, targets_g, B, F, steps=10, warmup=3):
@@ -308,6 +333,11 @@ def main():
             # (never the data-parallel step itself: this runs on rank 0 only, a collective here would wait for ever)
             n_, ms_ = eng.profile_site(s_id, one, 5)
             return (n_ // 5 if site > 0 else n_), ms_
+        phases = None
+        if not step.reduce and not args.feed:
+            phases = phase_table(eng, runner)
+            if phases:
+                phases["between_steps_us"] = round(ms * 1e3 - phases["span_us"], 1)
         prof = roofline(eng, prof_pass, kind, args.precision, T=T, cell=args.cell)
         # whole-step roofline fractions: algorithmic FLOPs against the dense bf16 MFMA peak and
         # algorithmic HBM bytes (optimiser + inputs) against 8 TB/s; per GPU (every rank does the same work)
@@ -327,7 +357,7 @@ def main():
                                    "D=R=%d, V=4188, E=468, H=512, A=128, T=%d, dropout 0.5, %s cells" % (args.rec, hi - lo, F, D, T, args.cell),
                        "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "deferred_reconstructor_update": bool(graphed is not None and graphed.deferred), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
                        "loss": round(sc["total_loss"], 5)},
-            "roofline": prof, "whole_step": whole,
+            "roofline": prof, "whole_step": whole, "phases": phases,
         }
         if not args.no_fp32_exact and world == 1 and args.precision == "bf16" and not args.feed:
             out["fp32_exact"] = fp32_exact(R, cfg_over, V, enc, targets, targets_g, B, F)

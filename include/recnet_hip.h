@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RECNET_ABI_VERSION 5
+#define RECNET_ABI_VERSION 6
 #define RECNET_ATTN_NONE 0
 #define RECNET_ATTN_SOFTMAX 1
 #define RECNET_OK 0
@@ -289,6 +289,15 @@ int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms);
 /* Same read-out without leaving profiling mode: when the bracketed launches were captured into a hipGraph (the event
  * records become graph nodes), call this after each replay — the durations are then those of the replayed graph. */
 int recnet_profile_read(recnet_handle* h, int32_t* n_launches, double* total_ms);
+/* Phase stamps of the LAST train step, written by the step's own kernels (no tracer, no extra launch, also in a replayed
+ * hipGraph): 14 values of the device's 100 MHz wall clock (10 ns units) —
+ *   [0] step start (the step-counter kernel of recnet_train_step[_fwd_bwd]_dev)
+ *   [1 + 2k], [2 + 2k] workgroup 0 of chain kernel k started running / left, k = 0 decoder forward chain, 1 decoder BPTT chain,
+ *                      2 global reconstructor forward, 3 global reconstructor backward, 4 local reconstructor forward, 5 local backward
+ *                      (the last launch of that chain; a chain that did not run keeps its old stamps)
+ *   [13] step end (the kernel that exports the step's scalars).
+ * Synchronises `stream`.  train.py:248-273 is the span between [0] and [13]. */
+int recnet_read_stamps(recnet_handle* h, uint64_t* out, int32_t n, void* stream);
 /* Calibration of the bracket itself: `count` launches of an empty kernel bracketed by the same two event records (call
  * between recnet_profile_begin and _read/_end, in the same eager / captured mode as the measurement).  bracket(count) =
  * E + count * f: E is what the two event records add to every bracketed duration, f the dispatch-to-completion time of

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RN_LIB_PROBE=1: the probe build (in-kernel time stamps); RN_LIB_VARIANT=acqinv: the cross-check build with acquire fences
 _VARIANT = "_probe" if os.environ.get("RN_LIB_PROBE") == "1" else ("_" + os.environ["RN_LIB_VARIANT"] if os.environ.get("RN_LIB_VARIANT") else "")
 LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip%s.so" % _VARIANT)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 REC_NONE, REC_GLOBAL, REC_LOCAL = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
@@ -132,6 +132,7 @@ EXPORTS["recnet_profile_begin"] = (_i, [C.c_void_p, _i])
 EXPORTS["recnet_profile_end"] = (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_d)])
 EXPORTS["recnet_profile_read"] = (_i, [C.c_void_p, C.POINTER(_i), C.POINTER(_d)])
 EXPORTS["recnet_profile_null_launch"] = (_i, [C.c_void_p, _i, C.c_void_p])
+EXPORTS["recnet_read_stamps"] = (_i, [C.c_void_p, C.POINTER(C.c_uint64), _i, C.c_void_p])
 EXPORTS["recnet_gemm_bf16"] = (_i, [C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _f, _i, _i,
                                   C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_train_step_part_dev"] = (_i, [C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, C.c_void_p, C.c_uint32,

@@ -14,6 +14,7 @@ __global__ void set_f32_kernel(float* p, float v) { *p = v; }
 // step counter += 1; seed slot = seed_base + step (graph-replay friendly train step)
 __global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t seed_base) {
   int s = *step + 1; *step = s; *seed_slot = seed_base + (uint32_t)s;
+  reinterpret_cast<unsigned long long*>(seed_slot + 32)[0] = wall_clock64();      // phase stamp: step start (recnet_read_stamps)
 }
 
 // sum_{z<n} p[z*stride] over the split-K slabs.  All (<= 16) loads are issued back to back and reduced as a

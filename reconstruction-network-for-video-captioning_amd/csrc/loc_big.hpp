@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void lcbig_bwd_kernel(const LocBigBwdArgs p) {
   }
   // everybody has passed the last barrier (and read the epoch long ago)
   if (relay && tid == 0) {
-    __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rc_stamp_slot(p.epoch)[1] = wall_clock64();
     if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
   }
 }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       }
       lc_poll(p.bar, p.NU + p.NC, fb + (unsigned)(F + 1), p.bar, spin);      // everybody is done (and has read the epoch)
       if (tid == 0) {
-        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rc_stamp_slot(p.epoch)[1] = wall_clock64();
         if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
       }
     }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
       unsigned spin = 0;
       lc_poll(p.bar, p.NU + p.NC, fb + (unsigned)(F + 1), p.bar, spin);
       if (tid == 0) {
-        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rc_stamp_slot(p.epoch)[1] = wall_clock64();
         if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
       }
     }
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void loc_chain_bwd_kernel(const LocChainBwdArg
       }
       lc_poll(p.bar, NU + NX + p.NC, fb + (unsigned)(F + 1), p.bar, spin);
       if (tid == 0) {
-        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.epoch, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rc_stamp_slot(p.epoch)[1] = wall_clock64();
         if (__hip_atomic_load(p.bar + 257, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *p.poison = __builtin_nanf("");
       }
     }

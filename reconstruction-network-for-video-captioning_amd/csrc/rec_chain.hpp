@@ -81,9 +81,23 @@ __host__ __device__ inline size_t rc_pan_elems(int K) { return (size_t)(((K + 31
 // workgroup 0 at the end (a workgroup that has passed a barrier knows every other one has started).  Barrier flags are
 // epoch << 7 | phase and stamped words carry epoch << 6 | step, so neither needs clearing between launches — in a replayed
 // hipGraph each clearing memset was a 6 us node on the critical path.
-__device__ __forceinline__ unsigned rc_epoch_read(const unsigned* epoch) { return __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Phase stamps (recnet_read_stamps): the launch-epoch words of the six chain kernels are consecutive words at the start of a
+// 256-byte line; the line behind it holds one pair of 100 MHz wall-clock stamps per chain — written by workgroup 0 when it starts
+// running and when it leaves — so that a REPLAYED hipGraph, which no tracer has to be attached to, reports where its step went
+// (prologue / chains / gaps / tail) at the cost of two 8-byte stores per launch.
+__device__ __forceinline__ unsigned long long* rc_stamp_slot(const unsigned* epoch) {
+  const unsigned long long a = (unsigned long long)epoch;
+  return reinterpret_cast<unsigned long long*>((a & ~255ull) + 256ull) + 2 * ((a >> 2) & 7ull);
+}
+__device__ __forceinline__ unsigned rc_epoch_read(const unsigned* epoch) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rc_stamp_slot(epoch)[0] = wall_clock64();
+  return __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void rc_epoch_bump(unsigned* epoch, unsigned e) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) __hip_atomic_store(epoch, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(epoch, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rc_stamp_slot(epoch)[1] = wall_clock64();
+  }
 }
 // Every wait in the chain kernels is bounded: a launch whose workgroups are not all resident (two such launches sharing
 // the GPU) would otherwise spin forever and take the device with it.  After ~2^22 polls (seconds) a waiter raises the
@@ -92,11 +106,11 @@ __device__ __forceinline__ void rc_epoch_bump(unsigned* epoch, unsigned e) {
 #define RC_SPIN_LIMIT (1u << 22)
 // 16 bytes per lane, written through to the agent's coherence point: the instruction an agent-scope relaxed atomic store compiles
 // to (global_store_dwordx2 ... sc1), in its 16-byte form — one request per lane instead of two
-// (the s_nop is the wait state a VMEM store of more than 8 bytes needs before a VALU instruction may overwrite its data registers:
-// the compiler's hazard recognizer inserts it behind its own stores and does not look inside inline asm — without it the next
-// loop iteration's adds corrupted the stored values)
+// (the s_nop 1 = the TWO wait states a VMEM store of more than 8 bytes needs before a VALU instruction may overwrite its data
+// registers: the compiler's hazard recognizer inserts `s_nop 1` behind its own dwordx4 stores and does not look inside inline asm —
+// without it the next loop iteration's adds corrupted the stored values; `s_nop 0` was one state short)
 __device__ __forceinline__ void rc_store16f(float* dst, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(dst), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void rc_store16(bf16_t* dst, const bf16_t* src) {
   rc_store16f(reinterpret_cast<float*>(dst), *reinterpret_cast<const f32x4*>(src));

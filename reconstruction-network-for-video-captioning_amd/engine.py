@@ -469,6 +469,21 @@ class Engine:
     def profile_null_launch(self, count=1):
         _lib.check(self.lib.recnet_profile_null_launch(self.handle, int(count), _stream()), "recnet_profile_null_launch")
 
+    def read_stamps(self):
+        """Phase stamps of the last train step (recnet_read_stamps): dict of microsecond offsets from the step's start —
+        `chains[name] = (begin, end)` for the chain kernels that ran inside it, `end` = the step's last kernel.  Written by the
+        step's own kernels, so it describes a REPLAYED graph with no tracer attached.  Synchronises."""
+        buf = (C.c_uint64 * 14)()
+        _lib.check(self.lib.recnet_read_stamps(self.handle, buf, 14, _stream()), "recnet_read_stamps")
+        t0, t1 = buf[0], buf[13]
+        names = ("decoder_forward", "decoder_bptt", "global_forward", "global_backward", "local_forward", "local_backward")
+        chains = {}
+        for k, nm in enumerate(names):
+            b, e = buf[1 + 2 * k], buf[2 + 2 * k]
+            if t0 <= b <= e <= t1:                       # ran inside this step
+                chains[nm] = ((b - t0) / 100.0, (e - t0) / 100.0)
+        return {"end": (t1 - t0) / 100.0 if t1 >= t0 else None, "chains": chains}
+
     def recurrent_step_bytes(self, which):
         return float(self.lib.recnet_recurrent_step_bytes(self.handle, int(which)))
 

@@ -127,7 +127,7 @@ class Decoder(nn.Module, _Generation):
         # by the caching allocator) and its in-place version counter — never on data_ptr alone.
         enc = encoder_outputs.contiguous()
         pver = self.weights_signature()
-        sig = (enc._version, tuple(enc.shape), pver)
+        sig = (encoder_outputs._version, tuple(enc.shape), pver)      # the CALLER's tensor: a .contiguous() copy always reads version 0
         fresh = getattr(eng, "_inv_ref", None) is not encoder_outputs or getattr(eng, "_inv_sig", None) != sig
         eng._inv_ref = encoder_outputs
         if fresh:
@@ -181,7 +181,7 @@ class _Reconstructor(nn.Module, _Generation):
         # — keyed on the tensor OBJECT (a reference is kept, so the caching allocator cannot hand its address to the
         # next batch's hiddens) and its in-place version counter, never on data_ptr alone.
         dh = decoder_hiddens.contiguous()
-        sig = (dh._version, tuple(dh.shape), pver)
+        sig = (decoder_hiddens._version, tuple(dh.shape), pver)      # the CALLER's tensor: a .contiguous() copy always reads version 0
         fresh = getattr(eng, "_inv_ref", None) is not decoder_hiddens or getattr(eng, "_inv_sig", None) != sig
         eng._inv_ref = decoder_hiddens
         eng._inv_sig = sig
