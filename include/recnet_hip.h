@@ -313,6 +313,14 @@ int recnet_gemm(int32_t precision, const float* A, int32_t a_col, int32_t lda, c
 int recnet_gemm_bf16(const void* A, int32_t a_col, int32_t lda, const void* B, int32_t b_col, int32_t ldb, float* C,
                      int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
                      int32_t splitk, float* splitk_ws, int32_t tag, void* stream);
+/* Grouped form: the tiles of n <= 8 products of one operand layout in ONE launch (csrc/gemm_lds.hpp: gemm_group_kernel); a
+ * product the scheduler splits along K is summed inside the launch by its last-arriving slice.  Arrays of n entries; splitk_ws:
+ * fp32 slabs (may be null: no splitting), counters: zero-initialised words the launch leaves zeroed (null: no splitting).
+ * The batched products of train.py:258-273 (the decoder's and reconstructor's weight gradients) are issued this way. */
+int recnet_gemm_group_bf16(int32_t a_col, int32_t b_col, int32_t n, const void* const* A, const int32_t* lda, const void* const* B,
+                           const int32_t* ldb, float* const* C, const int32_t* ldc, const float* const* bias, const int32_t* M,
+                           const int32_t* N, const int32_t* K, const float* alpha, const int32_t* accumulate, float* splitk_ws,
+                           int64_t ws_floats, uint32_t* counters, int32_t n_counters, void* stream);
 /* Probe builds only (csrc: make probe): in-kernel wall-clock stamps of the local chain kernels' last launch,
  * [role][step][8] uint64 ticks; RECNET_ESTATE in the product build. */
 int recnet_probe_read(recnet_handle* h, uint64_t* out, int32_t n);

@@ -50,6 +50,7 @@ struct OptGroup {
 };
 
 static inline int pad8(int n) { return (n + 7) & ~7; }
+#define RN_GCNT_WORDS 16384     // output tiles of the split members of one grouped launch
 #define RN_MAX_ROW_GROUPS 4      // persistent chains up to 4 x 112 = 448 captions per GPU
 
 struct recnet_handle {
@@ -128,6 +129,9 @@ struct recnet_handle {
   int free_fwd = 0;
   size_t gws_floats, slab_floats;
   float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
+  unsigned* gcnt = nullptr;      // tile counters of the grouped launches' in-launch split-K sums: one block of RN_GCNT_WORDS per slab workspace
+  int gg_slots = 0;              // workgroup slots the next grouped launches can expect (0 = whole chip): see host_common.inc
+  int gemm_single_group = 0;     // RN_GEMM_SINGLE=0: single products take gemm_lds_kernel + splitk_reduce_kernel (round-3 form)
   hipStream_t s2 = nullptr; hipEvent_t ev[16] = {}; int overlap = 1;
   // bindings
   recnet_decoder_tensors dP{}, dGd{}, dM{}, dV{}, dVm{};
@@ -210,6 +214,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->gws = take(h->gws_floats);
   h->gws2 = take(h->gws_floats);
   h->gws3 = take(h->gws_floats);
+  h->gcnt = (unsigned*)take(3 * RN_GCNT_WORDS);      // zero from the workspace memset; every launch leaves its counters zeroed
   {
     const size_t W = 8;
     h->sr_logits = take(B * V); h->sr_scores = take(W * B * V);
@@ -328,6 +333,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
   h->lazy_images = getenv("RN_LAZY_IMAGES") ? atoi(getenv("RN_LAZY_IMAGES")) : 1;
+  h->gemm_single_group = getenv("RN_GEMM_SINGLE") ? atoi(getenv("RN_GEMM_SINGLE")) : 0;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
   // equal size (at most RN_MAX_ROW_GROUPS of them) and every chain runs once per group, one launch after the other: a group is

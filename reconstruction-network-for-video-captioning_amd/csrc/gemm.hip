@@ -107,7 +107,7 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
                     int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag, int c_bf16, void* c2, int ldc2) {
   if (M <= 0 || N <= 0) return;
   GemmArgs a;
-  a.c_bf16 = c_bf16; a.C2 = c2; a.ldc2 = ldc2;
+  a.c_bf16 = c_bf16; a.C2 = c2; a.ldc2 = ldc2; a.cnt = nullptr;
   if (c_bf16 || c2) splitk = 1;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -181,4 +181,102 @@ int rn_effective_splitk(int prec, int K, int splitk) {
   if (splitk > nkt) splitk = nkt;
   int per = (nkt + splitk - 1) / splitk;
   return (nkt + per - 1) / per;
+}
+
+// ---------------------------------------------------------------------------------------------- grouped launch
+#include <algorithm>
+#include <queue>
+#include <vector>
+namespace {
+template <bool ACOL, bool BCOL>
+void launch_group_one(const GemmGroupArgs& g, int nblocks, hipStream_t st) {
+  static bool attr_done = false;
+  auto fn = gemm_group_kernel<ACOL, BCOL, 2>;
+  if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GL_STAGE_BYTES); attr_done = true; }
+  hipLaunchKernelGGL(fn, dim3(nblocks), dim3(256), 2 * GL_STAGE_BYTES, st, g);
+}
+// finish time of greedy list scheduling (items in the given order, each to the slot that frees up first) on `slots` slots:
+// what the hardware dispatcher does with the grid
+double list_makespan(const std::vector<std::pair<double, int>>& runs, int slots) {      // (length, count), queue order
+  std::priority_queue<double, std::vector<double>, std::greater<double>> q;
+  for (int i = 0; i < slots; ++i) q.push(0.0);
+  double end = 0.0;
+  for (auto& r : runs)
+    for (int c = 0; c < r.second; ++c) { double t = q.top(); q.pop(); t += r.first; q.push(t); if (t > end) end = t; }
+  return end;
+}
+}  // namespace
+
+int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float* ws, size_t ws_floats, unsigned* cnt, int cnt_words,
+                         hipStream_t st, int slots_hint) {
+  static const int on = getenv("RN_GEMM_GROUP") ? atoi(getenv("RN_GEMM_GROUP")) : 1;
+  if (!on || n < 1 || n > GG_MAX) return 1;
+  struct Prob { int idx, tiles, nkt, s; };
+  std::vector<Prob> pr;
+  for (int i = 0; i < n; ++i) {
+    if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0) continue;
+    if (!vec_ok(d[i].A, d[i].lda, 2) || !vec_ok(d[i].B, d[i].ldb, 2)) return 1;
+    Prob q; q.idx = i; q.s = 1; q.nkt = (d[i].K + 63) / 64;
+    q.tiles = ((d[i].M + GEMM_TILE - 1) / GEMM_TILE) * ((d[i].N + GEMM_TILE - 1) / GEMM_TILE);
+    pr.push_back(q);
+  }
+  if (pr.empty()) return 0;
+  // split factors: coordinate descent on the estimated finish time (k-tile units; every item pays ~3 units of pipeline fill
+  // and epilogue, a split product's slabs ~1 unit per slice more for the slice that sums them), 2 workgroups per CU
+  static int slots_all = 0;
+  if (!slots_all) { int dev = 0, ncu = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); slots_all = 2 * (ncu > 0 ? ncu : 256); }
+  const int slots = slots_hint > 0 ? slots_hint : slots_all;
+  auto per_slice = [](const Prob& q) { const int per = (q.nkt + q.s - 1) / q.s; return per; };
+  auto estimate = [&]() {
+    std::vector<std::pair<double, int>> runs;
+    std::vector<const Prob*> o;
+    for (auto& q : pr) o.push_back(&q);
+    std::sort(o.begin(), o.end(), [&](const Prob* a, const Prob* b) { return per_slice(*a) > per_slice(*b); });
+    for (auto* q : o) {
+      const int per = per_slice(*q), s_eff = (q->nkt + per - 1) / per;
+      runs.push_back({per + 3.0 + (s_eff > 1 ? 0.5 * s_eff : 0.0), q->tiles * s_eff});
+    }
+    return list_makespan(runs, slots);
+  };
+  const bool can_split = ws && cnt;
+  for (int iter = 0; iter < 32 && can_split; ++iter) {
+    const double base = estimate();
+    int best = -1; double best_t = base * 0.97;      // a split has to pay for its slabs
+    for (size_t i = 0; i < pr.size(); ++i) {
+      Prob& q = pr[i];
+      if (d[q.idx].c2 || (d[q.idx].N & 3) || q.s >= 16 || q.nkt / (q.s + 1) < 4) continue;
+      const int keep = q.s;
+      q.s = keep + 1;
+      const double t = estimate();
+      q.s = keep;
+      if (t < best_t) { best_t = t; best = (int)i; }
+    }
+    if (best < 0) break;
+    pr[best].s += 1;
+  }
+  std::sort(pr.begin(), pr.end(), [&](const Prob& a, const Prob& b) { return per_slice(a) > per_slice(b); });
+  GemmGroupArgs g;
+  g.np = (int)pr.size();
+  int blocks = 0; size_t ws_off = 0; int cnt_off = 0;
+  for (int k = 0; k < g.np; ++k) {
+    const RnGemmDesc& e = d[pr[k].idx];
+    GemmArgs& a = g.p[k];
+    a.A = e.A; a.B = e.B; a.C = e.C; a.bias = e.bias; a.M = e.M; a.N = e.N; a.K = e.K; a.lda = e.lda; a.ldb = e.ldb; a.ldc = e.ldc;
+    a.alpha = e.alpha; a.accumulate = e.accumulate; a.c_bf16 = e.c_bf16; a.C2 = e.c2; a.ldc2 = e.ldc2; a.a_vec = 1; a.b_vec = 1;
+    const int per = per_slice(pr[k]);
+    int s = (pr[k].nkt + per - 1) / per;
+    const size_t slab = (size_t)e.M * e.N;
+    if (s > 1 && (ws_off + (size_t)s * slab > ws_floats || cnt_off + pr[k].tiles > cnt_words || (size_t)s * slab * 4 >= ((size_t)1 << 31))) s = 1;
+    a.splitk = s; a.kchunk = (s > 1 ? per : pr[k].nkt) * 64;
+    a.ws = nullptr; a.cnt = nullptr;
+    if (s > 1) { a.ws = ws + ws_off; a.cnt = cnt + cnt_off; ws_off += (size_t)s * slab; cnt_off += pr[k].tiles; }
+    g.first[k] = blocks;
+    blocks += pr[k].tiles * s;
+  }
+  for (int k = g.np; k <= GG_MAX; ++k) g.first[k] = blocks;
+  if (!a_col && !b_col) launch_group_one<false, false>(g, blocks, st);
+  else if (!a_col && b_col) launch_group_one<false, true>(g, blocks, st);
+  else if (a_col && !b_col) launch_group_one<true, false>(g, blocks, st);
+  else launch_group_one<true, true>(g, blocks, st);
+  return 0;
 }

@@ -24,6 +24,8 @@ struct GemmArgs {
   int a_vec, b_vec;           // 16-byte vector loads are legal for this operand (alignment checked on host)
   int c_bf16;                 // direct epilogue stores bf16 into C (reinterpreted); requires splitk == 1
   void* C2; int ldc2;         // optional second, bf16 copy of the fp32 result (direct epilogue of gemm_lds only)
+  unsigned* cnt;              // grouped launches (gemm_group_kernel) with splitk > 1: one arrival counter per output tile —
+                              // the slice that arrives last sums the slabs and runs the epilogue (no reduction launch)
 };
 
 template <typename CT> struct GemmCfg;

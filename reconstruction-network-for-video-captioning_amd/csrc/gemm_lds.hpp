@@ -17,8 +17,12 @@
 // between the logical extent and its multiple of 8.
 #pragma once
 #include "gemm.hpp"
+#include <type_traits>
 
 #define GL_STAGE_BYTES 32768   // A image 16 KiB + B image 16 KiB
+#ifndef RC_ACQUIRE_INV
+#define RC_ACQUIRE_INV 0       // 1: cross-check build with the conventional acquire fences (rec_chain.hpp; Makefile: acqinv)
+#endif
 
 __device__ __forceinline__ int gl_col_swz(int k) { return ((k & 3) << 1) | (k & 8); }
 
@@ -104,16 +108,16 @@ __device__ __forceinline__ bf16x8 gl_frag(const char* img, int row /*first of th
 
 // BN = columns per workgroup: 128, or 96 (row/row form only) — N = 6144 with 4 K slices is 192 workgroups of 128
 // columns but 256 of 96, one per CU, each with a quarter less weight data and MFMA work on the chain's critical path.
-template <bool ACOL, bool BCOL, int NS, int TAG, int BN = 128>
-__global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
+// One output tile (bx, by) of K slice z.  FIX: the launch is a grouped one (gemm_group_kernel) and a split product is finished
+// inside it — see the fix-up block of the epilogue.
+template <bool ACOL, bool BCOL, int NS, int BN, bool FIX, typename ArgsT>
+__device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, const int by, const int z, char* gl_smem) {
   static_assert(BN == 128 || (BN == 96 && !BCOL), "96-column tiles: row-layout weights only");
-  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
   constexpr int NPB = BN / 32;                 // DMA pieces per wave of the B tile = 16-column groups per wave
   constexpr int STAGE = 16384 + BN * 128;      // A image 16 KiB + B image
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
-  const int m0 = blockIdx.y * GEMM_TILE, n0 = blockIdx.x * BN;
-  const int z = blockIdx.z;
+  const int m0 = by * GEMM_TILE, n0 = bx * BN;
   const int kbeg = z * p.kchunk;
   int kend = kbeg + p.kchunk;
   if (kend > p.K) kend = p.K;
@@ -184,6 +188,105 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
   const int ldc = to_slab ? p.N : p.ldc;
   const bool vec4 = ((ldc & 3) == 0) && ((((uintptr_t)Cb) & 15) == 0) && !p.c_bf16 &&
                     (!p.C2 || (((p.ldc2 & 3) == 0) && ((((uintptr_t)p.C2) & 7) == 0)));
+  if (FIX && to_slab && p.cnt) {
+    // ---- split product finished inside the launch.  Every slice writes its fp32 partial tile THROUGH to memory (sc1 16-byte
+    // stores: no release fence, nothing else of the L2 is written back), waits for the stores, and takes a ticket on the
+    // tile's counter; the slice that draws the last ticket reads all slabs back in slice order (sc1 loads: served by L2 /
+    // memory, never by this CU's L1) and runs the epilogue.  Slab addresses are written once and read once per launch, and
+    // the kernel boundary in front of the launch has dropped whatever an L2 held of them — the same argument as for the
+    // exchange panels of the chain kernels (rec_chain.hpp); RC_ACQUIRE_INV builds add the conventional acquire fence.
+    // The sum runs in slice order whoever arrives last: results do not depend on the schedule.  The host splits only products
+    // with N % 4 == 0 (every slab access is a whole 16-byte quad).
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, 0x7ffffffc, 0x00020000);
+    const unsigned slab_b = (unsigned)p.M * (unsigned)p.N * 4u;          // bytes of one slab (the host keeps splitk * slab_b < 2 GiB)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < NPB; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[(ii * 16 + cr + r) * 68 + j * 16 + cc] = acc[half * 2 + ii][j][r];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rl = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 68 + c4);
+        const int row = m0 + wm + half * 32 + rl, col = n0 + wn + c4;
+        if (row >= p.M || col >= p.N || c4 >= BN / 2) continue;
+        const unsigned off = (unsigned)z * slab_b + ((unsigned)row * (unsigned)p.N + (unsigned)col) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rs, off, 0, 16);      // (N % 4 == 0: whole quads)
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(gl_smem + 4 * 32 * 68 * 4);      // behind the four staging blocks
+    unsigned* cn = p.cnt + (size_t)by * ((p.N + BN - 1) / BN) + bx;
+    if (tid == 0) *flag = __hip_atomic_fetch_add(cn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != (unsigned)(p.splitk - 1)) return;
+    if (tid == 0) __hip_atomic_store(cn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+#if RC_ACQUIRE_INV
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    const int S = p.splitk;
+    const int nrow = (p.M - m0 < GEMM_TILE) ? p.M - m0 : GEMM_TILE;
+    const int ncol = (p.N - n0 < BN) ? p.N - n0 : BN;
+    // 16 quads per thread and slab; 16 loads of 16 bytes in flight per thread at a time (NBQ quads x ZS slices): the sum is
+    // bound by round trips, not by bytes — one quad at a time took 16 dependent trips per tile
+    auto sum_tile = [&](auto nbq_c, auto zs_c) {
+      constexpr int NBQ = decltype(nbq_c)::value, ZS = decltype(zs_c)::value;
+      for (int q0 = 0; q0 < GEMM_TILE * (BN / 4) / 256; q0 += NBQ) {
+        f32x4 part[NBQ * ZS];
+        unsigned off[NBQ]; bool ok[NBQ];
+#pragma unroll
+        for (int u = 0; u < NBQ; ++u) {
+          const int q = (q0 + u) * 256 + tid;
+          const int rl = q / (BN / 4), c4 = (q - rl * (BN / 4)) * 4;
+          ok[u] = rl < nrow && c4 < ncol;
+          off[u] = ((unsigned)(m0 + rl) * (unsigned)p.N + (unsigned)(n0 + c4)) * 4u;
+#pragma unroll
+          for (int zz = 0; zz < ZS; ++zz)
+            if (zz < S && ok[u]) part[u * ZS + zz] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + (unsigned)zz * slab_b, 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < NBQ; ++u) {
+          if (!ok[u]) continue;
+          f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int zz = 0; zz < ZS; ++zz) if (zz < S) sum += part[u * ZS + zz];
+          const int q = (q0 + u) * 256 + tid;
+          const int rl = q / (BN / 4), c4 = (q - rl * (BN / 4)) * 4;
+          const int row = m0 + rl, col = n0 + c4;
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = p.alpha * sum[e] + ((p.bias && col + e < p.N) ? p.bias[col + e] : 0.f);
+          if (p.c_bf16) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col;
+            for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = (bf16_t)o[e];
+          } else {
+            float* dst = p.C + (size_t)row * p.ldc + col;
+            if (((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) && !p.C2) {      // (N % 4 == 0: the quad is whole)
+              f32x4 w = f32x4{o[0], o[1], o[2], o[3]};
+              if (p.accumulate) w += *reinterpret_cast<const f32x4*>(dst);
+              *reinterpret_cast<f32x4*>(dst) = w;
+            } else {
+              for (int e = 0; e < 4 && col + e < p.N; ++e) {
+                float w = o[e];
+                if (p.accumulate) w += dst[e];
+                dst[e] = w;
+                if (p.C2) reinterpret_cast<bf16_t*>(p.C2)[(size_t)row * p.ldc2 + col + e] = (bf16_t)w;
+              }
+            }
+          }
+        }
+      }
+    };
+    if (S <= 2) sum_tile(std::integral_constant<int, 8>(), std::integral_constant<int, 2>());
+    else if (S <= 4) sum_tile(std::integral_constant<int, 4>(), std::integral_constant<int, 4>());
+    else if (S <= 8) sum_tile(std::integral_constant<int, 2>(), std::integral_constant<int, 8>());
+    else sum_tile(std::integral_constant<int, 1>(), std::integral_constant<int, 16>());
+    return;
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -231,4 +334,34 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
       }
     }
   }
+}
+
+template <bool ACOL, bool BCOL, int NS, int TAG, int BN = 128>
+__global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+  gemm_lds_tile<ACOL, BCOL, NS, BN, false>(p, blockIdx.x, blockIdx.y, blockIdx.z, gl_smem);
+}
+
+// ---- grouped launch: the tiles of up to GG_MAX products of one operand layout in ONE grid.  The hardware dispatcher deals the
+// workgroups out in index order as CUs free up, i.e. the grid IS a work queue: the host orders the products by slice length
+// (longest first), so the short tiles of the small products fill the tail of the schedule instead of running as launches of a
+// few dozen workgroups each, and a split product is summed by its last-arriving slice (no reduction launch, no memset node).
+#ifndef GG_MAX
+#define GG_MAX 8
+#endif
+struct GemmGroupArgs { GemmArgs p[GG_MAX]; int first[GG_MAX + 1]; int np; };
+template <bool ACOL, bool BCOL, int NS>
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
+  int i = 0;
+  const int bid = blockIdx.x;
+#pragma unroll
+  for (int k = 1; k < GG_MAX; ++k) if (k < g.np && bid >= g.first[k]) i = k;
+  const GemmArgs& p = g.p[i];
+  const int local = bid - g.first[i];
+  const int tn = (p.N + GEMM_TILE - 1) / GEMM_TILE, tm = (p.M + GEMM_TILE - 1) / GEMM_TILE;
+  // slices of a tile are neighbours in the queue (they finish together: the last arriver does not wait long for the others)
+  const int z = local % p.splitk, t = local / p.splitk;
+  gemm_lds_tile<ACOL, BCOL, NS, 128, true>(p, t % tn, t / tn, z, gl_smem);
+  (void)tm;
 }

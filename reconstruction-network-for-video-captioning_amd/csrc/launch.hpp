@@ -30,6 +30,22 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
                     int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag = 0, int c_bf16 = 0,
                     void* c2 = nullptr, int ldc2 = 0);
 
+// Grouped launch: up to 8 products of ONE operand layout (a_col, b_col) with bf16 operands in one grid (gemm_lds.hpp:
+// gemm_group_kernel).  Split factors are chosen here from a list-scheduling estimate over 2 workgroups per CU; a split
+// product is summed inside the launch by its last-arriving slice (ws: fp32 slabs, cnt: zero-initialised tile counters that the
+// kernel leaves zeroed).  Returns 0 when it launched; 1 when the group does not qualify (the caller runs the products one by one).
+#ifndef GG_MAX
+#define GG_MAX 8
+#endif
+struct RnGemmDesc {
+  const void* A; int lda; const void* B; int ldb; float* C; int ldc; const float* bias;
+  int M, N, K; float alpha; int accumulate; int c_bf16; void* c2; int ldc2;
+};
+// slots: workgroup slots the launch can expect to get (0: the whole chip, 2 per CU) — launches that run beside a persistent chain
+// kernel or beside another grouped launch pass what is left to them, so that the split factors are not chosen for an empty chip.
+int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float* ws, size_t ws_floats, unsigned* cnt, int cnt_words,
+                         hipStream_t st, int slots = 0);
+
 // ---- dropout descriptor handed to kernels: seed lives in device memory so a captured graph can be
 // replayed with a new seed.
 struct DropDesc {

@@ -511,6 +511,30 @@ class Engine:
                    "recnet_gemm_bf16")
         return C_out
 
+    def gemm_group_bf16(self, As, Bs, a_col=False, b_col=False, biases=None, alphas=None, C_outs=None, accumulate=None, split=True):
+        """Test hook for the grouped launch (recnet_gemm_group_bf16): lists of torch.bfloat16 operands of one layout; returns the
+        fp32 results.  split=False: no slab workspace, i.e. no product is split along K."""
+        n = len(As)
+        Ms = [A.shape[1] if a_col else A.shape[0] for A in As]
+        Ks = [A.shape[0] if a_col else A.shape[1] for A in As]
+        Ns = [B.shape[1] if b_col else B.shape[0] for B in Bs]
+        dev = As[0].device
+        if C_outs is None:
+            C_outs = [torch.zeros(m, nn_, dtype=torch.float32, device=dev) for m, nn_ in zip(Ms, Ns)]
+        ws = torch.empty(16 * max(m * nn_ for m, nn_ in zip(Ms, Ns)) * n, dtype=torch.float32, device=dev) if split else None
+        if not hasattr(self, "_gg_cnt"):
+            self._gg_cnt = torch.zeros(1 << 16, dtype=torch.int32, device=dev)
+        vp = lambda ts: (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in ts])
+        ia = lambda xs: (C.c_int32 * n)(*[int(x) for x in xs])
+        bl = biases if biases is not None else [None] * n
+        _lib.check(self.lib.recnet_gemm_group_bf16(int(a_col), int(b_col), n, vp(As), ia([A.stride(0) for A in As]), vp(Bs),
+                                                   ia([B.stride(0) for B in Bs]), vp(C_outs), ia([c.stride(0) for c in C_outs]), vp(bl),
+                                                   ia(Ms), ia(Ns), ia(Ks), (C.c_float * n)(*[float(x) for x in (alphas or [1.0] * n)]),
+                                                   ia(accumulate or [0] * n), _ptr(ws), ws.numel() if ws is not None else 0,
+                                                   _ptr(self._gg_cnt) if split else None, (1 << 16) if split else 0, _stream()),
+                   "recnet_gemm_group_bf16")
+        return C_outs
+
     def gemm(self, A, B, a_col=False, b_col=False, bias=None, alpha=1.0, C_out=None, accumulate=False, splitk=1,
              M=None, N=None, K=None):
         """Test hook: C[M,N] (+)= alpha * op(A) op(B)^T + bias through the MFMA GEMM."""

@@ -158,3 +158,77 @@ def test_gemm_lds_random_and_epilogue():
     eng.gemm_bf16(Ab, Bb, bias=bias, alpha=0.25, C_out=C, accumulate=True, M=M, N=N, K=K)
     torch.cuda.synchronize()
     assert (C.double() - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
+# ---- grouped launch (csrc/gemm_lds.hpp: gemm_group_kernel): several products of one layout in one grid, split products summed
+# inside the launch by their last-arriving slice
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _mk(M, N, K, a_col, b_col, g):
+    A = torch.randn((K, M) if a_col else (M, K), generator=g).cuda()
+    B = torch.randn((K, N) if b_col else (N, K), generator=g).cuda()
+    # leading dimensions of the library's operand buffers are multiples of 8 elements (zero padded)
+    def pad(t):
+        c = (t.shape[1] + 7) // 8 * 8
+        o = torch.zeros(t.shape[0], c, dtype=torch.bfloat16, device="cuda")
+        o[:, :t.shape[1]] = _bf(t)
+        return o[:, :t.shape[1]]
+    return pad(A), pad(B)
+
+
+GROUPS = {
+    # the decoder's deferred weight gradients at the benchmark shape (train.py:264-268): dW_c, dW_ih[:, :E], dW_hh, dW_att, dU
+    "tail": [(2048, 1536, 3100), (2048, 468, 3100), (2048, 512, 3000), (128, 512, 3000), (128, 1536, 2800)],
+    # one long-K product alone: split by the scheduler, summed in the launch
+    "split_one": [(3100, 1024, 6144)],
+    # ragged members, one of them tiny, one with K below a k-tile
+    "ragged": [(37, 97, 41), (300, 130, 1000), (5, 288, 112), (129, 257, 4100), (64, 8, 24)],
+    "prologue": [(3100, 2048, 468), (2800, 128, 1536), (2800, 2048, 1536)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(GROUPS))
+@pytest.mark.parametrize("a_col,b_col", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("split", [True, False])
+def test_gemm_group_matches_reference_and_single_launches(name, a_col, b_col, split):
+    eng = _engine("bf16")
+    g = torch.Generator().manual_seed(hash(name) % 1000 + 2 * a_col + b_col)
+    shapes = GROUPS[name]
+    ops = [_mk(M, N, K, a_col, b_col, g) for M, N, K in shapes]
+    As, Bs = [o[0] for o in ops], [o[1] for o in ops]
+    biases = [torch.randn(N, generator=g).cuda() if i % 2 == 0 else None for i, (M, N, K) in enumerate(shapes)]
+    alphas = [1.0 if i % 3 else 0.5 for i in range(len(shapes))]
+    outs = None
+    for rep in range(3):           # the tile counters must come back to zero: a second and third launch see the same results
+        Cs = eng.gemm_group_bf16(As, Bs, bool(a_col), bool(b_col), biases=biases, alphas=alphas, split=split)
+        torch.cuda.synchronize()
+        if outs is not None:
+            for c0, c1 in zip(outs, Cs):
+                assert torch.equal(c0, c1)
+        outs = Cs
+    for (M, N, K), A, B, bias, al, Cg in zip(shapes, As, Bs, biases, alphas, outs):
+        ref = al * _ref(A.float(), B.float(), a_col, b_col)
+        if bias is not None:
+            ref = ref + bias.double()
+        scale = ref.abs().max().item()
+        assert (Cg.double() - ref).abs().max().item() <= 2e-5 * scale + 1e-4, (M, N, K)      # bf16 products are exact in fp32; only the summation order differs
+        C1 = eng.gemm_bf16(A, B, bool(a_col), bool(b_col), bias=bias, alpha=al)
+        assert (Cg - C1).abs().max().item() <= 2e-5 * scale + 1e-4
+
+
+def test_gemm_group_accumulate_and_exact_integers():
+    eng = _engine("bf16")
+    g = torch.Generator().manual_seed(11)
+    shapes = [(152, 200, 4096), (128, 128, 64), (264, 72, 2048)]      # (col operands: M and N are the leading dimensions, multiples of 8)
+    As = [_bf(torch.randint(-2, 3, (K, M), generator=g).float()).cuda() for M, N, K in shapes]
+    Bs = [_bf(torch.randint(-2, 3, (K, N), generator=g).float()).cuda() for M, N, K in shapes]
+    C0 = [torch.randint(-5, 6, (M, N), generator=g).float().cuda() for M, N, K in shapes]
+    Cs = eng.gemm_group_bf16(As, Bs, True, True, C_outs=[c.clone() for c in C0], accumulate=[1, 1, 0])
+    torch.cuda.synchronize()
+    for A, B, c0, c, acc in zip(As, Bs, C0, Cs, (1, 1, 0)):
+        ref = A.double().t() @ B.double()
+        if acc:
+            ref = ref + c0.double()
+        assert torch.equal(c.double(), ref)
