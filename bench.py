@@ -171,9 +171,14 @@ def phase_table(eng, run, replays=12):
         out["chain_%s_us" % nm] = med([r["chains"][nm][1] - r["chains"][nm][0] for r in rows])
         if i + 1 < len(order):
             out["gap_%s_to_%s_us" % (nm, order[i + 1])] = med([r["chains"][order[i + 1]][0] - r["chains"][nm][1] for r in rows])
+    # grouped GEMM launches (first workgroup started, last workgroup left), offsets from the step's start
+    for nm in rows[0].get("groups", {}):
+        if all(nm in r["groups"] for r in rows):
+            out["group_%s_us" % nm] = [med([r["groups"][nm][0] for r in rows]), med([r["groups"][nm][1] for r in rows])]
     out["tail_us"] = med([r["end"] - r["chains"][order[-1]][1] for r in rows])
     out["span_us"] = med([r["end"] for r in rows])
-    out["outside_chains_us"] = round(out["span_us"] - sum(v for k, v in out.items() if k.startswith("chain_")), 1)
+    out["chain_offsets_us"] = {nm: [med([r["chains"][nm][0] for r in rows]), med([r["chains"][nm][1] for r in rows])] for nm in order}
+    out["outside_chains_us"] = round(out["span_us"] - sum(v for k, v in out.items() if k.startswith("chain_") and isinstance(v, float)), 1)
     return out
 
 
@@ -212,7 +217,7 @@ def main():
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the fp32_exact sub-record (the same workload on the exact-fp32 path)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
-    ap.add_argument("--defer", type=int, default=0, help="1: deferred reconstructor update (one rank, graph mode, global reconstructor): the "
+    ap.add_argument("--defer", type=int, default=0, choices=[0, 1, 2], help="1: deferred reconstructor update (one rank, graph mode, global reconstructor): the "
                     "update of step n runs under the decoder forward chain of step n + 1; flushed inside the timed region.  Measured "
                     "slower (2.34 against 1.95 ms at C2, DESIGN.md section 5): not the default")
     ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"], help="recurrent cell of decoder and reconstructor "
@@ -274,7 +279,7 @@ def main():
     if args.graph:
         # one rank: the reconstructor's weight-gradient products + Adam step of replay n run under the decoder forward
         # chain of replay n + 1 (api.GraphedStep: defer_reconstructor_update); the last one is flushed INSIDE the timed region
-        runner = graphed = R.GraphedStep(step, enc, targets, T, w, defer_reconstructor_update=bool(args.defer))
+        runner = graphed = R.GraphedStep(step, enc, targets, T, w, defer_reconstructor_update={0: False, 1: True, 2: "recurrent"}[args.defer])
     if args.feed:
         # PCIe-inclusive variant: host batches -> pinned staging -> H2D (side stream) -> the step's input buffers
         import itertools

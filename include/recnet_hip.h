@@ -261,7 +261,11 @@ int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* s
  * recnet_flush are bit-identical to the non-deferred step's.  recnet_flush completes a pending update on `stream` (a no-op
  * on the device when nothing is pending); every other entry point of the handle that reads the reconstructor's parameters,
  * gradients or Adam state flushes first, callers that read them through their own pointers (state_dict, checkpoints)
- * call recnet_flush themselves. */
+ * call recnet_flush themselves.
+ * on == 2 (global reconstructor): SPLIT update — only the recurrent weights (rnn.weight_hh_l0: 60 % of the reconstructor's
+ * weight-gradient work) are left pending; the input-side weights, the output layer and the biases are updated inside the step,
+ * beside the decoder's BPTT chain.  The pending product then fits under the next step's decoder forward chain (137 workgroups,
+ * 119 CUs idle) without delaying that step's reconstructor, and this step's BPTT window is not overfilled. */
 int recnet_set_deferred_reconstructor_update(recnet_handle* h, int32_t on, void* stream);
 int recnet_flush(recnet_handle* h, void* stream);
 /* A hipGraph that captured a fused step was replayed (replays run no host code): tells the handle that the reconstructor's
@@ -295,7 +299,10 @@ int recnet_profile_read(recnet_handle* h, int32_t* n_launches, double* total_ms)
  *   [1 + 2k], [2 + 2k] workgroup 0 of chain kernel k started running / left, k = 0 decoder forward chain, 1 decoder BPTT chain,
  *                      2 global reconstructor forward, 3 global reconstructor backward, 4 local reconstructor forward, 5 local backward
  *                      (the last launch of that chain; a chain that did not run keeps its old stamps)
- *   [13] step end (the kernel that exports the step's scalars).
+ *   [13] step end (the kernel that exports the step's scalars)
+ *   n >= 30: [14 + 2j], [15 + 2j] first workgroup started / last workgroup left of the grouped GEMM launch of site j:
+ *            0 decoder prologue (Xe, Uv, P), 1 reconstructor weight gradients inside the step, 2 the pending half of a split
+ *            reconstructor update (mode 2), 3 decoder weight gradients.
  * Synchronises `stream`.  train.py:248-273 is the span between [0] and [13]. */
 int recnet_read_stamps(recnet_handle* h, uint64_t* out, int32_t n, void* stream);
 /* Calibration of the bracket itself: `count` launches of an empty kernel bracketed by the same two event records (call

@@ -516,7 +516,9 @@ class GraphedStep:
         eng = self.eng
         self.deferred = (bool(defer_reconstructor_update) and not self.split and self.rs is not None and
                          st.reconstructor["model"].kind == "global")
-        eng.set_deferred_reconstructor_update(self.deferred)
+        # "recurrent": only d W_hh and its Adam step are left to the next replay (mode 2 of recnet_set_deferred_reconstructor_update)
+        self.defer_mode = ("recurrent" if defer_reconstructor_update in (2, "recurrent") else True) if self.deferred else False
+        eng.set_deferred_reconstructor_update(self.defer_mode)
         eng.set_step(self.ms.step)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

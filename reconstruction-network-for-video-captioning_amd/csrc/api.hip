@@ -50,6 +50,8 @@ struct OptGroup {
 };
 
 static inline int pad8(int n) { return (n + 7) & ~7; }
+// index of rnn.weight_hh_l0 in the reconstructor's tensor list (rec_list): behind the four attention tensors of the local form
+#define RN_REC_T_WHH(h) ((h)->kind == RECNET_REC_LOCAL ? 5 : 1)
 #define RN_GCNT_WORDS 16384     // output tiles of the split members of one grouped launch
 #define RN_MAX_ROW_GROUPS 4      // persistent chains up to 4 x 112 = 448 captions per GPU
 
@@ -112,6 +114,8 @@ struct recnet_handle {
   // lazy refresh of the reconstructor's derived weight images (transposes, streamed fragments): the fused step leaves them stale
   // at its end and refreshes them in its next run's hoisted side work, under the decoder forward chain (host_common.inc)
   int lazy_images = 1, in_fused = 0, rec_images_stale = 0, side_fork_recorded = 0;
+  int hoist_fork_recorded = 0;   // dec_fwd_chain recorded the fork events of hoist_side_work itself, in front of the chain launch
+  int rec_wait_pending = 0;      // fwd_rec_global waits for ev[12] (the pending W_hh update, mode 2) in front of its recurrent chain
   int defer_rec = 0, defer_now = 0, defer_err = 0, maybe_pending = 0, def_rows = 0, defer_flags = 3; hipStream_t s3 = nullptr; float* gws3 = nullptr;
   int mp_done = 0;          // h->mp holds the mean-pooled decoder states of the last decoder forward (dec_chain_kernel)
   int ncu = 0;
@@ -130,9 +134,10 @@ struct recnet_handle {
   size_t gws_floats, slab_floats;
   float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
   unsigned* gcnt = nullptr;      // tile counters of the grouped launches' in-launch split-K sums: one block of RN_GCNT_WORDS per slab workspace
+  int gg_site = 0;               // the next grouped launch stamps its start / end into this slot (1..8) of the group stamps
   int gg_slots = 0;              // workgroup slots the next grouped launches can expect (0 = whole chip): see host_common.inc
   int gemm_single_group = 0;     // RN_GEMM_SINGLE=0: single products take gemm_lds_kernel + splitk_reduce_kernel (round-3 form)
-  hipStream_t s2 = nullptr; hipEvent_t ev[16] = {}; int overlap = 1;
+  hipStream_t s2 = nullptr; hipEvent_t ev[24] = {}; int overlap = 1;
   // bindings
   recnet_decoder_tensors dP{}, dGd{}, dM{}, dV{}, dVm{};
   recnet_reconstructor_tensors rP{}, rG{}, rM{}, rV{}, rVm{};
@@ -427,7 +432,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
 void recnet_destroy(recnet_handle* h) {
   if (!h) return;
   for (auto e : h->prof_ev) hipEventDestroy(e);
-  for (int i = 0; i < 16; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  for (int i = 0; i < 24; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
   if (h->s2) hipStreamDestroy(h->s2);
   if (h->s3) hipStreamDestroy(h->s3);
   delete h;
@@ -516,7 +521,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
     else
       HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
-    for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 24; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
   }
   h->fwd_dec_done = h->fwd_rec_done = h->rec_bwd_done = 0;
   int r = upload_tables(h, 0); if (r) return r;

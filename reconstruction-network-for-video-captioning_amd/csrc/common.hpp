@@ -87,3 +87,24 @@ __device__ __forceinline__ float rn_tanh(float x) {
   const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
   return copysignf(r, x);
 }
+
+// ---------------------------------------------------------------- Adam (shared by adam_chunk_kernel and the GEMM epilogue)
+// torch.optim.Adam (single-tensor form of torch 2.10): g' = clip * (g + reg) + wd * p ; m <- lerp(m, g', 1-b1) ;
+// v <- b2 v + (1-b2) g'^2 ; [vmax <- max(vmax, v)] ; p <- p - (lr / bc1) * m / (sqrt(v̂) / sqrt(bc2) + eps).
+// One definition, contraction pinned per expression, so that the optimiser kernel and the weight-gradient product that applies
+// the update in its epilogue (gemm_lds.hpp) round identically.
+struct AdamHyper { double lr, beta1, beta2; float eps, wd, one_m_b1, beta2f, one_m_b2; int amsgrad; float reg_coef; };
+// what the products of one grouped launch share when they apply Adam in their epilogue (gemm_lds.hpp)
+struct AdamShared { AdamHyper hp; const int32_t* step_ptr; const float* poison; const uint32_t* pending; int step_off; int pad; };
+__device__ __forceinline__ float rn_adam_update(float p, float gr, float& m, float& v, float& vmx, float k, float cl, const AdamHyper& hp,
+                                                float step_size, float bc2s) {
+#pragma clang fp contract(on)
+  float g = (gr + k * p) * cl;
+  g = g + hp.wd * p;
+  m = m + hp.one_m_b1 * (g - m);
+  v = v * hp.beta2f + hp.one_m_b2 * g * g;
+  float vh = v;
+  if (hp.amsgrad) { vh = fmaxf(vmx, v); vmx = vh; }
+  const float denom = sqrtf(vh) / bc2s + hp.eps;
+  return p - step_size * (m / denom);
+}

@@ -2,6 +2,7 @@
 #include "gemm_chain.hpp"
 #include "launch.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 template <typename CT, typename TA, typename TB>
@@ -107,7 +108,7 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
                     int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag, int c_bf16, void* c2, int ldc2) {
   if (M <= 0 || N <= 0) return;
   GemmArgs a;
-  a.c_bf16 = c_bf16; a.C2 = c2; a.ldc2 = ldc2; a.cnt = nullptr;
+  a.c_bf16 = c_bf16; a.C2 = c2; a.ldc2 = ldc2; a.cnt = nullptr; a.ad_p = nullptr;
   if (c_bf16 || c2) splitk = 1;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -188,10 +189,10 @@ int rn_effective_splitk(int prec, int K, int splitk) {
 #include <queue>
 #include <vector>
 namespace {
-template <bool ACOL, bool BCOL>
+template <bool ACOL, bool BCOL, bool EPI = false>
 void launch_group_one(const GemmGroupArgs& g, int nblocks, hipStream_t st) {
   static bool attr_done = false;
-  auto fn = gemm_group_kernel<ACOL, BCOL, 2>;
+  auto fn = gemm_group_kernel<ACOL, BCOL, 2, EPI>;
   if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GL_STAGE_BYTES); attr_done = true; }
   hipLaunchKernelGGL(fn, dim3(nblocks), dim3(256), 2 * GL_STAGE_BYTES, st, g);
 }
@@ -208,7 +209,7 @@ double list_makespan(const std::vector<std::pair<double, int>>& runs, int slots)
 }  // namespace
 
 int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float* ws, size_t ws_floats, unsigned* cnt, int cnt_words,
-                         hipStream_t st, int slots_hint) {
+                         hipStream_t st, int slots_hint, const AdamShared* adam, unsigned long long* stamp) {
   static const int on = getenv("RN_GEMM_GROUP") ? atoi(getenv("RN_GEMM_GROUP")) : 1;
   if (!on || n < 1 || n > GG_MAX) return 1;
   struct Prob { int idx, tiles, nkt, s; };
@@ -244,7 +245,7 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
     int best = -1; double best_t = base * 0.97;      // a split has to pay for its slabs
     for (size_t i = 0; i < pr.size(); ++i) {
       Prob& q = pr[i];
-      if (d[q.idx].c2 || (d[q.idx].N & 3) || q.s >= 16 || q.nkt / (q.s + 1) < 4) continue;
+      if (d[q.idx].c2 || d[q.idx].ad_p || (d[q.idx].N & 3) || q.s >= 16 || q.nkt / (q.s + 1) < 4) continue;      // (Adam epilogue: whole K in one workgroup)
       const int keep = q.s;
       q.s = keep + 1;
       const double t = estimate();
@@ -256,6 +257,9 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
   }
   std::sort(pr.begin(), pr.end(), [&](const Prob& a, const Prob& b) { return per_slice(a) > per_slice(b); });
   GemmGroupArgs g;
+  bool any_epi = false;
+  if (adam) g.ad = *adam; else memset(&g.ad, 0, sizeof(g.ad));
+  g.stamp = stamp;
   g.np = (int)pr.size();
   int blocks = 0; size_t ws_off = 0; int cnt_off = 0;
   for (int k = 0; k < g.np; ++k) {
@@ -263,6 +267,9 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
     GemmArgs& a = g.p[k];
     a.A = e.A; a.B = e.B; a.C = e.C; a.bias = e.bias; a.M = e.M; a.N = e.N; a.K = e.K; a.lda = e.lda; a.ldb = e.ldb; a.ldc = e.ldc;
     a.alpha = e.alpha; a.accumulate = e.accumulate; a.c_bf16 = e.c_bf16; a.C2 = e.c2; a.ldc2 = e.ldc2; a.a_vec = 1; a.b_vec = 1;
+    a.ad_p = adam ? e.ad_p : nullptr; a.ad_m = e.ad_m; a.ad_v = e.ad_v; a.ad_vmax = e.ad_vmax; a.ad_img = e.ad_img; a.ad_imgt = e.ad_imgt;
+    a.ad_pnorm = e.ad_pnorm; a.ad_ld_img = e.ad_ld_img; a.ad_ld_imgt = e.ad_ld_imgt;
+    if (a.ad_p) any_epi = true;
     const int per = per_slice(pr[k]);
     int s = (pr[k].nkt + per - 1) / per;
     const size_t slab = (size_t)e.M * e.N;
@@ -274,6 +281,11 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
     blocks += pr[k].tiles * s;
   }
   for (int k = g.np; k <= GG_MAX; ++k) g.first[k] = blocks;
+  if (any_epi) {
+    if (!(a_col && b_col)) return 1;                       // (the fused update exists for the dY^T . X form only)
+    launch_group_one<true, true, true>(g, blocks, st);
+    return 0;
+  }
   if (!a_col && !b_col) launch_group_one<false, false>(g, blocks, st);
   else if (!a_col && b_col) launch_group_one<false, true>(g, blocks, st);
   else if (a_col && !b_col) launch_group_one<true, false>(g, blocks, st);

@@ -24,6 +24,10 @@ struct GemmArgs {
   int a_vec, b_vec;           // 16-byte vector loads are legal for this operand (alignment checked on host)
   int c_bf16;                 // direct epilogue stores bf16 into C (reinterpreted); requires splitk == 1
   void* C2; int ldc2;         // optional second, bf16 copy of the fp32 result (direct epilogue of gemm_lds only)
+  // Adam in the epilogue (grouped launches of dY^T . X products, gemm_lds.hpp): the product IS the gradient of a parameter
+  // block with the layout of C — p / m / v / vmax point at that block's first row, img / imgT at its packed operand image
+  // ([rows][ld_img] bf16) and the transposed image ([cols][ld_imgt] bf16, may be null); null p: plain epilogue
+  float* ad_p; float* ad_m; float* ad_v; float* ad_vmax; void* ad_img; void* ad_imgt; const float* ad_pnorm; int ad_ld_img, ad_ld_imgt;
   unsigned* cnt;              // grouped launches (gemm_group_kernel) with splitk > 1: one arrival counter per output tile —
                               // the slice that arrives last sums the slabs and runs the epilogue (no reduction launch)
 };

@@ -110,8 +110,9 @@ __device__ __forceinline__ bf16x8 gl_frag(const char* img, int row /*first of th
 // columns but 256 of 96, one per CU, each with a quarter less weight data and MFMA work on the chain's critical path.
 // One output tile (bx, by) of K slice z.  FIX: the launch is a grouped one (gemm_group_kernel) and a split product is finished
 // inside it — see the fix-up block of the epilogue.
-template <bool ACOL, bool BCOL, int NS, int BN, bool FIX, typename ArgsT>
-__device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, const int by, const int z, char* gl_smem) {
+template <bool ACOL, bool BCOL, int NS, int BN, bool FIX, bool EPI = false, typename ArgsT>
+__device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, const int by, const int z, char* gl_smem,
+                                              const AdamShared* sh = nullptr) {
   static_assert(BN == 128 || (BN == 96 && !BCOL), "96-column tiles: row-layout weights only");
   constexpr int NPB = BN / 32;                 // DMA pieces per wave of the B tile = 16-column groups per wave
   constexpr int STAGE = 16384 + BN * 128;      // A image 16 KiB + B image
@@ -287,6 +288,80 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
     else sum_tile(std::integral_constant<int, 1>(), std::integral_constant<int, 16>());
     return;
   }
+  if constexpr (EPI) {
+    if (!to_slab && p.ad_p && sh) {
+      // ---- the product is a weight gradient and this launch also applies its Adam update (single-rank fused step): every
+      // quad of the tile is written as the gradient and, in the same pass, updates p / m / v and the bf16 operand image; the
+      // transposed image (the chain kernels' K-contiguous form) goes through a per-wave LDS block so that every lane writes
+      // 64 contiguous bytes.  What a separate Adam kernel (28 B per parameter through ~120 CUs) and two transpose kernels did.
+      float* hy = reinterpret_cast<float*>(gl_smem + 4 * 32 * 68 * 4 + 16);
+      if (tid == 0) {
+        const double st = (double)(*sh->step_ptr + sh->step_off);
+        const double bc1 = 1.0 - pow(sh->hp.beta1, st), bc2 = 1.0 - pow(sh->hp.beta2, st);
+        hy[0] = (float)(sh->hp.lr / bc1); hy[1] = (float)sqrt(bc2);
+        // a chain kernel of this step gave up (poison), or no step left an update pending: gradient only
+        hy[2] = ((sh->poison && *sh->poison != 0.f) || (sh->pending && *sh->pending == 0u)) ? 0.f : 1.f;
+      }
+      __syncthreads();
+      const float step_size = hy[0], bc2s = hy[1];
+      const bool active = hy[2] != 0.f;
+      const float nrm = p.ad_pnorm ? *p.ad_pnorm : 0.f;
+      const float kreg = nrm > 0.f ? sh->hp.reg_coef / nrm : 0.f;
+      const bool ams = sh->hp.amsgrad != 0;
+      constexpr int TS = 40;                                  // row stride of the transposed block (bf16): 80 bytes
+      bf16_t* tT = reinterpret_cast<bf16_t*>(gl_smem + 36864 + wave * (64 * TS * 2));
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NPB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(ii * 16 + cr + r) * 68 + j * 16 + cc] = acc[half * 2 + ii][j][r];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int rl = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 68 + c4);
+          const int row = m0 + wm + half * 32 + rl, col = n0 + wn + c4;
+          if (row >= p.M || col >= p.N || c4 >= BN / 2) continue;
+          const size_t off = (size_t)row * p.ldc + col;
+          const f32x4 g4 = p.alpha * v;
+          *reinterpret_cast<f32x4*>(p.C + off) = g4;
+          if (!active) continue;
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(p.ad_p + off);
+          f32x4 m4 = *reinterpret_cast<const f32x4*>(p.ad_m + off), v4 = *reinterpret_cast<const f32x4*>(p.ad_v + off);
+          f32x4 x4 = ams ? *reinterpret_cast<const f32x4*>(p.ad_vmax + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 n4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float mm = m4[e], vv = v4[e], xx = x4[e];
+            n4[e] = rn_adam_update(p4[e], g4[e], mm, vv, xx, kreg, 1.f, sh->hp, step_size, bc2s);
+            m4[e] = mm; v4[e] = vv; x4[e] = xx;
+          }
+          *reinterpret_cast<f32x4*>(p.ad_m + off) = m4; *reinterpret_cast<f32x4*>(p.ad_v + off) = v4;
+          if (ams) *reinterpret_cast<f32x4*>(p.ad_vmax + off) = x4;
+          *reinterpret_cast<f32x4*>(p.ad_p + off) = n4;
+          bf16x4 hb; hb[0] = (bf16_t)n4[0]; hb[1] = (bf16_t)n4[1]; hb[2] = (bf16_t)n4[2]; hb[3] = (bf16_t)n4[3];
+          if (p.ad_img) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.ad_img) + (size_t)row * p.ad_ld_img + col) = hb;
+          if (p.ad_imgt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tT[(c4 + e) * TS + rl] = hb[e];
+          }
+        }
+        if (p.ad_imgt && active) {
+          // lane c owns column c of the wave's 32 x 64 block: 32 consecutive rows = 64 contiguous bytes of the transposed image
+          const int col = n0 + wn + lane, r0 = m0 + wm + half * 32;
+          if (col < p.N && r0 + 32 <= p.M && lane < BN / 2) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(p.ad_imgt) + (size_t)col * p.ad_ld_imgt + r0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<f32x4*>(dst + q * 8) = *reinterpret_cast<const f32x4*>(tT + lane * TS + q * 8);
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -349,8 +424,9 @@ __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
 #ifndef GG_MAX
 #define GG_MAX 8
 #endif
-struct GemmGroupArgs { GemmArgs p[GG_MAX]; int first[GG_MAX + 1]; int np; };
-template <bool ACOL, bool BCOL, int NS>
+// stamp: optional pair of 100 MHz wall-clock words {first workgroup started, last workgroup left} (recnet_read_stamps)
+struct GemmGroupArgs { GemmArgs p[GG_MAX]; int first[GG_MAX + 1]; int np; AdamShared ad; unsigned long long* stamp; };
+template <bool ACOL, bool BCOL, int NS, bool EPI = false>
 __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
   int i = 0;
@@ -362,6 +438,8 @@ __global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupArgs g) 
   const int tn = (p.N + GEMM_TILE - 1) / GEMM_TILE, tm = (p.M + GEMM_TILE - 1) / GEMM_TILE;
   // slices of a tile are neighbours in the queue (they finish together: the last arriver does not wait long for the others)
   const int z = local % p.splitk, t = local / p.splitk;
-  gemm_lds_tile<ACOL, BCOL, NS, 128, true>(p, t % tn, t / tn, z, gl_smem);
+  if (g.stamp && bid == 0 && threadIdx.x == 0) __hip_atomic_store(g.stamp, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  gemm_lds_tile<ACOL, BCOL, NS, 128, true, EPI>(p, t % tn, t / tn, z, gl_smem, &g.ad);
+  if (g.stamp && threadIdx.x == 0) __hip_atomic_fetch_max(g.stamp + 1, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   (void)tm;
 }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void scale_grads_kernel(const TensorDesc* __re
   for (int i = ch.y + threadIdx.x; i < end; i += 256) td.g[i] *= c;
 }
 
-struct AdamHyper { double lr, beta1, beta2; float eps, wd, one_m_b1, beta2f, one_m_b2; int amsgrad; float reg_coef; };
+// (AdamHyper, rn_adam_update: common.hpp)
 // torch.optim.Adam (single-tensor form of torch 2.10): g' = clip * (g + reg) + wd * p ;
 // m <- lerp(m, g', 1-b1) ; v <- b2 v + (1-b2) g'^2 ; [vmax <- max(vmax, v)] ;
 // p <- p - (lr / bc1) * m / (sqrt(v̂) / sqrt(bc2) + eps)
@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
                                                          const float* __restrict__ clip, const int32_t* __restrict__ step_ptr,
                                                          const PackDesc* __restrict__ pack, int lp,
                                                          const float* __restrict__ poison,
-                                                         const uint32_t* __restrict__ pending = nullptr, int step_off = 0) {
+                                                         const uint32_t* __restrict__ pending = nullptr, int step_off = 0,
+                                                         uint32_t skip_mask = 0u) {
   // A persistent chain kernel of this step gave up waiting (rec_chain.hpp: rc_give_up) and marked the step: its gradients
   // are garbage, so parameters, moments and the packed images stay as they are (the host sees the flag through
   // recnet_chain_status and the NaN total loss).
@@ -114,6 +115,8 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
   // deferred reconstructor update (recnet_flush / the next fused step): nothing to do unless a step left one pending;
   // step_off = -1 when the step counter has already been advanced for the step this launch runs beside
   if (pending && *pending == 0u) return;
+  // tensors another launch updates (the split reconstructor update: recurrent weights in the next step, the rest in this one)
+  if ((skip_mask >> chunks[blockIdx.x].x) & 1u) return;
   __shared__ float sc[2];
   if (threadIdx.x == 0) {
     const double st = (double)(*step_ptr + step_off);
@@ -146,14 +149,7 @@ __global__ __launch_bounds__(256) void adam_chunk_kernel(const TensorDesc* __res
       }
   };
   auto upd = [&](float p, float gr, float& m, float& v, float& vmx) -> float {
-    float g = (gr + k * p) * cl;
-    g = g + hp.wd * p;
-    m = m + hp.one_m_b1 * (g - m);
-    v = v * hp.beta2f + hp.one_m_b2 * g * g;
-    float vh = v;
-    if (hp.amsgrad) { vh = fmaxf(vmx, v); vmx = vh; }
-    const float denom = sqrtf(vh) / bc2s + hp.eps;
-    return p - step_size * (m / denom);
+    return rn_adam_update(p, gr, m, v, vmx, k, cl, hp, step_size, bc2s);
   };
   // The update streams 28 (36 with AMSGrad) bytes per parameter: 16-byte accesses for the whole quads of the chunk (chunks
   // start at multiples of RN_CHUNK elements of 16-byte aligned tensors); a quad that lies inside one row and inside (or

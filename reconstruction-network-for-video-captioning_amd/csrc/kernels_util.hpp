@@ -14,7 +14,13 @@ __global__ void set_f32_kernel(float* p, float v) { *p = v; }
 // step counter += 1; seed slot = seed_base + step (graph-replay friendly train step)
 __global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t seed_base) {
   int s = *step + 1; *step = s; *seed_slot = seed_base + (uint32_t)s;
-  reinterpret_cast<unsigned long long*>(seed_slot + 32)[0] = wall_clock64();      // phase stamp: step start (recnet_read_stamps)
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(seed_slot + 32), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // phase stamp: step start (recnet_read_stamps, wait_chain_kernel)
+}
+
+// step counter = step (host-numbered train step), with the step-start stamp of advance_step_kernel
+__global__ void set_step_kernel(int32_t* step, int32_t v) {
+  *step = v;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(step + 31), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // sum_{z<n} p[z*stride] over the split-K slabs.  All (<= 16) loads are issued back to back and reduced as a

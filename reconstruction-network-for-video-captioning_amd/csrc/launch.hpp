@@ -40,11 +40,13 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
 struct RnGemmDesc {
   const void* A; int lda; const void* B; int ldb; float* C; int ldc; const float* bias;
   int M, N, K; float alpha; int accumulate; int c_bf16; void* c2; int ldc2;
+  // Adam in the epilogue (gemm.hpp: GemmArgs::ad_*): null ad_p = plain product
+  float* ad_p; float* ad_m; float* ad_v; float* ad_vmax; void* ad_img; void* ad_imgt; const float* ad_pnorm; int ad_ld_img, ad_ld_imgt;
 };
 // slots: workgroup slots the launch can expect to get (0: the whole chip, 2 per CU) — launches that run beside a persistent chain
 // kernel or beside another grouped launch pass what is left to them, so that the split factors are not chosen for an empty chip.
 int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float* ws, size_t ws_floats, unsigned* cnt, int cnt_words,
-                         hipStream_t st, int slots = 0);
+                         hipStream_t st, int slots = 0, const struct AdamShared* adam = nullptr, unsigned long long* stamp = nullptr);
 
 // ---- dropout descriptor handed to kernels: seed lives in device memory so a captured graph can be
 // replayed with a new seed.

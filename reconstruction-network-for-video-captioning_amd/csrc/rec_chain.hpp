@@ -90,13 +90,29 @@ __device__ __forceinline__ unsigned long long* rc_stamp_slot(const unsigned* epo
   return reinterpret_cast<unsigned long long*>((a & ~255ull) + 256ull) + 2 * ((a >> 2) & 7ull);
 }
 __device__ __forceinline__ unsigned rc_epoch_read(const unsigned* epoch) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rc_stamp_slot(epoch)[0] = wall_clock64();
+  // (written through: wait_chain_kernel on another XCD polls it)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) __hip_atomic_store(rc_stamp_slot(epoch), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void rc_epoch_bump(unsigned* epoch, unsigned e) {
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     __hip_atomic_store(epoch, e + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     rc_stamp_slot(epoch)[1] = wall_clock64();
+  }
+}
+// Ordering tool for the streams BESIDE a chain: a chain kernel's workgroups need whole CUs (up to 512 registers per lane), so
+// ordinary workgroups that are already running when it launches delay its residency by as long as they run.  Work that may run
+// beside chain k is therefore enqueued behind this one-wave kernel, which returns once workgroup 0 of chain k has started in the
+// CURRENT step (its begin stamp is younger than the step's start stamp) — or after `limit` ticks of the 100 MHz clock: the wait
+// only shapes the schedule, nothing depends on it for correctness.
+__global__ void wait_chain_kernel(const unsigned long long* step_start, const unsigned long long* chain_begin, unsigned limit) {
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    const unsigned long long s = __hip_atomic_load(step_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(chain_begin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b >= s && b != 0ull) break;
+    if (wall_clock64() - t0 > (unsigned long long)limit) break;
+    __builtin_amdgcn_s_sleep(8);
   }
 }
 // Every wait in the chain kernels is bounded: a launch whose workgroups are not all resident (two such launches sharing

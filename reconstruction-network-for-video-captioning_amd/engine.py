@@ -275,7 +275,8 @@ class Engine:
     def set_deferred_reconstructor_update(self, on):
         """Opt in to / out of the deferred reconstructor update of the fused step (include/recnet_hip.h); completes a
         pending update first."""
-        _lib.check(self.lib.recnet_set_deferred_reconstructor_update(self.handle, int(bool(on)), _stream()), "recnet_set_deferred_reconstructor_update")
+        mode = 2 if on in (2, "recurrent") else int(bool(on))      # 2: only the recurrent weights' update is deferred
+        _lib.check(self.lib.recnet_set_deferred_reconstructor_update(self.handle, mode, _stream()), "recnet_set_deferred_reconstructor_update")
 
     def mark_pending(self):
         _lib.check(self.lib.recnet_mark_pending(self.handle), "recnet_mark_pending")
@@ -473,8 +474,8 @@ class Engine:
         """Phase stamps of the last train step (recnet_read_stamps): dict of microsecond offsets from the step's start —
         `chains[name] = (begin, end)` for the chain kernels that ran inside it, `end` = the step's last kernel.  Written by the
         step's own kernels, so it describes a REPLAYED graph with no tracer attached.  Synchronises."""
-        buf = (C.c_uint64 * 14)()
-        _lib.check(self.lib.recnet_read_stamps(self.handle, buf, 14, _stream()), "recnet_read_stamps")
+        buf = (C.c_uint64 * 30)()
+        _lib.check(self.lib.recnet_read_stamps(self.handle, buf, 30, _stream()), "recnet_read_stamps")
         t0, t1 = buf[0], buf[13]
         names = ("decoder_forward", "decoder_bptt", "global_forward", "global_backward", "local_forward", "local_backward")
         chains = {}
@@ -482,7 +483,12 @@ class Engine:
             b, e = buf[1 + 2 * k], buf[2 + 2 * k]
             if t0 <= b <= e <= t1:                       # ran inside this step
                 chains[nm] = ((b - t0) / 100.0, (e - t0) / 100.0)
-        return {"end": (t1 - t0) / 100.0 if t1 >= t0 else None, "chains": chains}
+        groups = {}
+        for j, nm in enumerate(("prologue_products", "reconstructor_weight_gradients", "pending_recurrent_update", "decoder_weight_gradients")):
+            b, e = buf[14 + 2 * j], buf[15 + 2 * j]
+            if t0 <= b <= e <= t1:
+                groups[nm] = ((b - t0) / 100.0, (e - t0) / 100.0)
+        return {"end": (t1 - t0) / 100.0 if t1 >= t0 else None, "chains": chains, "groups": groups}
 
     def recurrent_step_bytes(self, which):
         return float(self.lib.recnet_recurrent_step_bytes(self.handle, int(which)))
