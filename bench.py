@@ -217,9 +217,10 @@ def main():
     ap.add_argument("--no-fp32-exact", action="store_true", help="skip the fp32_exact sub-record (the same workload on the exact-fp32 path)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
-    ap.add_argument("--defer", type=int, default=0, choices=[0, 1, 2], help="1: deferred reconstructor update (one rank, graph mode, global reconstructor): the "
-                    "update of step n runs under the decoder forward chain of step n + 1; flushed inside the timed region.  Measured "
-                    "slower (2.34 against 1.95 ms at C2, DESIGN.md section 5): not the default")
+    ap.add_argument("--defer", type=int, default=2, choices=[0, 1, 2], help="one rank, graph mode — 2 (default): SPLIT reconstructor update: d W_hh and its "
+                    "Adam step of step n run under the decoder forward chain of step n + 1 (119 CUs idle there), everything else inside "
+                    "step n; 1: the whole update deferred (global reconstructor; measured slower); 0: everything inside the step.  The "
+                    "last step's pending half is flushed INSIDE the timed region: every timed step's work is timed")
     ap.add_argument("--cell", default="LSTM", choices=["LSTM", "GRU"], help="recurrent cell of decoder and reconstructor "
                     "(the north-star workload is LSTM; GRU is config.py:31's literal default)")
     ap.add_argument("--lengths", default="uniform", choices=["uniform", "msvd"], help="caption lengths: the benchmark's "

@@ -514,8 +514,9 @@ class GraphedStep:
         self.flags = _lib.OPT_REG | _lib.OPT_CLIP
         self.split = bool(dp_step.reduce)
         eng = self.eng
+        recurrent_only = defer_reconstructor_update in (2, "recurrent")
         self.deferred = (bool(defer_reconstructor_update) and not self.split and self.rs is not None and
-                         st.reconstructor["model"].kind == "global")
+                         (st.reconstructor["model"].kind == "global" or recurrent_only))
         # "recurrent": only d W_hh and its Adam step are left to the next replay (mode 2 of recnet_set_deferred_reconstructor_update)
         self.defer_mode = ("recurrent" if defer_reconstructor_update in (2, "recurrent") else True) if self.deferred else False
         eng.set_deferred_reconstructor_update(self.defer_mode)

@@ -113,8 +113,9 @@ struct recnet_handle {
   // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
   // lazy refresh of the reconstructor's derived weight images (transposes, streamed fragments): the fused step leaves them stale
   // at its end and refreshes them in its next run's hoisted side work, under the decoder forward chain (host_common.inc)
-  int lazy_images = 1, in_fused = 0, rec_images_stale = 0, side_fork_recorded = 0;
+  int lazy_images = 0, in_fused = 0, rec_images_stale = 0, side_fork_recorded = 0;
   int hoist_fork_recorded = 0;   // dec_fwd_chain recorded the fork events of hoist_side_work itself, in front of the chain launch
+  int split_ok = 0;              // the pending half of a split reconstructor update fits beside the decoder forward chain (recnet_create)
   int rec_wait_pending = 0;      // fwd_rec_global waits for ev[12] (the pending W_hh update, mode 2) in front of its recurrent chain
   int defer_rec = 0, defer_now = 0, defer_err = 0, maybe_pending = 0, def_rows = 0, defer_flags = 3; hipStream_t s3 = nullptr; float* gws3 = nullptr;
   int mp_done = 0;          // h->mp holds the mean-pooled decoder states of the last decoder forward (dec_chain_kernel)
@@ -337,7 +338,10 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->RA = c.reconstructor_type == RECNET_REC_LOCAL ? c.reconstructor_attn_size : 0;
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
-  h->lazy_images = getenv("RN_LAZY_IMAGES") ? atoi(getenv("RN_LAZY_IMAGES")) : 1;
+  // Lazy refresh of the reconstructor's derived weight images is OPT-IN: a caller that replays a captured fused step
+  // and then calls a non-fused reconstructor entry point would otherwise read stale transposes unless it calls recnet_mark_pending.
+  // The default step of this library — the split update, mode 2 — rewrites the images where it updates the weights.
+  h->lazy_images = getenv("RN_LAZY_IMAGES") ? atoi(getenv("RN_LAZY_IMAGES")) : 0;
   h->gemm_single_group = getenv("RN_GEMM_SINGLE") ? atoi(getenv("RN_GEMM_SINGLE")) : 0;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
@@ -423,6 +427,17 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const int reserve = er ? atoi(er) : 0;
     h->persist_dec_bwd = (eb ? atoi(eb) : 1) && h->persist_dec && h->use_wcomb_t && (h->H & 15) == 0 && (h->ldWS & 7) == 0 &&
                          (NAb > Bg ? NAb : Bg) + 1 + reserve <= ncu;
+  }
+  {
+    // Split reconstructor update (mode 2 of recnet_set_deferred_reconstructor_update): d W_hh of step n runs beside the decoder
+    // forward chain of step n + 1, on the CUs that chain leaves idle.  It is applied only where it fits there — estimated from
+    // the product's FLOPs at the rate the grouped GEMM reaches beside a chain (~2.4 TFLOP/s per CU, measured) against ~10 us per
+    // chain step; at R = 3584 the product (177 GFLOP) would take twice the chain's time and hold up the reconstructor's forward.
+    const int NA = (4 * h->H + h->A) / 16, wg = (NA > Bg ? NA : Bg) + 1, free_cus = h->ncu - wg;
+    const double rows = (double)((h->kind == RECNET_REC_LOCAL ? h->F : h->Tm) - 1) * h->B;
+    const double flops = 2.0 * 4.0 * h->R * (double)h->R * rows;
+    const double t_pending = free_cus > 0 ? flops / (free_cus * 2.4e6) : 1e30, t_chain = 10.0 * h->Tm * ((h->B + Bg - 1) / Bg);
+    h->split_ok = h->kind != RECNET_REC_NONE && h->persist_dec && h->lp && t_pending <= 0.9 * t_chain;
   }
   h->need = carve(h, nullptr);
   *out = h;

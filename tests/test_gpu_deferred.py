@@ -51,7 +51,7 @@ def _run(kind, prec, dims, deferred, lens_sets, order):
         enc, targets = GU.make_batch(B, F, D, V, lens, 9 + i)
         T, w = step.prepare(targets.numpy())
         graphs.append(R.GraphedStep(step, enc.cuda(), targets.cuda(), T, w, warmup=0, defer_reconstructor_update=deferred))
-        assert graphs[-1].deferred == (bool(deferred) and kind == "global")
+        assert graphs[-1].deferred == (bool(deferred) and (kind == "global" or deferred == "recurrent"))
     for i in order:
         losses.append(graphs[i]().clone())
     graphs[0].flush()
@@ -61,11 +61,13 @@ def _run(kind, prec, dims, deferred, lens_sets, order):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f32"])
-@pytest.mark.parametrize("kind", ["global"])
+@pytest.mark.parametrize("kind", ["global", "local"])
 @pytest.mark.parametrize("shape", list(SHAPES))
 @pytest.mark.parametrize("lengths", ["full", "alternating"])
 @pytest.mark.parametrize("mode", [True, "recurrent"])      # whole update deferred / only the recurrent weights' (mode 2)
 def test_deferred_update_equals_the_immediate_one_once_flushed(mode, lengths, shape, kind, prec):
+    if kind == "local" and mode is True:
+        pytest.skip("the whole-update mode exists for the global reconstructor")
     dims = SHAPES[shape]
     B = dims[0]
     rs = np.random.RandomState(1)
@@ -82,10 +84,10 @@ def test_deferred_update_equals_the_immediate_one_once_flushed(mode, lengths, sh
         order = [0, 1, 1, 0, 1, 0]
     # (mode "recurrent": the in-step half is a different grouped launch than the immediate update's — other split factors,
     # equal to fp32 rounding)
-    exact = (lengths == "full" or kind == "local") and mode is True
+    exact = lengths == "full" and mode is True
     d0, r0, l0 = _run(kind, prec, dims, False, sets, order)
     d1, r1, l1 = _run(kind, prec, dims, mode, sets, order)
-    assert np.allclose(l0[:, :7], l1[:, :7], rtol=1e-6, atol=0), (l0[:, 6], l1[:, 6])
+    assert np.allclose(l0[:, :7], l1[:, :7], rtol=1e-6 if mode is True else 3e-6, atol=0), (l0[:, 6], l1[:, 6])
     for k in d0:
         assert _same(d0[k], d1[k], k, True), ("decoder", k, float((d0[k] - d1[k]).abs().max()))
     for k in r0:
