@@ -57,9 +57,15 @@ struct DecChainArgs {
 // XF: frames 32 .. 47 of the caption's P block and Uv rows are served from (dynamic) LDS — the register file holds 32
 // frames; F <= 32 launches the XF = false instance with no dynamic LDS.
 #define DC_XF 16              // extra frames
-template <bool XF>
+// LW (round 4, F <= 32): the attention projection W h_{t-1} of a caption is computed BY ITS OWN workgroup — attn_W (128 x 512
+// bf16 = 128 KB) stays in LDS for the whole launch and h_{t-1}[b] never left the workgroup — so scores and context no longer
+// wait for phase A: the scores of step t + 1 are formed while the grid barrier of step t completes, the context MFMAs while
+// phase A's gate pre-activations travel, and only the cell waits for them.  Phase A shrinks to the 4H gate columns.
+template <bool XF, bool LW = false>
 __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
-  __shared__ float red[4 * RC_PAN_ROWS * DC_RED_LD];                 // phase A: 4 K-partials of the [112 x 16] tile
+  static_assert(!(XF && LW), "the LDS-resident attn_W and the LDS frames 32..47 do not fit together");
+  // phase A: K-partials of the [112 x 16] tile (LW: two buffers, summed in two stages — the room attn_W needs)
+  __shared__ float red[(LW ? 2 : 4) * RC_PAN_ROWS * DC_RED_LD];
   __shared__ __attribute__((aligned(16))) float spre[4 * 512];       // phase B: gate pre-activations
   __shared__ float swh[128];
   __shared__ __attribute__((aligned(16))) float sa[32 + DC_XF];
@@ -68,8 +74,18 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t hl[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, B = p.B, Bs = p.Bs, W4 = 4 * H, N = 4 * H + A;
-  const int NA = N >> 4;
+  const int NA = LW ? (W4 >> 4) : (N >> 4);
   const int wg = blockIdx.x;
+  bf16_t* wlds = reinterpret_cast<bf16_t*>(dc_dyn);      // LW: attn_W as [k / 8][128 a][8] (an MFMA B fragment = 16 bytes per lane, 256 contiguous bytes per 16 lanes)
+  if (LW) {
+    for (int c = tid; c < 64 * 128; c += 256) {
+      const int a = c & 127, kg = c >> 7;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (a < A && kg * 8 < H) v = *reinterpret_cast<const bf16x8*>(p.W + (size_t)(W4 + a) * p.ldw + kg * 8);
+      *reinterpret_cast<bf16x8*>(wlds + (size_t)c * 8) = v;
+    }
+    for (int j = tid; j < 512; j += 256) hl[j] = (bf16_t)0.f;
+  }
   const bool isA = wg < NA, isB = wg < B;
   const int kq = (lane >> 4) * 8;
   const size_t pan_t = rc_pan_elems(H);
@@ -151,6 +167,47 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
     return;
   }
 
+  // LW: attention projection and scores of step tt, from this caption's own h_{tt-1} (hl, bf16) — no other workgroup involved
+  auto lw_scores = [&](const int tt) {
+    if (tt > 0) {
+      // Wh[a] = sum_k attn_W[a][k] h[k]: 16x16x32 MFMAs with h in every row of the A operand (row 0 of the result is read);
+      // wave = two 16-column groups of the 128 attention columns
+      f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+      const int cg0 = 2 * wave;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks * 32 < H) {
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(hl + ks * 32 + (lane >> 4) * 8);
+          const bf16_t* wp = wlds + ((size_t)(ks * 4 + (lane >> 4)) * 128 + (lane & 15)) * 8;
+          w0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, *reinterpret_cast<const bf16x8*>(wp + (cg0 * 16) * 8), w0, 0, 0, 0);
+          w1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, *reinterpret_cast<const bf16x8*>(wp + (cg0 * 16 + 16) * 8), w1, 0, 0, 0);
+        }
+      }
+      if (lane < 16) { swh[cg0 * 16 + lane] = w0[0]; swh[cg0 * 16 + 16 + lane] = w1[0]; }
+    } else if (tid < 128) swh[tid] = 0.f;
+    __syncthreads();
+    if (tid < A) p.Wh[((size_t)tt * Bs + b) * A + tid] = swh[tid];
+    {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const int k = 16 * ko + i;
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(swab + 2 * k);          // (w_k, b_k, w_k+1, b_k+1)
+        s0 += wa[0] * rn_tanh(swh[k] + wa[1] + uvq[i]);
+        s1 += wa[2] * rn_tanh(swh[k + 1] + wa[3] + uvq[i + 1]);
+      }
+      sps[ko * 32 + sf] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const float sc = ((sps[tid] + sps[32 + tid]) + (sps[64 + tid] + sps[96 + tid])) + ((sps[128 + tid] + sps[160 + tid]) + (sps[192 + tid] + sps[224 + tid]));
+      sa[tid] = tid < F ? sc : 0.f;
+      if (tid < F && !p.softmax) p.att[((size_t)tt * Bs + b) * F + tid] = sc;
+    }
+    __syncthreads();
+    if (p.softmax) { attn_softmax_lds(sa, F, p.att + ((size_t)tt * Bs + b) * F); __syncthreads(); }
+  };
+  if (LW && isB) { __syncthreads(); lw_scores(0); }
   for (int t = 0; t < p.T; ++t) {
     // input part of the gates of this step: independent of the chain, requested before any waiting
     f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
@@ -179,12 +236,30 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int i = 0; i < RC_MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], wb[s], acc[i], 0, 0, 0);
-        float* part = red + wave * (RC_PAN_ROWS * DC_RED_LD);
         const int rr = (lane >> 4) * 4, cl = lane & 15;
+        if (LW) {
+          // waves 2, 3 hand their partials to waves 0, 1 through the two buffers, which then hold the two half sums
+          float* part = red + (wave & 1) * (RC_PAN_ROWS * DC_RED_LD);
+          if (wave >= 2) {
 #pragma unroll
-        for (int i = 0; i < RC_MB; ++i)
+            for (int i = 0; i < RC_MB; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * DC_RED_LD + cl] = acc[i][r];
+              for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * DC_RED_LD + cl] = acc[i][r];
+          }
+          __syncthreads();
+          if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < RC_MB; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * DC_RED_LD + cl] += acc[i][r];
+          }
+        } else {
+          float* part = red + wave * (RC_PAN_ROWS * DC_RED_LD);
+#pragma unroll
+          for (int i = 0; i < RC_MB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * DC_RED_LD + cl] = acc[i][r];
+        }
         __syncthreads();
         DC_TS(1);
         float* Gt = p.G1 + (size_t)t * B * N + wg * 16;
@@ -194,7 +269,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
           if (idx < RC_PAN_ROWS * 8 && row < B) {
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < (LW ? 2 : 4); ++w) {
               v0 += red[w * (RC_PAN_ROWS * DC_RED_LD) + row * DC_RED_LD + pc];
               v1 += red[w * (RC_PAN_ROWS * DC_RED_LD) + row * DC_RED_LD + pc + 1];
             }
@@ -231,11 +306,14 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       float pre[8];
       pre[0] = x0[0]; pre[1] = x0[1]; pre[2] = x0[2]; pre[3] = x0[3]; pre[4] = x1[0]; pre[5] = x1[1]; pre[6] = x1[2]; pre[7] = x1[3];
       float whv = 0.f;
+      // (LW: the scores of this step are already in `sa` — lw_scores ran before the barrier wait of the step before; the context
+      // MFMAs below come first and the gate pre-activations of phase A are polled after them)
+      auto poll_pre = [&]() {
       if (t > 0 && p.ll) {
         // poll this caption's words until every stamp is this step's
         const uint64_t* L = reinterpret_cast<const uint64_t*>(p.G1) + ((size_t)t * B + b) * N;
         const uint64_t* lc = L + (live ? col : 0);
-        const uint64_t* lw = L + W4 + (tid < A ? tid : 0);
+        const uint64_t* lw = LW ? lc : L + W4 + (tid < A ? tid : 0);      // (LW: phase A does not produce the attention columns)
         const unsigned want = ep | (unsigned)t;
         uint64_t wv[8], ww;
         unsigned spin = 0;
@@ -262,6 +340,9 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
         pre[0] += g0[0]; pre[1] += g0[1]; pre[2] += g0[2]; pre[3] += g0[3];
         pre[4] += g1[0]; pre[5] += g1[1]; pre[6] += g1[2]; pre[7] += g1[3];
       }
+      };
+      if (!LW) {
+      poll_pre();
       // all 128 entries: the score threads read swh[k] for every k of their column range (w_k = 0 beyond A, but 0 x garbage
       // from uninitialised LDS could be NaN)
       if (tid < 128) swh[tid] = tid < A ? whv : 0.f;
@@ -304,6 +385,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       }
       __syncthreads();
       if (p.softmax) { attn_softmax_lds(sa, F, p.att + ((size_t)t * Bs + b) * F); __syncthreads(); }
+      }      // !LW
       DC_TS(8);
       {
         // context of this wave's gate block: ctx[n] = sum_f a_f P[b, f, n] as MFMAs.  Rows 4i / 4i + 1 of the A operand are the
@@ -351,6 +433,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
           spre[g * 512 + r * 64 + lane] = (k0 * c0 + k1 * c1) + (k2 * c2 + k3 * c3);
         }
       }
+      if (LW) poll_pre();      // the gate pre-activations of phase A: they travelled while the context was formed
       if (live) {        // (the wave reads back what it wrote itself: LDS accesses of a wave are in order)
         const float invF = 1.0f / (float)F;
         float* dst = spre + g * 512 + lane * 8;
@@ -401,6 +484,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
           a[0] = av[jj][0]; a[H] = av[jj][1]; a[2 * H] = av[jj][2]; a[3 * H] = av[jj][3];
         }
       }
+      if (LW && t + 1 < p.T) lw_scores(t + 1);      // from hl = h_t, while the barrier completes
       if (t + 1 < p.T) { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
       DC_TS(7);
     } else if (t + 1 < p.T) {
