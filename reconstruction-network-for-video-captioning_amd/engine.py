@@ -484,7 +484,7 @@ class Engine:
             if t0 <= b <= e <= t1:                       # ran inside this step
                 chains[nm] = ((b - t0) / 100.0, (e - t0) / 100.0)
         groups = {}
-        for j, nm in enumerate(("prologue_products", "reconstructor_weight_gradients", "pending_recurrent_update", "decoder_weight_gradients", "recurrent_update_in_step")):
+        for j, nm in enumerate(("prologue_products", "reconstructor_weight_gradients", "pending_recurrent_update", "decoder_weight_gradients")):
             b, e = buf[14 + 2 * j], buf[15 + 2 * j]
             if t0 <= b <= e <= t1:
                 groups[nm] = ((b - t0) / 100.0, (e - t0) / 100.0)
