@@ -341,8 +341,8 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   // Lazy refresh of the reconstructor's derived weight images is OPT-IN: a caller that replays a captured fused step
   // and then calls a non-fused reconstructor entry point would otherwise read stale transposes unless it calls recnet_mark_pending.
   // The default step of this library — the split update, mode 2 — rewrites the images where it updates the weights.
-  h->lazy_images = getenv("RN_LAZY_IMAGES") ? atoi(getenv("RN_LAZY_IMAGES")) : 0;
-  h->gemm_single_group = getenv("RN_GEMM_SINGLE") ? atoi(getenv("RN_GEMM_SINGLE")) : 0;
+  h->lazy_images = 0;
+  h->gemm_single_group = 0;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
   // equal size (at most RN_MAX_ROW_GROUPS of them) and every chain runs once per group, one launch after the other: a group is
@@ -413,8 +413,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
                          nwb <= h->ncu && nwb - 1 <= 256;
   }
   {
-    const char* e = getenv("RN_DEC_BWD_NT");
-    h->use_wcomb_t = (e ? atoi(e) : 1) && h->lp && (h->B <= 128 || Bg < h->B);
+    h->use_wcomb_t = h->lp && (h->B <= 128 || Bg < h->B);
     const char* eb = getenv("RN_PERSIST_DEC_BWD");
     int dev = 0, ncu = 0;
     hipGetDevice(&dev);
@@ -525,16 +524,9 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * 4));
   h->gws_cur = h->gws;
   if (!h->s2) {
-    const char* ov = getenv("RN_OVERLAP");
-    h->overlap = ov ? atoi(ov) : 1;
-    // RN_SIDE_PRIO=1: the side stream at the lowest priority, so that work on the caller's stream (the chains and what they
-    // wait for) wins the CUs when both have workgroups to place
-    const char* pr = getenv("RN_SIDE_PRIO");
-    int lo = 0, hi = 0;
-    if (pr && atoi(pr) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
-      HIPCHK(hipStreamCreateWithPriority(&h->s2, hipStreamNonBlocking, lo));
-    else
-      HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
+    h->overlap = 1;
+    // (a lowest-priority side stream was measured in round 4: 2.63 against 1.82 ms — the side work is on the critical path often enough)
+    HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
     for (int i = 0; i < 24; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));
   }

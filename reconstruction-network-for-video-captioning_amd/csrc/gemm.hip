@@ -134,8 +134,8 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
     else if (!a_bf16 && b_bf16) launch_layout<bf16_t, float, bf16_t>(a, a_col, b_col, grid, st, tag);
     else if (a.a_vec && a.b_vec) {
       // forward-form chain launches (activations x weights^T, M <= 128, K slice <= 6 k-tiles): single round trip kernel
-      static int chain_on = getenv("RN_GEMM_CHAIN") ? atoi(getenv("RN_GEMM_CHAIN")) : 1;
-      static int chain_ng = getenv("RN_GEMM_CHAIN_NG") ? atoi(getenv("RN_GEMM_CHAIN_NG")) : 0;
+      static int chain_on = 1;
+      static int chain_ng = 0;
       if (chain_on && tag_chain && !a_col && !b_col && M <= 128 && per <= GC_MAX_KT && !c_bf16 && !c2) {
         // 128-column workgroups unless that leaves half the chip idle (e.g. the decoder's N = 4H + A = 2176)
         const int ng = chain_ng ? chain_ng : ((((N + 127) / 128) * splitk >= 128) ? 2 : 1);
@@ -145,11 +145,11 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
       // both operands bf16 in memory: the DMA-staged ring kernel.  Chain launches (tag > 0) run ~1 block
       // per CU and want the deepest ring; batched GEMMs trade ring depth for 2 resident blocks per CU.
       static int ns_chain = getenv("RN_GEMM_NS_CHAIN") ? atoi(getenv("RN_GEMM_NS_CHAIN")) : 4;
-      static int ns_batch = getenv("RN_GEMM_NS_BATCH") ? atoi(getenv("RN_GEMM_NS_BATCH")) : 2;
+      static int ns_batch = 2;
       const int ns = tag ? ns_chain : ns_batch;
       {
         // chain launch, row/row: 96-column workgroups when that turns a partial wave of workgroups into one per CU
-        static int bn96 = getenv("RN_GEMM_BN96") ? atoi(getenv("RN_GEMM_BN96")) : 1;
+        static int bn96 = 1;
         const int t128 = ((N + 127) / 128) * ((M + 127) / 128) * splitk, t96 = ((N + 95) / 96) * ((M + 127) / 128) * splitk;
         if (bn96 && tag == RN_TAG_REC_FWD && !a_col && !b_col && ns >= 4 && N % 96 == 0 && t128 < 224 && t96 <= 256) {
           launch_lds_96<4, RN_TAG_REC_FWD>(a, st);
@@ -210,7 +210,7 @@ double list_makespan(const std::vector<std::pair<double, int>>& runs, int slots)
 
 int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float* ws, size_t ws_floats, unsigned* cnt, int cnt_words,
                          hipStream_t st, int slots_hint, const AdamShared* adam, unsigned long long* stamp) {
-  static const int on = getenv("RN_GEMM_GROUP") ? atoi(getenv("RN_GEMM_GROUP")) : 1;
+  const int on = getenv("RN_GEMM_GROUP") ? atoi(getenv("RN_GEMM_GROUP")) : 1;      // (read per call: the tests flip it inside one process)
   if (!on || n < 1 || n > GG_MAX) return 1;
   struct Prob { int idx, tiles, nkt, s; };
   std::vector<Prob> pr;
