@@ -716,15 +716,25 @@ __device__ __forceinline__ void lcb_xsplit_role(const LocChainBwdArgs& p, float*
     __syncthreads();
     if (xi == 0) LC_TS(5, q, 1);
     float* Dq = p.Dx + ((size_t)q * p.KSX + kp) * B * H;
-    for (int idx = tid; idx < OWN * (UWX / 2); idx += 256) {
-      const int rg = own_lo + idx / (UWX / 2), pc = (idx % (UWX / 2)) * 2, rl = rg - r0;
+    // four columns per thread, one 16-byte write-through store (round 3 shipped two columns / 8-byte stores after a 4-column form
+    // aborted the forced-split small-shape tests; round 4 rebuilt it with every index checked — see LCB_CHECK below and DESIGN.md)
+    for (int idx = tid; idx < OWN * (UWX / 4); idx += 256) {
+      const int rg = own_lo + idx / (UWX / 4), pc = (idx % (UWX / 4)) * 4, rl = rg - r0;
       if (rg < B && j0 + pc < H) {
-        float v0 = 0.f, v1 = 0.f;
+        float* dst = Dq + (size_t)rg * H + j0 + pc;
+        // LCB_CHECK: row of the reduction buffer inside the tile, the four columns inside H, a 16-byte-aligned address inside this
+        // step's [KSX][B][H] block — a violation raises the chain's sticky word (the step reports NaN) instead of writing
+        const bool ok = rl >= 0 && rl < ROWS && j0 + pc + 3 < H && (((uintptr_t)dst) & 15) == 0 &&
+                        ((size_t)q * p.KSX + kp) * B * H + (size_t)rg * H + j0 + pc + 3 < (size_t)F * p.KSX * B * H;
+        if (!ok) { __hip_atomic_store(p.bar + 257, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { v0 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc]; v1 += red[w * (ROWS * RED_LD) + rl * RED_LD + pc + 1]; }
-        union { float f[2]; uint64_t u; } pk;
-        pk.f[0] = v0 * drop_at(p.dd, key, s, rg, H, j0 + pc); pk.f[1] = v1 * drop_at(p.dd, key, s, rg, H, j0 + pc + 1);
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(Dq + (size_t)rg * H + j0 + pc), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += red[w * (ROWS * RED_LD) + rl * RED_LD + pc + e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= drop_at(p.dd, key, s, rg, H, j0 + pc + e);
+        rc_store16f(dst, v);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -78,7 +78,7 @@ class DeviceFeeder:
       caller stream : waits for the slot's copy event only.
     The returned tensors are the slot's device buffers: they are valid until the call after next."""
 
-    def __init__(self, batches, device, caption_max_len=30, shard=None, depth=3, threaded=True):
+    def __init__(self, batches, device, caption_max_len=30, shard=None, depth=3, threaded=True, ahead=1):
         import queue
         import threading
         from .api import decode_len, step_weights
@@ -87,7 +87,8 @@ class DeviceFeeder:
         self.device = torch.device(device)
         self.Tm = caption_max_len + 1
         self.shard = shard
-        self.depth = max(2, depth)
+        self.ahead = max(1, int(ahead))                  # H2D copies kept in flight beyond the batch being handed out
+        self.depth = max(self.ahead + 2, depth)
         self.stream = torch.cuda.Stream(device=self.device)
         self.free, self.staged = queue.Queue(), queue.Queue()
         self.inflight, self._last, self._done = [], None, False
@@ -99,12 +100,23 @@ class DeviceFeeder:
 
     # ---- worker thread: host-only work
     def _new_slot(self, eshape, tshape):
-        s = dict(enc_h=torch.empty(eshape, dtype=torch.float32).pin_memory(),
-                 tg_h=torch.empty(tshape, dtype=torch.int64).pin_memory(),
-                 w_h=torch.zeros(self.Tm, dtype=torch.float32).pin_memory(),
-                 enc_d=torch.empty(eshape, dtype=torch.float32, device=self.device),
-                 tg_d=torch.empty(tshape, dtype=torch.int64, device=self.device),
-                 w_d=torch.empty(self.Tm, dtype=torch.float32, device=self.device), ev=None, copied=None)
+        # ONE pinned staging blob and ONE device blob per slot (features | targets | step weights, each 256-byte aligned): a batch
+        # is one H2D copy — three copies per batch cost the copy stream and the host three launches for 17 MB + 25 KB + 124 B
+        import math
+        ne, nt = int(np.prod(eshape)) * 4, int(np.prod(tshape)) * 8
+        o_t = (ne + 255) // 256 * 256
+        o_w = o_t + (nt + 255) // 256 * 256
+        total = o_w + (self.Tm * 4 + 255) // 256 * 256
+        blob_h = torch.empty(total, dtype=torch.uint8).pin_memory()
+        blob_d = torch.empty(total, dtype=torch.uint8, device=self.device)
+
+        def views(blob):
+            return (blob[:ne].view(torch.float32).view(*eshape), blob[o_t:o_t + nt].view(torch.int64).view(*tshape),
+                    blob[o_w:o_w + self.Tm * 4].view(torch.float32))
+        eh, th, wh = views(blob_h)
+        ed, td, wd = views(blob_d)
+        wh.zero_()
+        s = dict(blob_h=blob_h, blob_d=blob_d, enc_h=eh, tg_h=th, w_h=wh, enc_d=ed, tg_d=td, w_d=wd, ev=None, copied=None)
         s["enc_n"], s["tg_n"], s["w_n"] = s["enc_h"].numpy(), s["tg_h"].numpy(), s["w_h"].numpy()
         return s
 
@@ -163,9 +175,7 @@ class DeviceFeeder:
         with torch.cuda.stream(self.stream):
             if s["ev"] is not None:
                 self.stream.wait_event(s["ev"])          # the step that read these device buffers has finished
-            s["enc_d"].copy_(s["enc_h"], non_blocking=True)
-            s["tg_d"].copy_(s["tg_h"], non_blocking=True)
-            s["w_d"].copy_(s["w_h"], non_blocking=True)
+            s["blob_d"].copy_(s["blob_h"], non_blocking=True)
             s["copied"] = torch.cuda.Event()
             s["copied"].record(self.stream)
         self.inflight.append((s, T))
@@ -185,7 +195,8 @@ class DeviceFeeder:
         if not self.inflight and not self._issue(block=True):
             raise StopIteration
         s, T = self.inflight.pop(0)
-        self._issue(block=False)                         # next batch's H2D goes out before this step is enqueued
+        while len(self.inflight) < self.ahead and self._issue(block=False):      # the next batches' H2D go out before this step is enqueued
+            pass
         torch.cuda.current_stream().wait_event(s["copied"])
         self._last = s
         return s["enc_d"], s["tg_d"], T, s["w_d"][:T]
