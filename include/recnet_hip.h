@@ -274,6 +274,14 @@ int recnet_flush(recnet_handle* h, void* stream);
  * reconstructor. */
 int recnet_mark_pending(recnet_handle* h);
 
+/* Data-parallel step inside ONE stream-ordered sequence (or one captured graph): with on != 0, part 1 of
+ * recnet_train_step_part_dev returns with the reconstructor's weight-gradient products still running on the library's side
+ * stream; recnet_join_side makes `stream` — the stream the caller launches the all-reduce of the reconstructor bucket from — wait
+ * for them, while the caller's main stream goes straight on to part 2 (the decoder's BPTT).  Without it part 1 waits for those
+ * products itself (+0.2 ms in front of the BPTT at the benchmark shape).  train.py:264-273; SURVEY.md section 8e. */
+int recnet_set_dp_overlap(recnet_handle* h, int32_t on);
+int recnet_join_side(recnet_handle* h, void* stream);
+
 /* ---- plumbing exposed for tests and profiling */
 /* Between begin and end every recurrent-step GEMM launch of one site (the dependent-chain kernels: one
  * per decoder / reconstructor time step) is bracketed by hipEvents on its stream; end() synchronises and

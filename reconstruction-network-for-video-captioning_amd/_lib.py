@@ -135,6 +135,8 @@ EXPORTS["recnet_profile_null_launch"] = (_i, [C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_gemm_group_bf16"] = (_i, [_i, _i, _i, C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(C.c_void_p), C.POINTER(_i),
                                          C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(_i),
                                          C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i), C.c_void_p, C.c_int64, C.c_void_p, _i, C.c_void_p])
+EXPORTS["recnet_set_dp_overlap"] = (_i, [C.c_void_p, _i])
+EXPORTS["recnet_join_side"] = (_i, [C.c_void_p, C.c_void_p])
 EXPORTS["recnet_read_stamps"] = (_i, [C.c_void_p, C.POINTER(C.c_uint64), _i, C.c_void_p])
 EXPORTS["recnet_gemm_bf16"] = (_i, [C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _f, _i, _i,
                                   C.c_void_p, _i, C.c_void_p])

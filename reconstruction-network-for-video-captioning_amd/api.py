@@ -513,6 +513,7 @@ class GraphedStep:
         self.seed_base = st.seed_base
         self.flags = _lib.OPT_REG | _lib.OPT_CLIP
         self.split = bool(dp_step.reduce)
+        self._comm = None
         eng = self.eng
         recurrent_only = defer_reconstructor_update in (2, "recurrent")
         self.deferred = (bool(defer_reconstructor_update) and not self.split and self.rs is not None and
@@ -538,15 +539,61 @@ class GraphedStep:
                 eng.train_step_dev(self.enc, self.targets, self.T, self.w, self.seed_base, self.flags)
             self.graphs = [g]
         else:
-            for part in (1, 2):
+            # ONE graph with the collectives captured inside it (RCCL kernels are capturable; round 4) — one replay per step
+            # instead of three with two eager collectives between them.  RN_DP_ONE_GRAPH=0, or a backend whose collectives
+            # cannot be captured (gloo in the CPU tests), takes the three-graph form.
+            import os as _os
+            self.one_graph = False
+            # (ring transport only: the direct reduce-scatter form stages through plain torch ops on a side stream of its own)
+            if int(_os.environ.get("RN_DP_ONE_GRAPH", "1")) and self.enc.is_cuda and dp_step.transport.algo == "ring":
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, **mode):
+                        self._dp_body()
+                    self.graphs = [g]
+                    self.one_graph = True
+                except Exception as e:          # noqa: BLE001  (the capture is abandoned; nothing ran)
+                    import warnings
+                    warnings.warn("one-graph data-parallel step unavailable (%s): three graphs + eager collectives" % (e,))
+                    torch.cuda.synchronize()
+                    self.graphs = []
+            if not self.one_graph:
+                for part in (1, 2):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, **mode):
+                        eng.train_step_part_dev(part, self.enc, self.targets, self.T, self.w, self.seed_base)
+                    self.graphs.append(g)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, **mode):
-                    eng.train_step_part_dev(part, self.enc, self.targets, self.T, self.w, self.seed_base)
+                    eng.optimizer_step_dev(self.flags)
                 self.graphs.append(g)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **mode):
-                eng.optimizer_step_dev(self.flags)
-            self.graphs.append(g)
+
+    def _dp_body(self):
+        """The data-parallel step in stream order: part 1 (forward, reconstructor backward) -> early buckets on the wire ->
+        part 2 (decoder BPTT + its weight gradients) -> late bucket -> wait -> optimiser.  Eager, or captured as one graph."""
+        # the early buckets go out from a stream of their own that waits for the library's side stream (the reconstructor's weight
+        # gradients are still being formed there): this stream goes straight on to the decoder's BPTT
+        cur = torch.cuda.current_stream()
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        self.eng.set_dp_overlap(True)
+        try:
+            self.eng.train_step_part_dev(1, self.enc, self.targets, self.T, self.w, self.seed_base)
+        finally:
+            self.eng.set_dp_overlap(False)
+        self._comm.wait_stream(cur)
+        with torch.cuda.stream(self._comm):
+            self.eng.join_side()
+            works = self._reduce_async(self.dp.early_buffers())
+        # (Tried in round 4 and left out: the reconstructor's Adam step on that stream as soon as its bucket is reduced, i.e. beside
+        # the BPTT like in the single-rank step — hipStreamEndCapture of the resulting graph segfaults in the HIP runtime of
+        # ROCm 7.2, so both optimiser steps stay at the end.)
+        self.eng.train_step_part_dev(2, self.enc, self.targets, self.T, self.w, self.seed_base)
+        works += self._reduce_async(self.dp.late_buffers())
+        for w in works:
+            self.dp.transport.finish(w)
+        cur.wait_stream(self._comm)
+        self.eng.optimizer_step_dev(self.flags)
 
     def flush(self):
         """Completes a pending deferred reconstructor update (stream-ordered, no host sync); a no-op otherwise."""
@@ -581,6 +628,8 @@ class GraphedStep:
         if not self.split:
             self.graphs[0].replay()
             self.eng.mark_pending()          # (a replay runs no host code: the handle's lazily refreshed weight images / a deferred update)
+        elif self.one_graph:
+            self.graphs[0].replay()
         else:
             ga, gb, gc = self.graphs
             ga.replay()

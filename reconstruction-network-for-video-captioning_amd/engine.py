@@ -278,6 +278,13 @@ class Engine:
         mode = 2 if on in (2, "recurrent") else int(bool(on))      # 2: only the recurrent weights' update is deferred
         _lib.check(self.lib.recnet_set_deferred_reconstructor_update(self.handle, mode, _stream()), "recnet_set_deferred_reconstructor_update")
 
+    def set_dp_overlap(self, on):
+        _lib.check(self.lib.recnet_set_dp_overlap(self.handle, int(bool(on))), "recnet_set_dp_overlap")
+
+    def join_side(self):
+        """The current stream waits for the library's side stream (recnet_join_side)."""
+        _lib.check(self.lib.recnet_join_side(self.handle, _stream()), "recnet_join_side")
+
     def mark_pending(self):
         _lib.check(self.lib.recnet_mark_pending(self.handle), "recnet_mark_pending")
 

@@ -36,8 +36,9 @@ def _models(kind, prec):
     return R, dec, rec, enc, targets
 
 
-def _worker_nccl(port, kind, prec, grad_dtype, grad_algo, q):
+def _worker_nccl(port, kind, prec, grad_dtype, grad_algo, q, one_graph=True):
     import torch.distributed as dist
+    os.environ["RN_DP_ONE_GRAPH"] = "1" if one_graph else "0"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -47,7 +48,9 @@ def _worker_nccl(port, kind, prec, grad_dtype, grad_algo, q):
                                    grad_algo=grad_algo)
     T, w = step.prepare(targets.numpy())
     run = R.GraphedStep(step, enc.cuda(), targets.cuda(), T, w, warmup=1)
-    assert run.split and len(run.graphs) == 3
+    # round 4: ONE graph with the RCCL collectives captured inside it; RN_DP_ONE_GRAPH=0: three graphs, eager collectives between them
+    one_graph = one_graph and step.transport.algo == "ring"      # (the direct transport keeps the three-graph form)
+    assert run.split and run.one_graph == one_graph and len(run.graphs) == (1 if one_graph else 3)
     for _ in range(2):
         sc = run()
     torch.cuda.synchronize()
@@ -60,14 +63,15 @@ def _worker_nccl(port, kind, prec, grad_dtype, grad_algo, q):
 
 @pytest.mark.parametrize("grad_dtype,grad_algo", [("f32", None), ("f32", "direct"), ("bf16", None)])
 @pytest.mark.parametrize("kind,prec", [("global", "bf16"), ("local", "bf16"), ("global", "f32")])
-def test_three_graph_step_on_rccl_world_size_one_matches_the_one_graph_step(kind, prec, grad_dtype, grad_algo):
+@pytest.mark.parametrize("one_graph", [True, False])
+def test_data_parallel_step_on_rccl_world_size_one_matches_the_single_rank_step(one_graph, kind, prec, grad_dtype, grad_algo):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_worker_nccl, args=(port, kind, prec, grad_dtype, grad_algo, q))
+    p = ctx.Process(target=_worker_nccl, args=(port, kind, prec, grad_dtype, grad_algo, q, one_graph))
     p.start()
-    sc3, dec3, rec3, status = q.get(timeout=600)
+    sc3, dec3, rec3, status = q.get(timeout=180)
     p.join(timeout=120)
     assert p.exitcode == 0 and status == 0
     # the single-rank step: one graph, no collective
