@@ -145,7 +145,10 @@ def test_bptt_chain_beside_a_resident_collective_kernel():
     # occupier's remaining time in one run of three.  What the reserve guarantees is residency, i.e. no give-up.)
     # (2) no reserve and MORE CUs taken than the chain can spare (it needs ~H/16*4+1 of them; all but 16 are held for 6 ms):
     # the resident part of the chain spins — bounded — until the occupier leaves, then the step completes, same gradients
-    g2, st2, ms2 = _bptt_beside(ncu - 16, 6000, 0)
+    for attempt in range(4):      # (whether the occupier is resident when part 2 starts is a race of two streams: retry until it was)
+        g2, st2, ms2 = _bptt_beside(ncu - 16, 6000, 0)
+        if ms2 > 3.0:
+            break
     assert st2 == 0, "chain gave up instead of waiting for the CUs to free up (status 0x%x)" % st2
     for grp in g0:
         for k in g0[grp]:
