@@ -436,8 +436,11 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const int NA = (4 * h->H + h->A) / 16, wg = (NA > Bg ? NA : Bg) + 1, free_cus = h->ncu - wg;
     const double rows = (double)((h->kind == RECNET_REC_LOCAL ? h->F : h->Tm) - 1) * h->B;
     const double flops = 2.0 * 4.0 * h->R * (double)h->R * rows;
-    const double t_pending = free_cus > 0 ? flops / (free_cus * 2.4e6) : 1e30, t_chain = 10.0 * h->Tm * ((h->B + Bg - 1) / Bg);
-    h->split_ok = h->kind != RECNET_REC_NONE && h->persist_dec && h->lp && t_pending <= 0.9 * t_chain;
+    // (x 1.36: the Adam epilogue of the product — calibrated on C2: 58.5 GFLOP + 9.4 M parameters in 279 us on 119 CUs.
+    // Leaving only SOME gate blocks of W_hh pending at R = 3584 was tried in round 4: the fragment images of the R > 2048 chains
+    // have to be re-packed behind either half, and the step got slower, 3.49 against 3.29 ms.)
+    const double t_pending = free_cus > 0 ? 1.36 * flops / (free_cus * 2.4e6) : 1e30, t_chain = 0.95 * 10.0 * h->Tm * ((h->B + Bg - 1) / Bg);
+    h->split_ok = h->kind != RECNET_REC_NONE && h->persist_dec && h->lp && t_pending <= t_chain;
   }
   h->need = carve(h, nullptr);
   *out = h;
