@@ -75,6 +75,33 @@ __global__ void norm_finalize_kernel(const float* __restrict__ norms, int n, flo
     *clip_out = c;
   }
 }
+// tensor_norm_kernel + norm_finalize_kernel in one launch of one workgroup (<= 16 tensors, a few hundred chunk partials each): the
+// per-tensor norms out_norm[i] in the same summation order, then total / clip / sum — one launch less on the step's tail
+__global__ __launch_bounds__(256) void norm_all_kernel(const TensorDesc* __restrict__ tab, const float* __restrict__ partial, int ntens,
+                                                       float* __restrict__ out_norm, float max_norm, float* total_out, float* clip_out,
+                                                       float* sum_out) {
+  __shared__ float sm[4];
+  __shared__ float nrm[16];
+  for (int i = 0; i < ntens; ++i) {
+    const TensorDesc td = tab[i];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < td.nchunks; c += 256) s += partial[td.chunk0 + c];
+    s = block_sum256(s, sm);
+    if (threadIdx.x == 0) { nrm[i] = sqrtf(s); out_norm[i] = nrm[i]; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  float ss = 0.f, sn = 0.f;
+  for (int i = 0; i < ntens; ++i) { ss += nrm[i] * nrm[i]; sn += nrm[i]; }
+  const float tot = sqrtf(ss);
+  if (total_out) *total_out = tot;
+  if (sum_out) *sum_out = sn;
+  if (clip_out) {
+    float c = 1.f;
+    if (max_norm > 0.f) { c = max_norm / (tot + 1e-6f); if (c > 1.f) c = 1.f; }
+    *clip_out = c;
+  }
+}
 // g += coef * p / ||p||   (autograd-compatible path: the regulariser's gradient, train.py:69-70)
 __global__ __launch_bounds__(256) void add_reg_grad_kernel(const TensorDesc* __restrict__ tab, const int2* __restrict__ chunks,
                                                            const float* __restrict__ pnorm, float coef) {

@@ -389,6 +389,55 @@ __global__ __launch_bounds__(128) void embed_fwd_kernel(const float* __restrict_
   AT* dst = emb + (size_t)row * ld;
   for (int j = threadIdx.x; j < ld; j += 128) dst[j] = (AT)(j < E ? src[j] * scale * drop_at(dd, key, t, b, E, j) : 0.f);
 }
+// The decoder prologue's three small kernels as ONE launch (bf16 path, fused step): blocks [0, nb_pack) cast the features to
+// the bf16 operand copy (16-byte loads, 8-byte stores), the next ceil(rowsT / 2) blocks gather two embedding rows each, the last
+// block forms the gate bias b_ih + b_hh — no fork / join of two streams in front of the grouped product that consumes all three.
+struct ProPackArgs {
+  bf16_t* enc_lp; int ld_enc; const float* enc; int rowsE, D;
+  const float* Emb; const int64_t* targets; bf16_t* emb; int ld_emb, B, E, V; float scale; DropDesc dd; int rowsT;
+  const float* bih; const float* bhh; float* bsum; int Hd, gru;
+  int nb_pack;
+};
+__global__ __launch_bounds__(256) void prologue_pack_kernel(const ProPackArgs p) {
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk < p.nb_pack) {
+    if ((p.D & 3) == 0 && (p.ld_enc & 3) == 0 && ((((uintptr_t)p.enc) | ((uintptr_t)p.enc_lp)) & 15) == 0) {
+      const int q4 = p.ld_enc >> 2;                       // quads per destination row
+      const size_t total = (size_t)p.rowsE * q4;
+      for (size_t i = (size_t)blk * 256 + tid; i < total; i += (size_t)p.nb_pack * 256) {
+        const int r = (int)(i / q4), c = (int)(i % q4) * 4;
+        bf16x4 o = {0, 0, 0, 0};
+        if (c < p.D) { const f32x4 v = *reinterpret_cast<const f32x4*>(p.enc + (size_t)r * p.D + c); o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3]; }
+        *reinterpret_cast<bf16x4*>(p.enc_lp + (size_t)r * p.ld_enc + c) = o;
+      }
+    } else {
+      const size_t total = (size_t)p.rowsE * p.ld_enc;
+      for (size_t i = (size_t)blk * 256 + tid; i < total; i += (size_t)p.nb_pack * 256) {
+        const int r = (int)(i / p.ld_enc), c = (int)(i % p.ld_enc);
+        p.enc_lp[i] = (bf16_t)(c < p.D ? p.enc[(size_t)r * p.D + c] : 0.f);
+      }
+    }
+    return;
+  }
+  const int eb = blk - p.nb_pack, neb = (p.rowsT + 1) >> 1;
+  if (eb < neb) {
+    const int row = eb * 2 + (tid >> 7), t128 = tid & 127;
+    if (row >= p.rowsT) return;
+    const int t = row / p.B, b = row % p.B;
+    long tok = t == 0 ? 1 : p.targets[(size_t)(t - 1) * p.B + b];
+    tok = tok < 0 ? 0 : (tok >= p.V ? p.V - 1 : tok);
+    const uint32_t key = drop_key(p.dd);
+    const float* src = p.Emb + (size_t)tok * p.E;
+    bf16_t* dst = p.emb + (size_t)row * p.ld_emb;
+    for (int j = t128; j < p.ld_emb; j += 128) dst[j] = (bf16_t)(j < p.E ? src[j] * p.scale * drop_at(p.dd, key, t, b, p.E, j) : 0.f);
+    return;
+  }
+  for (int i = tid; i < 4 * p.Hd; i += 256) {
+    if (!p.gru) { p.bsum[i] = p.bih[i] + p.bhh[i]; continue; }
+    const int g = i / p.Hd;
+    p.bsum[i] = g < 2 ? p.bih[i] + p.bhh[i] : (g == 2 ? p.bih[i] : p.bhh[i - p.Hd]);
+  }
+}
 // input token of decoder step t for caption b: the tokens that were actually fed when a free-running forward recorded
 // them (in_tok [T][B], train.py:47-51), else teacher forcing: <SOS> at t = 0, targets[t-1] after (train.py:25,45)
 __device__ __forceinline__ long rn_input_token(const int64_t* __restrict__ in_tok, const int64_t* __restrict__ targets, int t, int b,

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): bench lines, rocprofv3 kernel statistics, step timelines and PMC traffic passes of the GPU
-# configurations of BASELINE.json, written under gpurun_out/r03/ (copied into profiles/ afterwards).
+# configurations of BASELINE.json, written under gpurun_out/r04/ (copied into profiles/ afterwards).
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-RND=r03
+RND=r04
 O=gpurun_out/$RND; mkdir -p $O
 run() {  # name "bench args" extra
   local n=$1 args="$2"
@@ -51,6 +51,17 @@ RN_LOC_HYBRID=0 python3 bench.py $C5 $x > $O/bench_c5_per_step_forward.json 2>/d
 # PCIe-inclusive rate (never `value`): every step takes a fresh host batch through feed.DeviceFeeder
 python3 bench.py --feed 1 $x > $O/bench_c2_host_feed.json 2>/dev/null
 python3 bench.py --defer 1 $x > $O/bench_c2_deferred_reconstructor_update.json 2>/dev/null
+# the step with everything inside it (round 3's form) and the switches of round 4, one at a time
+python3 bench.py --defer 0 $x > $O/bench_c2_update_inside_the_step.json 2>/dev/null
+python3 bench.py --rec local --defer 0 $x > $O/bench_c3_update_inside_the_step.json 2>/dev/null
+RN_GEMM_GROUP=0 python3 bench.py $x > $O/bench_c2_no_grouped_launches.json 2>/dev/null
+RN_DEC_LOCAL_WH=0 python3 bench.py $x > $O/bench_c2_attention_projection_in_phase_A.json 2>/dev/null
+RN_ADAM_EPILOGUE=0 python3 bench.py $x > $O/bench_c2_adam_kernel_instead_of_epilogue.json 2>/dev/null
+RN_WAIT_CHAIN=0 python3 bench.py $x > $O/bench_c2_no_residency_waits.json 2>/dev/null
+# the data-parallel step at ONE rank (no byte crosses xGMI): one captured graph with the collectives inside / three graphs
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --force-allreduce $x > $O/bench_c2_dp_one_rank_one_graph.json 2>/dev/null
+RN_DP_ONE_GRAPH=0 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --force-allreduce $x > $O/bench_c2_dp_one_rank_three_graphs.json 2>/dev/null
+for i in 2 3; do python3 bench.py --feed 1 $x > $O/bench_c2_host_feed_$i.json 2>/dev/null; python3 bench.py $x > $O/bench_c2_resident_$i.json 2>/dev/null; done
 python3 tools/rccl_bucket_bench.py > $O/rccl_buckets_1rank_c2.json 2>/dev/null
 # in-kernel stamps of the chain kernels (probe build of the library)
 RN_LIB_PROBE=1 python3 tools/loc_chain_probe.py 100 28 1536 > $O/chain_probe_c3.txt 2>/dev/null
