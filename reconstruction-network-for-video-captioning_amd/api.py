@@ -545,7 +545,9 @@ class GraphedStep:
             import os as _os
             self.one_graph = False
             # (ring transport only: the direct reduce-scatter form stages through plain torch ops on a side stream of its own)
-            if int(_os.environ.get("RN_DP_ONE_GRAPH", "1")) and self.enc.is_cuda and dp_step.transport.algo == "ring":
+            import torch.distributed as _dist
+            nccl = _dist.is_available() and _dist.is_initialized() and _dist.get_backend(dp_step.group) == "nccl"
+            if int(_os.environ.get("RN_DP_ONE_GRAPH", "1")) and self.enc.is_cuda and dp_step.transport.algo == "ring" and nccl:
                 try:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, **mode):

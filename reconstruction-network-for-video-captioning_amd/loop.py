@@ -37,7 +37,8 @@ class Trainer:
         # opt-in (measured slower at the benchmark shape): graph steps on one rank leave the
         # reconstructor's update pending for the next step to run under its decoder forward chain (api.GraphedStep);
         # flush() completes it wherever the parameters are read (validation, checkpoints, the end of fit)
-        self.defer = bool(defer_reconstructor_update) and world_size == 1 and use_graphs and self.reconstructor is not None
+        # (True: the whole update, global reconstructor; "recurrent": the split update of round 4 — d W_hh and its Adam step only)
+        self.defer = defer_reconstructor_update if (defer_reconstructor_update and world_size == 1 and use_graphs and self.reconstructor is not None) else False
         self._graphs, self._static = {}, None
         self.iteration = 0
         self._eager_until = eager_steps       # optimiser step count up to which steps are launched eagerly
