@@ -113,15 +113,18 @@ def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
              (1, 0, "gemm_chain_kernel (recurrent-step GEMM, decoder fwd, one launch per step)"),
              (3, 1, "gemm_lds_kernel<false, false, 4, 3, 96> (recurrent-step GEMM, reconstructor fwd, one launch per step)"),
              (4, 2, "gemm_lds_kernel<false, true, 4, 4, 128> (recurrent-step GEMM, reconstructor bwd, one launch per step)")]
-    chains, per_step, meas = {}, {}, []
+    chains, per_step, meas, covered = {}, {}, [], set()
     for s_id, wh, nm in cands:
         if wh in (1, 2, 3, 4) and kind is None:
+            continue
+        if s_id in covered:                      # the chain kernel of this recurrence ran: its per-step GEMM site has no launches
             continue
         n_, ms_ = run_step(s_id)
         if n_ > 0:
             short = nm.split(" ")[0].split("<")[0]
             if s_id >= 7:
                 chains[short] = round(ms_ * 1e3, 1)
+                covered.add({9: 1, 10: 2, 7: 3, 8: 4}[s_id])
             per_step["site %d: %s" % (s_id, nm.split(" (")[0])] = {"launches_per_step": n_, "avg_us": round(ms_ * 1e3, 1),
                                                                     "us_per_step": round(n_ * ms_ * 1e3, 1)}
             meas.append((n_, ms_, s_id, wh, nm))
@@ -131,7 +134,7 @@ def roofline(eng, run_step, kind, precision, iters=5, T=31, cell="LSTM"):
     n, ms_raw, site, which, kname = ranked[0]                 # the true maximum; the runner-up is listed beside it
     runner_up = ranked[1][4].split(" (")[0] if len(ranked) > 1 else None
     # What the two event records add to a bracket (E), from brackets around 1 and around 17 empty kernels in the same
-    # mode (graph nodes / eager): b(c) = E + c * f.  The kernel's dispatch-to-completion time — what rocprofv3 reports as
+    # mode (eager launches): b(c) = E + c * f.  The kernel's dispatch-to-completion time — what rocprofv3 reports as
     # its duration — is its bracket minus E.
     _, b1 = run_step(-1)
     _, b17 = run_step(-17)
@@ -329,31 +332,29 @@ def main():
         eng = step.step_impl.engine
 
         def prof_pass(site):
-            # the step captured once into a hipGraph with hipEvent records around every launch of `site` as graph
-            # nodes, then replayed: per-launch durations as the product runs them (engine.profile_site_graph)
+            # hipEvent brackets around every launch of `site` in EAGER launches of the step (engine.profile_site); site < 0: around
+            # -site empty kernels, the calibration of what the two event records add to a bracket
             def one():
                 if site < 0:
                     for _ in range(16):
                         eng.profile_null_launch(-site)
                     return
                 eng.train_step_dev(enc, targets, T, w, step.step_impl.seed_base, 3)
-            s_id = site if site > 0 else 5
-            if site >= 7:
-                # a chain kernel runs for hundreds of microseconds: bracketed in eager launches of the step (event
-                # records inside a replayed graph can be scheduled long before the node they precede)
-                n_, ms_ = eng.profile_site(s_id, one, 5)
-                return n_ // 5, ms_
-            if args.graph and not step.reduce:
-                return eng.profile_site_graph(s_id, one)
             # (never the data-parallel step itself: this runs on rank 0 only, a collective here would wait for ever)
-            n_, ms_ = eng.profile_site(s_id, one, 5)
+            n_, ms_ = eng.profile_site(site if site > 0 else 5, one, 5)
             return (n_ // 5 if site > 0 else n_), ms_
         phases = None
         if not step.reduce and not args.feed:
             phases = phase_table(eng, runner)
             if phases:
                 phases["between_steps_us"] = round(ms * 1e3 - phases["span_us"], 1)
+        for _ in range(int(os.environ.get("RN_BENCH_ROOFLINE_REPEATS", "1")) - 1):       # (stress of the measurement path: tools/crash_hunt.sh)
+            roofline(eng, prof_pass, kind, args.precision, T=T, cell=args.cell)
         prof = roofline(eng, prof_pass, kind, args.precision, T=T, cell=args.cell)
+        if prof and phases:
+            # cross-check of the hipEvent brackets (taken around EAGER launches of the step) against the device's own stamps inside
+            # the REPLAYED graph (first workgroup started -> last statement of workgroup 0): what the timed region really ran
+            prof["chain_kernel_stamps_us"] = {k[len("chain_"):-len("_us")]: v for k, v in phases.items() if k.startswith("chain_") and isinstance(v, float)}
         # whole-step roofline fractions: algorithmic FLOPs against the dense bf16 MFMA peak and
         # algorithmic HBM bytes (optimiser + inputs) against 8 TB/s; per GPU (every rank does the same work)
         Bl = hi - lo
@@ -370,7 +371,7 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
                                    "D=R=%d, V=4188, E=468, H=512, A=128, T=%d, dropout 0.5, %s cells" % (args.rec, hi - lo, F, D, T, args.cell),
-                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "deferred_reconstructor_update": bool(graphed is not None and graphed.deferred), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
+                       "global_batch": Bg, "parallelism": "dp%d" % world, "hipgraph": bool(args.graph), "deferred_reconstructor_update": bool(graphed is not None and graphed.deferred and (graphed.defer_mode is True or eng.lib.recnet_dim(eng.handle, 10) == 1)), "host_feed": bool(args.feed), "grad_allreduce": bool(step.reduce),
                        "loss": round(sc["total_loss"], 5)},
             "roofline": prof, "whole_step": whole, "phases": phases,
         }

@@ -298,8 +298,9 @@ int recnet_join_side(recnet_handle* h, void* stream);
 #define RECNET_SITE_DEC_CHAIN_BWD 10  /* ... and the whole BPTT chain                                                    */
 int recnet_profile_begin(recnet_handle* h, int32_t site);
 int recnet_profile_end(recnet_handle* h, int32_t* n_launches, double* total_ms);
-/* Same read-out without leaving profiling mode: when the bracketed launches were captured into a hipGraph (the event
- * records become graph nodes), call this after each replay — the durations are then those of the replayed graph. */
+/* Same read-out without leaving profiling mode.  Brackets are taken around EAGER launches only: on a capturing stream the
+ * launches of the site are not bracketed (round 4: event-record nodes read back after every replay aborted inside the HIP
+ * runtime in about 1 of 100 bench runs; a replayed graph is described by recnet_read_stamps instead). */
 int recnet_profile_read(recnet_handle* h, int32_t* n_launches, double* total_ms);
 /* Phase stamps of the LAST train step, written by the step's own kernels (no tracer, no extra launch, also in a replayed
  * hipGraph): 14 values of the device's 100 MHz wall clock (10 ns units) —
@@ -353,6 +354,8 @@ int recnet_debug_poison_lds(recnet_handle* h, void* stream);
 #define RECNET_DIM_R 7
 #define RECNET_DIM_RA 8
 #define RECNET_DIM_TM 9      /* caption_max_len + 1: rows of `targets` */
+#define RECNET_DIM_SPLIT_FITS 10   /* 1: mode 2 of recnet_set_deferred_reconstructor_update is applied at this shape (the pending
+                                    * product fits beside the decoder's forward chain); 0: the step updates immediately */
 int32_t recnet_dim(const recnet_handle* h, int32_t which);
 /* One reconstructor step with the reference's per-step semantics — GlobalReconstructor.forward(input, hidden,
  * decoder_hiddens) (models/global_reconstructor.py:30-46, called at train.py:94) and LocalReconstructor.forward(hidden,

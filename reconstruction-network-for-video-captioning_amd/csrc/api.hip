@@ -115,6 +115,7 @@ struct recnet_handle {
   // at its end and refreshes them in its next run's hoisted side work, under the decoder forward chain (host_common.inc)
   int lazy_images = 0, in_fused = 0, rec_images_stale = 0, side_fork_recorded = 0;
   int dp_overlap = 0, side_open = 0;   // recnet_set_dp_overlap: part 1 of the data-parallel step leaves the side stream's weight-gradient products unjoined (recnet_join_side)
+  int rbias_in_prologue = 0, rec_wait_pending_join5 = 0;   // mode 2: the reconstructor's gate bias formed by prologue_pack_kernel; ev[12] also covers the hoisted branch
   int hoist_fork_recorded = 0;   // dec_fwd_chain recorded the fork events of hoist_side_work itself, in front of the chain launch
   int split_ok = 0;              // the pending half of a split reconstructor update fits beside the decoder forward chain (recnet_create)
   int rec_wait_pending = 0;      // fwd_rec_global waits for ev[12] (the pending W_hh update, mode 2) in front of its recurrent chain
@@ -407,7 +408,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
       const int ebig = getenv("RN_PERSIST_LOC_BIG") ? atoi(getenv("RN_PERSIST_LOC_BIG")) : 1;
       const int steps = h->R / 128, nwg = (h->H + h->R) / 64 * 4;
       h->persist_big_bwd = ebig && (eb ? atoi(eb) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && h->R > 2048 && h->R % 128 == 0 &&
-                           (steps == 24 || steps == 28 || steps == 32) && h->H % 64 == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 7) == 0 &&
+                           (steps >= 18 && steps <= 32 && (steps & 1) == 0) && h->H % 64 == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 7) == 0 &&
                            h->B <= 64 && Bg == h->B && h->Tm <= 32 && h->F <= 40 && nwg <= h->ncu && nwg <= 256 && h->R / 16 < nwg && h->B < nwg;
     }
     h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && h->R <= 2048 && (h->H & 15) == 0 && !(Bg > 64 && h->R > 1536) &&
@@ -440,7 +441,8 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     // Leaving only SOME gate blocks of W_hh pending at R = 3584 was tried in round 4: the fragment images of the R > 2048 chains
     // have to be re-packed behind either half, and the step got slower, 3.49 against 3.29 ms.)
     const double t_pending = free_cus > 0 ? 1.36 * flops / (free_cus * 2.4e6) : 1e30, t_chain = 0.95 * 10.0 * h->Tm * ((h->B + Bg - 1) / Bg);
-    h->split_ok = h->kind != RECNET_REC_NONE && h->persist_dec && h->lp && t_pending <= t_chain;
+    // (one row group only: at B = 200, two groups of 100, the split form measured 3.21 ms against 3.10 ms for the immediate one)
+    h->split_ok = h->kind != RECNET_REC_NONE && h->persist_dec && h->lp && Bg == h->B && t_pending <= t_chain;
   }
   h->need = carve(h, nullptr);
   *out = h;

@@ -438,41 +438,14 @@ class Engine:
     # ---- live measurement of one recurrent-step GEMM site with HIP events on its own stream
     def profile_site(self, site, fn, iters=3):
         """Runs fn() `iters` times with hipEvents around every launch of `site` (1 dec fwd, 2 dec bwd, 3 rec
-        fwd, 4 rec bwd, 5 local-attention); returns (launches, average ms per launch)."""
+        fwd, 4 rec bwd, 5 local-attention, 7-10 the chain kernels); returns (launches, average ms per launch).  fn() launches
+        EAGERLY: on a capturing stream no bracket is taken (csrc/host_common.inc: prof_take)."""
         _lib.check(self.lib.recnet_profile_begin(self.handle, int(site)), "recnet_profile_begin")
         for _ in range(iters):
             fn()
         n, ms = C.c_int32(0), C.c_double(0.0)
         _lib.check(self.lib.recnet_profile_end(self.handle, C.byref(n), C.byref(ms)), "recnet_profile_end")
         return n.value, (ms.value / n.value if n.value else 0.0)
-
-    def profile_site_graph(self, site, fn, replays=5):
-        """Like profile_site, but fn() is captured ONCE into a hipGraph with the hipEvent records of `site` as graph
-        nodes, and the graph is replayed: the durations are those of the launches inside the replayed graph (the way
-        the product runs them), not of eager launches.  Returns (launches per replay, average ms per launch)."""
-        _lib.check(self.lib.recnet_profile_begin(self.handle, int(site)), "recnet_profile_begin")
-        g = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()                                           # warm-up outside capture
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        n, ms = C.c_int32(0), C.c_double(0.0)
-        _lib.check(self.lib.recnet_profile_end(self.handle, C.byref(n), C.byref(ms)), "recnet_profile_end")
-        _lib.check(self.lib.recnet_profile_begin(self.handle, int(site)), "recnet_profile_begin")
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            fn()
-        tot, cnt = 0.0, 0
-        for _ in range(replays):
-            g.replay()
-            torch.cuda.synchronize()
-            _lib.check(self.lib.recnet_profile_read(self.handle, C.byref(n), C.byref(ms)), "recnet_profile_read")
-            tot += ms.value
-            cnt += n.value
-        per_replay = n.value
-        _lib.check(self.lib.recnet_profile_end(self.handle, C.byref(n), C.byref(ms)), "recnet_profile_end")
-        return per_replay, (tot / cnt if cnt else 0.0)
 
     def profile_null_launch(self, count=1):
         _lib.check(self.lib.recnet_profile_null_launch(self.handle, int(count), _stream()), "recnet_profile_null_launch")

@@ -29,7 +29,7 @@ for name, kind, B, F, D in CONFIGS:
     targets = tg.cuda()
     step = R.DataParallelTrainStep(dec, rec, B, 0, 1, n_frames=F)
     T, w = step.prepare(tg.numpy())
-    runner = R.GraphedStep(step, enc, targets, T, w)
+    runner = R.GraphedStep(step, enc, targets, T, w, defer_reconstructor_update="recurrent")      # the bench default (round 4): split update
     for _ in range(10):
         runner()
     torch.cuda.synchronize()
@@ -40,6 +40,7 @@ for name, kind, B, F, D in CONFIGS:
         t0 = time.perf_counter()
         for _ in range(WIN):
             runner()
+        runner.flush()
         torch.cuda.synchronize()
         wins.append((time.perf_counter() - t0) / WIN * 1e3)
         st = eng.chain_status()
