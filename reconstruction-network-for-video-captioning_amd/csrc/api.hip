@@ -115,7 +115,6 @@ struct recnet_handle {
   // at its end and refreshes them in its next run's hoisted side work, under the decoder forward chain (host_common.inc)
   int lazy_images = 0, in_fused = 0, rec_images_stale = 0, side_fork_recorded = 0;
   int dp_overlap = 0, side_open = 0;   // recnet_set_dp_overlap: part 1 of the data-parallel step leaves the side stream's weight-gradient products unjoined (recnet_join_side)
-  int rbias_in_prologue = 0, rec_wait_pending_join5 = 0;   // mode 2: the reconstructor's gate bias formed by prologue_pack_kernel; ev[12] also covers the hoisted branch
   int hoist_fork_recorded = 0;   // dec_fwd_chain recorded the fork events of hoist_side_work itself, in front of the chain launch
   int split_ok = 0;              // the pending half of a split reconstructor update fits beside the decoder forward chain (recnet_create)
   int rec_wait_pending = 0;      // fwd_rec_global waits for ev[12] (the pending W_hh update, mode 2) in front of its recurrent chain

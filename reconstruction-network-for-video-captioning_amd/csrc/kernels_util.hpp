@@ -396,7 +396,6 @@ struct ProPackArgs {
   bf16_t* enc_lp; int ld_enc; const float* enc; int rowsE, D;
   const float* Emb; const int64_t* targets; bf16_t* emb; int ld_emb, B, E, V; float scale; DropDesc dd; int rowsT;
   const float* bih; const float* bhh; float* bsum; int Hd, gru;
-  const float* rbih; const float* rbhh; float* rbsum; int rHd, rgru;      // the reconstructor's gate bias as well (null: not here)
   int nb_pack;
 };
 __global__ __launch_bounds__(256) void prologue_pack_kernel(const ProPackArgs p) {
@@ -438,12 +437,6 @@ __global__ __launch_bounds__(256) void prologue_pack_kernel(const ProPackArgs p)
     const int g = i / p.Hd;
     p.bsum[i] = g < 2 ? p.bih[i] + p.bhh[i] : (g == 2 ? p.bih[i] : p.bhh[i - p.Hd]);
   }
-  if (p.rbsum)
-    for (int i = tid; i < 4 * p.rHd; i += 256) {
-      if (!p.rgru) { p.rbsum[i] = p.rbih[i] + p.rbhh[i]; continue; }
-      const int g = i / p.rHd;
-      p.rbsum[i] = g < 2 ? p.rbih[i] + p.rbhh[i] : (g == 2 ? p.rbih[i] : p.rbhh[i - p.rHd]);
-    }
 }
 // input token of decoder step t for caption b: the tokens that were actually fed when a free-running forward recorded
 // them (in_tok [T][B], train.py:47-51), else teacher forcing: <SOS> at t = 0, targets[t-1] after (train.py:25,45)

@@ -10,7 +10,7 @@ def bench(fn, n=20):
     g.replay(); torch.cuda.synchronize()
     t0 = time.perf_counter(); g.replay(); g.replay(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / (2 * n)
-shapes = [("Xg  NT", 3100, 6144, 512, "nt"), ("P   NT", 2800, 2048, 1536, "nt"), ("logit NT", 3100, 4188, 512, "nt"), ("Xe NT", 3100, 2048, 468, "nt"),
+shapes = [("Xg  NT", 3100, 6144, 512, "nt"), ("Xg2 NT", 3100, 6144, 1024, "nt"), ("dhid2 NN", 3100, 1024, 6144, "nn"), ("P   NT", 2800, 2048, 1536, "nt"), ("logit NT", 3100, 4188, 512, "nt"), ("Xe NT", 3100, 2048, 468, "nt"),
           ("dhid NN", 3100, 512, 6144, "nn"), ("dHs NN", 3100, 512, 4188, "nn"), ("demb NN", 3100, 468, 2048, "nn"),
           ("dWih_c TN", 2048, 1536, 3100, "tn"), ("dWo TN", 4188, 512, 3100, "tn"), ("dWih_rec TN", 6144, 512, 3100, "tn"), ("dWhh_rec TN", 6144, 1536, 3000, "tn")]
 for name, M, N, K, lay in shapes:

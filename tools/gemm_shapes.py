@@ -13,7 +13,7 @@ def bench(fn, n=20):
     t0 = time.perf_counter(); g.replay(); g.replay(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / (2 * n)
 shapes = [("Uv NT", 2800, 128, 1536, 0, 0), ("P NT", 2800, 2048, 1536, 0, 0), ("Xe NT", 3100, 2048, 468, 0, 0),
-          ("logits NT", 3100, 4188, 512, 0, 0), ("Xg NT", 3100, 6144, 512, 0, 0), ("dHs NN", 3100, 512, 4188, 0, 1),
+          ("logits NT", 3100, 4188, 512, 0, 0), ("Xg NT", 3100, 6144, 512, 0, 0), ("Xg2 NT", 3100, 6144, 1024, 0, 0), ("dhid2 NN", 3100, 1024, 6144, 0, 1), ("dHs NN", 3100, 512, 4188, 0, 1),
           ("dW_o TN", 4188, 512, 3100, 1, 1), ("dhid NN", 3100, 512, 6144, 0, 1), ("dWih TN", 6144, 512, 3100, 1, 1),
           ("dWhh_r TN", 6144, 1536, 3000, 1, 1), ("demb NN", 3100, 468, 2048, 0, 1), ("dW_e TN", 2048, 468, 3100, 1, 1),
           ("dW_c TN", 2048, 1536, 3100, 1, 1), ("dW_hh TN", 2048, 512, 3000, 1, 1), ("dW_att TN", 128, 512, 3000, 1, 1),
