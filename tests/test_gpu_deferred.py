@@ -135,3 +135,32 @@ def test_local_reconstructor_keeps_the_immediate_update():
     b = _run("local", "bf16", dims, True, [[4] * dims[0]], [0, 0])
     for k in a[1]:
         assert _same(a[1][k], b[1][k], k, True), k
+
+
+@pytest.mark.parametrize("kind", ["global", "local"])
+def test_split_update_runs_beside_the_decoder_chain_in_the_replayed_graph(kind):
+    """Mode 2 is only worth having if the replayed graph really runs the pending W_hh update BESIDE the next step's decoder
+    forward chain.  Round 4 lost that once without any test noticing (a change of the graph's cross-stream edges made the runtime
+    run it BEHIND the chain at the local reconstructor's benchmark shape: 2.27 against 2.15 ms).  The kernels' own stamps of a
+    replayed step (Engine.read_stamps, no tracer) say where it ran: it has to start before the chain is a third through."""
+    B, F, D, V = 100, 28, 1536, 4188
+    dims = [B, F, D, V, 468, 512, 128, 128]
+    decP = GU.formula_params(GU.decoder_shapes(V, 468, 512, 128, D), 3)
+    recP = GU.formula_params(GU.rec_shapes(kind, 512, D, 128), 4)
+    _, dec, rec = make_models(dims, kind, "bf16", decP, recP)
+    step = R.DataParallelTrainStep(dec, rec, B, 0, 1, n_frames=F)
+    enc, targets = GU.make_batch(B, F, D, V, [30] * B, 11)
+    T, w = step.prepare(targets.numpy())
+    run = R.GraphedStep(step, enc.cuda(), targets.cuda(), T, w, warmup=2, defer_reconstructor_update="recurrent")
+    eng = step.step_impl.engine
+    assert eng.lib.recnet_dim(eng.handle, 10) == 1, "the split update is applied at the benchmark shapes"
+    beside = 0
+    for _ in range(6):
+        run()
+        st = eng.read_stamps()
+        c0, c1 = st["chains"]["decoder_forward"]
+        p0, p1 = st["groups"]["pending_recurrent_update"]
+        beside += p0 < c0 + (c1 - c0) / 3
+    run.flush()
+    assert eng.chain_status() == 0
+    assert beside >= 5, "the pending update ran behind the decoder's forward chain instead of beside it"
