@@ -358,11 +358,13 @@ class TrainState:
             self.rec_opt = torch.optim.Adam([self.rec[k] for k in rec_param_order(self.rec)], lr=rec_lr,
                                             weight_decay=rec_wd, amsgrad=rec_amsgrad)
 
-    def losses(self, enc, targets, masks, drop=None):
-        dl, hid, _, ce, _ = forward_decoder(self.dec, enc, targets, masks, cell=self.cell,
-                                            lambda_reg=self.dec_lambda_reg,
-                                            caption_max_len=self.caption_max_len, p_emb=self.p_emb,
-                                            p_out=self.p_out, drop=drop, return_parts=True)
+    def losses(self, enc, targets, masks, drop=None, teacher_forcing=True):
+        dl, hid, idx, ce, _ = forward_decoder(self.dec, enc, targets, masks, cell=self.cell,
+                                              lambda_reg=self.dec_lambda_reg,
+                                              caption_max_len=self.caption_max_len, p_emb=self.p_emb,
+                                              p_out=self.p_out, drop=drop, return_parts=True,
+                                              teacher_forcing=teacher_forcing)
+        self.last_output_indices = idx            # (train.py:50: the tokens a free-running pass fed back)
         rl = mse = None
         if self.rec is not None:
             if self.rec_kind == "global":
@@ -376,10 +378,11 @@ class TrainState:
                                                          drop=drop, return_parts=True)
         return dl, rl, hid, ce, mse
 
-    def step(self, enc, targets, masks, drop=None):
+    def step(self, enc, targets, masks, drop=None, teacher_forcing=True):
         """The train-step body, train.py:248-273.  Returns python floats (dec_loss, rec_loss, total,
-        decoder grad-norm before clipping)."""
-        dl, rl, _, _, _ = self.losses(enc, targets, masks, drop)
+        decoder grad-norm before clipping).  teacher_forcing: the iteration's draw of train.py:38
+        (`random.random() <= C.decoder_teacher_forcing_ratio`, made by the caller)."""
+        dl, rl, _, _, _ = self.losses(enc, targets, masks, drop, teacher_forcing)
         loss = dl if rl is None else dl + self.lambda_recon * rl         # :259-262
         self.dec_opt.zero_grad()                                         # :265-267
         if self.rec_opt is not None:

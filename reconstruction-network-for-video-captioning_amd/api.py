@@ -421,9 +421,15 @@ class TrainStep:
     caller (the reference syncs three times per step, train.py:275-277)."""
 
     def __init__(self, decoder, reconstructor=None, batch_size=None, n_frames=None, global_batch=None,
-                 batch_offset=0):
+                 batch_offset=0, teacher_forcing_ratio=None):
         C = decoder["_C"]
         self.decoder, self.reconstructor = decoder, reconstructor
+        # config.py:71 decoder_teacher_forcing_ratio, handed to forward_decoder at train.py:251.  Every call of the step draws
+        # `random.random() <= ratio` from Python's global generator like train.py:38 does (also at ratio 1, where the draw is
+        # always True — the generator advances as the reference's does).  A False draw runs the free-running iteration.
+        self.teacher_forcing_ratio = float(getattr(C, "decoder_teacher_forcing_ratio", 1.0) if teacher_forcing_ratio is None
+                                           else teacher_forcing_ratio)
+        self.output_indices = None        # [T, B] tokens the last free-running iteration fed back (train.py:50), else None
         dm = decoder["model"]
         rm = reconstructor["model"] if reconstructor else None
         B = batch_size or C.batch_size
@@ -458,7 +464,11 @@ class TrainStep:
         # dropout seed of optimiser step n (1-based) = seed_base + n, the same rule the device-side counter of
         # the graph-replay path applies (recnet_train_step_fwd_bwd_dev)
         seed = self.seed_base + ms.step + 1 if seed is None else seed
-        self.engine.train_step_fwd_bwd(enc, targets, T, step_weight, seed)
+        if random.random() <= self.teacher_forcing_ratio:                             # train.py:38
+            self.output_indices = None
+            self.engine.train_step_fwd_bwd(enc, targets, T, step_weight, seed)
+        else:
+            self._free_fwd_bwd(enc, targets, T, step_weight, seed)
 
     def optimizer_step(self):
         ms = self.decoder["_state"]
@@ -479,9 +489,29 @@ class TrainStep:
         ms.step += 1
         if self.reconstructor:
             self.reconstructor["_state"].step = ms.step
-        self.engine.train_step(enc, targets, T, step_weight, seed, ms.step)
+        if random.random() <= self.teacher_forcing_ratio:                             # train.py:38
+            self.output_indices = None
+            self.engine.train_step(enc, targets, T, step_weight, seed, ms.step)
+        else:
+            self._free_fwd_bwd(enc, targets, T, step_weight, seed)
+            self.engine.optimizer_step(ms.step, _lib.OPT_REG | _lib.OPT_CLIP)
         self._mark()
         return self.engine.scalars
+
+    def _free_fwd_bwd(self, enc, targets, T, step_weight, seed):
+        """Forward + backward of the iteration of train.py:248-268 whose draw said no teacher forcing: the decoder feeds its own
+        arg-max back (train.py:46-51, per-step kernels: the arg-max of step t is the input of step t + 1, so nothing of the
+        forward can be batched over time), the reconstructor reads those hidden states, and the backward differentiates that
+        unroll — the arg-max passes no gradient, the embedding gradient goes to the rows of the tokens that were fed.  The
+        optimiser step that follows is the teacher-forced iteration's (regulariser gradient, decoder clip, AMSGrad / Adam, re-pack)."""
+        eng = self.engine
+        eng.flush()                                   # (a deferred update left by a replayed graph completes first)
+        _, self.output_indices = eng.forward_decoder_free(enc, targets, T, step_weight, train=True, seed=seed)
+        dh = None
+        if self.reconstructor:
+            eng.forward_reconstructor(enc, None, T, train=True, seed=seed)
+            dh = eng.backward_reconstructor(enc, grad_scale=float(eng.hyper["lambda_recon"]))      # train.py:260
+        eng.backward_decoder(enc, targets, dh, 1.0)
 
 
 class GraphedStep:
@@ -506,6 +536,10 @@ class GraphedStep:
         bit-identical to the non-deferred step's."""
         self.dp = dp_step
         st = dp_step.step_impl
+        if st.teacher_forcing_ratio < 1.0:
+            # train.py:38 draws per iteration on the host; a replayed graph makes no draw.  TrainStep (eager) runs such a schedule.
+            raise ValueError("GraphedStep replays the teacher-forced step; decoder_teacher_forcing_ratio = %g < 1 needs "
+                             "TrainStep, which draws per call" % st.teacher_forcing_ratio)
         self.eng = st.engine
         self.enc, self.targets, self.T, self.w = enc, targets, T, step_weight
         self.ms = st.decoder["_state"]

@@ -112,7 +112,8 @@ class Trainer:
     def step(self, enc, targets, T, w):
         """enc [B_local,F,D], targets [31,B_local] on the device; T / w from the GLOBAL batch (feed.DeviceFeeder)."""
         self.iteration += 1
-        if not self.use_graphs or self.decoder["_state"].step < self._eager_until:
+        # (decoder_teacher_forcing_ratio < 1: the draw of train.py:38 is made on the host in every iteration — eager steps only)
+        if not self.use_graphs or self.dp.step_impl.teacher_forcing_ratio < 1.0 or self.decoder["_state"].step < self._eager_until:
             return self.dp(enc, targets, T, w)         # first steps eagerly: module loading, RCCL set-up
         if self._static is None:
             self._static = (torch.empty_like(enc), torch.empty_like(targets))

@@ -105,7 +105,12 @@ ONLY = None   # --only a,b,c : regenerate just these cases
 
 
 def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None, rec_cell="LSTM",
-             RA=None, train_mode=True, n_steps=3, seed=0, drop_seed=42, full=True, formula_seed=None):
+             RA=None, train_mode=True, n_steps=3, seed=0, drop_seed=42, full=True, formula_seed=None,
+             tf_ratio=1.0, py_seed=None, out_scale=None):
+    """tf_ratio < 1 (config.py:71 decoder_teacher_forcing_ratio): forward_decoder draws `random.random() <= ratio` once per
+    iteration (train.py:38) from Python's global generator, seeded here with py_seed; the iterations that draw False feed the
+    arg-max back (train.py:46-51) and are differentiated like the others.  out_scale: a decisive vocabulary projection, so the
+    arg-max of a free-running iteration is not a coin flip at default init."""
     if ONLY is not None and name not in ONLY:
         return
     RA = RA or A
@@ -119,6 +124,10 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
             rec["model"].load_state_dict(formula_params(rec["model"].state_dict(), formula_seed + 1))
     st = DropState()
     dm = dec["model"]
+    if out_scale is not None:
+        with torch.no_grad():
+            dm.out.weight.mul_(out_scale)
+            dm.out.bias.mul_(out_scale)
     dm.embedding_dropout = HashDropout(C.embedding_dropout, dropmask.SITE_DEC_EMBED, st)
     dm.out_dropout = HashDropout(C.decoder_out_dropout, dropmask.SITE_DEC_LOGIT, st)
     if rec:
@@ -167,10 +176,19 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
         out["step_c"] = np.stack(c_all)
 
     # ---- train steps exactly as train.py:248-273
+    import random
+    if py_seed is not None:
+        random.seed(py_seed)
+        out["meta_py_seed"] = np.array(py_seed)
+        out["meta_tf_ratio"] = np.array(tf_ratio, dtype=np.float64)
+        out["meta_tf_pattern"] = np.array([int(random.random() <= tf_ratio) for _ in range(n_steps)], dtype=np.int64)
+        random.seed(py_seed)
     for it in range(n_steps):
         dm.train(train_mode)
         st.reset(drop_seed + it)
-        dl, hiddens, _ = ref_train.forward_decoder(dec, enc, targets, masks, 1.0)
+        dl, hiddens, fed = ref_train.forward_decoder(dec, enc, targets, masks, tf_ratio)
+        if py_seed is not None and not int(out["meta_tf_pattern"][it]):
+            out["output_indices_step%d" % it] = fed.numpy().astype(np.int64)
         rl = None
         if rec:
             rec["model"].train(train_mode)
@@ -314,6 +332,10 @@ if __name__ == "__main__":
     run_free_case("free_dec", lens=[7, 3, 8, 1, 5], **SMALL)
     run_free_case("free_global", lens=[6, 9, 2, 4, 4], rec_kind="global", **SMALL)
     run_free_case("free_local_gru", lens=[30, 4, 11, 2, 9], dec_cell="GRU", rec_kind="local", rec_cell="GRU", RA=16, **SMALL)
+    # decoder_teacher_forcing_ratio < 1 in TRAINING (config.py:71, train.py:38,251): four iterations, the draw of each from
+    # random.seed(py_seed) — teacher-forced and free-running iterations mixed, every one differentiated and stepped
+    run_case("tf_half_global", lens=[6, 9, 2, 4, 4], rec_kind="global", n_steps=4, tf_ratio=0.5, py_seed=3, out_scale=6.0, **SMALL)
+    run_case("tf_half_local", lens=[7, 3, 8, 1, 5], rec_kind="local", RA=16, n_steps=4, tf_ratio=0.5, py_seed=10, out_scale=6.0, **SMALL)
     # full-shape cases (SURVEY.md §8a C1..C3 dims): parameters from formula_params(seed) so they can be
     # regenerated without the reference; only outputs / norms / slices are stored.
     FULL = dict(F=28, D=1536, V=4188, E=468, H=512, A=128)

@@ -160,3 +160,37 @@ def test_chain_give_up_skips_the_update_and_is_reported():
     hist = tr.fit(iter(data[2:]), 4, log_every=1, log=lambda m: None)
     assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist)
     assert any(not torch.equal(v, before[k]) for k, v in tr.decoder["model"].state_dict().items())
+
+
+def test_teacher_forcing_ratio_below_one_runs_eager_steps_with_the_host_draw():
+    """config.py:71 decoder_teacher_forcing_ratio < 1: the draw of train.py:38 is a host decision per iteration, so the Trainer
+    keeps to eager steps (a replayed graph makes no draw; GraphedStep refuses such a step) — and the same seven iterations
+    through a plain TrainStep with the same Python seed give the same parameters, free-running iterations included."""
+    import random
+    C = R.make_config(use_recon=True, reconstructor_type="global", decoder_teacher_forcing_ratio=0.5, **DIMS)
+    data = _batches(7)
+    torch.manual_seed(0)
+    tr = R.Trainer(C, V)
+    random.seed(11)
+    pattern = [random.random() <= 0.5 for _ in range(7)]
+    assert any(pattern) and not all(pattern)
+    random.seed(11)
+    tr.fit(iter(data), 7, log_every=100)
+    assert tr.iteration == 7 and len(tr._graphs) == 0
+    torch.manual_seed(0)
+    dec, rec = R.build_decoder(V, C), R.build_reconstructor(C)
+    step = R.TrainStep(dec, rec)
+    assert step.teacher_forcing_ratio == 0.5
+    with pytest.raises(ValueError):
+        enc0, tg0 = torch.from_numpy(data[0][0]).cuda(), torch.from_numpy(data[0][1]).cuda()
+        T0, w0 = step.prepare(data[0][1])
+        R.GraphedStep(R.DataParallelTrainStep(dec, rec, 6, 0, 1), enc0, tg0, T0, w0)
+    random.seed(11)
+    for (enc, tg), tf in zip(data, pattern):
+        T, w = step.prepare(tg)
+        step(torch.from_numpy(enc).cuda(), torch.from_numpy(tg).cuda(), T, w)
+        assert (step.output_indices is None) == tf
+    for k, v in dec["model"].state_dict().items():
+        assert torch.equal(v, tr.decoder["model"].state_dict()[k]), k
+    for k, v in rec["model"].state_dict().items():
+        assert torch.equal(v, tr.reconstructor["model"].state_dict()[k]), k

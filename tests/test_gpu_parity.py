@@ -146,6 +146,47 @@ def test_fused_train_steps_match_reference_optimizer(name, prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["tf_half_global", "tf_half_local"])
+def test_teacher_forcing_ratio_below_one_in_the_train_step(name, prec):
+    """config.py:71 decoder_teacher_forcing_ratio < 1 (train.py:38,251): TrainStep draws `random.random() <= ratio` per call
+    like the reference; a False draw runs the free-running iteration (arg-max fed back, differentiated, stepped).  Four
+    reference iterations from random.seed(py_seed) — teacher-forced and free-running mixed: the tokens fed back, every loss, and
+    (fp32) the parameters after the fourth step.  bf16: a near-tie of the arg-max may flip, which changes that caption's later
+    inputs — losses are held only up to the first iteration whose tokens differ."""
+    import random
+    g, dims, kind, decP, recP, enc, targets = load_case(name)
+    C, dec, rec = make_models(dims, kind, prec, decP, recP, cells=g["_cells"])
+    ratio, n = float(g["meta_tf_ratio"]), int(g["meta_n_steps"])
+    step = R.TrainStep(dec, rec, teacher_forcing_ratio=ratio)
+    encd, tg = enc.cuda(), targets.cuda()
+    T, w = step.prepare(targets.numpy())
+    seed0 = int(g["meta_drop_seed"])
+    tol = TOL[prec]
+    random.seed(int(g["meta_py_seed"]))
+    same = True
+    for it in range(n):
+        sc = step(encd, tg, T, w, seed=seed0 + it)
+        torch.cuda.synchronize()
+        assert step.engine.chain_status() == 0
+        tf = bool(g["meta_tf_pattern"][it])
+        assert (step.output_indices is None) == tf, it
+        if not tf:
+            agree = step.output_indices.cpu().numpy() == g["output_indices_step%d" % it]
+            if prec == "f32":
+                assert agree.all(), it
+            same = same and bool(agree.all())
+        if same:
+            ref = float(g["loss_step%d" % it])
+            assert abs(float(sc[6]) - ref) <= (tol["loss"] + REG_SLACK) * abs(ref), it
+        assert np.isfinite(float(sc[6]))
+    if prec == "f32":
+        for grp, md in (("dec", dec), ("rec", rec)):
+            for k, v in GU.group(g, "%s_after%d" % (grp, n)).items():
+                got = md["model"].state_dict()[k].cpu().numpy()
+                assert np.abs(got - v.numpy()).max() <= tol["param"], (grp, k)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
 @pytest.mark.parametrize("cells", [("LSTM", "LSTM"), ("GRU", "GRU"), ("GRU", "LSTM")])
 @pytest.mark.parametrize("kind", [None, "global", "local"])
 def test_fused_step_vs_oracle_ragged_shapes(kind, prec, cells):

@@ -134,3 +134,32 @@ def test_free_running_validation_pass(name):
             fwd = O.forward_global_reconstructor if kind == "global" else O.forward_local_reconstructor
             rl = fwd(recP, hid, enc, cell=cells[1], drop=O.Dropper("eval"))
             assert abs(float(rl) - float(g["rec_loss"])) <= 2e-6 * max(1.0, abs(float(g["rec_loss"])))
+
+
+TF_CASES = ["tf_half_global", "tf_half_local"]
+
+
+@pytest.mark.parametrize("name", TF_CASES)
+def test_teacher_forcing_ratio_below_one_in_training(name):
+    """config.py:71 / train.py:38,251: with decoder_teacher_forcing_ratio < 1 every training iteration draws
+    `random.random() <= ratio` from Python's global generator; the iterations that draw False feed the arg-max back
+    (train.py:46-51) and are differentiated and stepped like the others.  Four reference iterations from random.seed(py_seed):
+    the draws, the fed-back tokens, every loss and the parameters after the fourth step."""
+    import random
+    g, decP, recP, kind, cells, enc, targets = _setup(name)
+    masks = targets > 0
+    st = O.TrainState(decP, recP, kind, cell=cells[0], rec_cell=cells[1])
+    n_steps, ratio = int(g["meta_n_steps"]), float(g["meta_tf_ratio"])
+    random.seed(int(g["meta_py_seed"]))
+    for it in range(n_steps):
+        tf = random.random() <= ratio                                # train.py:38
+        assert int(tf) == int(g["meta_tf_pattern"][it])
+        dl, rl, loss, gn = st.step(enc, targets, masks, _drop(g, it), teacher_forcing=tf)
+        assert abs(loss - float(g["loss_step%d" % it])) <= 3e-6 * max(1.0, abs(loss)), it
+        if not tf:
+            assert np.array_equal(st.last_output_indices.numpy(), g["output_indices_step%d" % it])
+    assert 0 < int(g["meta_tf_pattern"].sum()) < n_steps             # both kinds of iteration are in the fixture
+    for k, v in GU.group(g, "dec_after%d" % n_steps).items():
+        np.testing.assert_allclose(st.dec[k].detach().numpy(), v.numpy(), atol=1e-6, rtol=0)
+    for k, v in GU.group(g, "rec_after%d" % n_steps).items():
+        np.testing.assert_allclose(st.rec[k].detach().numpy(), v.numpy(), atol=1e-6, rtol=0)
