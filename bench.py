@@ -234,7 +234,11 @@ def main():
                     "ranks (BASELINE configs[3]: 256 over 8, configs[4]: 512 over 8); default 0 = weak scaling, --batch per rank")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="gradient transport of the all-reduce")
     ap.add_argument("--feed", type=int, default=0, help="1: every step takes a fresh HOST batch through feed.DeviceFeeder "
-                    "(pinned staging + H2D on a side stream); reports the PCIe-inclusive rate, not the headline value")
+                    "(pinned staging + H2D on a side stream); reports the PCIe-inclusive rate, not the headline value.  1: the batch "
+                    "is staged by the calling thread (measured faster: 1.70 against 1.81 ms), 2: by the feeder's worker thread.  "
+                    "Every slot of the feeder has a captured graph of its own; at least 40 untimed warm-up steps are run so that each "
+                    "has been replayed a few times (the first replays of an executable graph are slow: 1.87 against 1.70 ms over "
+                    "50 timed steps with 10 warm-up steps)")
     args = ap.parse_args()
 
     import torch
@@ -292,7 +296,7 @@ def main():
         # The feeder's H2D copies land in the device buffers of a ring of slots, two batches ahead of the step, and every slot
         # has its OWN captured graph reading those buffers in place (round 3 copied each batch into one graph's fixed inputs:
         # three device-to-device copies per step on the launch stream, +19 %)
-        feeder = DeviceFeeder(itertools.cycle(host), dev, 30, shard=(lo, hi), threaded=args.feed == 1, depth=4, ahead=2)
+        feeder = DeviceFeeder(itertools.cycle(host), dev, 30, shard=(lo, hi), threaded=args.feed == 2, depth=4, ahead=2)
         slot_graphs = {}
 
         def runner():
@@ -305,6 +309,8 @@ def main():
                 g_ = slot_graphs[key] = R.GraphedStep(step, e, t, T_, wd, warmup=0,
                                                       defer_reconstructor_update={0: False, 1: True, 2: "recurrent"}[args.defer])
             return g_()
+    if args.feed:
+        args.warmup = max(args.warmup, 40)          # (reported in the line: see --feed)
     for _ in range(args.warmup):
         runner()
     sync_all()
@@ -316,6 +322,7 @@ def main():
     if graphed is not None:
         graphed.flush()                                 # every timed step's optimiser work is inside the timed region
     ev1.record()
+    host_ms = (time.perf_counter() - t0) / args.steps * 1e3      # what the host needed to ENQUEUE a step (no wait for the device)
     sync_all()
     el = time.perf_counter() - t0
     ms_ev = ev0.elapsed_time(ev1) / args.steps          # the same region by hipEvents on the launch stream
@@ -344,7 +351,7 @@ def main():
             n_, ms_ = eng.profile_site(site if site > 0 else 5, one, 5)
             return (n_ // 5 if site > 0 else n_), ms_
         phases = None
-        if not step.reduce and not args.feed:
+        if not step.reduce:
             phases = phase_table(eng, runner)
             if phases:
                 phases["between_steps_us"] = round(ms * 1e3 - phases["span_us"], 1)
@@ -367,7 +374,7 @@ def main():
         out = {
             "metric": "captions/sec (train step) MSVD bs=100 28x1536 feats", "value": round(Bg * 1e3 / ms, 1),
             "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "ms_per_step_hipevent": round(ms_ev, 4), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4), "ms_per_step_hipevent": round(ms_ev, 4), "host_enqueue_ms_per_step": round(host_ms, 4), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "decoder + %s reconstructor train step (fwd+bwd+clip+Adam), B=%d per GPU, F=%d, "
                                    "D=R=%d, V=4188, E=468, H=512, A=128, T=%d, dropout 0.5, %s cells" % (args.rec, hi - lo, F, D, T, args.cell),

@@ -71,16 +71,21 @@ class DeviceFeeder:
     captions on the device while T / step weights still come from the whole (global) batch.
 
     Three stages, each on its own resource, over a ring of `depth` slots (pinned staging + device buffers):
-      worker thread : next(batches), host-side T / step weights, memcpy into the slot's pinned staging
-                      (numpy releases the GIL; 17 MB take ~3 ms of one core at B=100)
+      worker thread : next(batches), host-side T / step weights, memcpy into the slot's pinned staging (numpy releases the
+                      GIL; 17 MB take 0.34 ms of one core of the GPU box's host, 2 ms in the build container; `copy_threads`
+                      > 1 splits the features into row blocks on a small pool — no gain on either host, default 1).
+                      threaded=False stages on the calling thread instead (the bench's default: 1.70 against 1.81 ms per step)
       copy stream   : H2D of the staged slot, issued one batch ahead; waits (on the stream, not the host) for the
                       step that last read the slot's device buffers
       caller stream : waits for the slot's copy event only.
     The returned tensors are the slot's device buffers: they are valid until the call after next."""
 
-    def __init__(self, batches, device, caption_max_len=30, shard=None, depth=3, threaded=True, ahead=1):
+    def __init__(self, batches, device, caption_max_len=30, shard=None, depth=3, threaded=True, ahead=1, copy_threads=1):
         import queue
         import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.copy_threads = max(1, int(copy_threads))
+        self._pool = ThreadPoolExecutor(self.copy_threads) if self.copy_threads > 1 else None
         from .api import decode_len, step_weights
         self._decode_len, self._step_weights = decode_len, step_weights
         self.it = iter(batches)
@@ -138,9 +143,20 @@ class DeviceFeeder:
         s = self.free.get()
         if s is None or s["enc_n"].shape != enc.shape:
             s = self._new_slot(enc.shape, tgl.shape)
-        if s["copied"] is not None:
-            s["copied"].synchronize()            # the staging's previous H2D has drained (long ago)
-        np.copyto(s["enc_n"], enc, casting="same_kind"); np.copyto(s["tg_n"], tgl); s["w_n"][:T] = w
+        if s["copied"] is not None and not s["copied"].query():
+            # the staging's previous H2D has not drained: the copy stream holds it behind the step that last read the slot's
+            # device buffers, i.e. the host has run ~6 steps ahead of the device.  This wait is the loop's back-pressure (round 4
+            # measured 0.8 ms per batch here at the benchmark shape: the device, not the host, sets the pace)
+            s["copied"].synchronize()
+        n, k = enc.shape[0], self.copy_threads
+        if self._pool is not None and enc.nbytes >= (4 << 20) and n >= k:
+            futs = [self._pool.submit(np.copyto, s["enc_n"][i * n // k:(i + 1) * n // k], enc[i * n // k:(i + 1) * n // k], "same_kind")
+                    for i in range(k)]
+            for f in futs:
+                f.result()
+        else:
+            np.copyto(s["enc_n"], enc, casting="same_kind")
+        np.copyto(s["tg_n"], tgl); s["w_n"][:T] = w
         return s, T
 
     def _work(self):

@@ -1,0 +1,34 @@
+#!/bin/bash
+# The round's final collection in one gpurun call (bench lines, rocprofv3 kernel stats + one-step timelines of C2 / C3 / C4, soak):
+#   gpurun --timeout 2400 -- 'bash tools/collect_final.sh'      -> gpurun_out/r04/ ; copy what is to be judged into profiles/r04_*
+# (the --pmc traffic passes are tools/collect_profiles.sh's; the chain kernels did not change after them)
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+RND=r04; O=gpurun_out/$RND; mkdir -p $O
+x="--no-cpu-baseline --no-fp32-exact"
+C3="--rec local"; C4="--rec local --batch 32 --frames 40 --feat 2048"; C5="--rec local --batch 64 --frames 28 --feat 3584"
+python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err                  # the headline line, complete (cpu_baseline, fp32_exact)
+for n in c2 c3 c4; do
+  case $n in c2) a="";; c3) a="$C3";; c4) a="$C4";; esac
+  [ $n != c2 ] && python3 bench.py $a $x > $O/bench_$n.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats -d $O/prof_$n -o $n -- python3 bench.py $a $x --steps 30 > $O/bench_under_rocprof_$n.json 2>/dev/null
+  python3 tools/rocpd_stats.py $O/prof_$n/${n}_results.db > $O/kernel_stats_$n.csv
+  python3 tools/step_timeline.py $O/prof_$n/${n}_results.db 0 > $O/timeline_$n.txt
+  rm -rf $O/prof_$n
+done
+python3 bench.py $C5 $x > $O/bench_c5.json 2>/dev/null
+python3 bench.py --rec none $x > $O/bench_decoder_only.json 2>/dev/null
+python3 bench.py --lengths msvd $x > $O/bench_c2_msvd_lengths.json 2>/dev/null
+python3 bench.py --cell GRU $x > $O/bench_c2_gru.json 2>/dev/null
+python3 bench.py --batch 200 $x > $O/bench_c2_B200.json 2>/dev/null
+python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c4_weak_B256.json 2>/dev/null
+python3 bench.py --defer 0 $x > $O/bench_c2_update_inside_the_step.json 2>/dev/null
+python3 bench.py $C3 --defer 0 $x > $O/bench_c3_update_inside_the_step.json 2>/dev/null
+RN_GEMM_GROUP=0 python3 bench.py $x > $O/bench_c2_no_grouped_launches.json 2>/dev/null
+RN_DEC_LOCAL_WH=0 python3 bench.py $x > $O/bench_c2_attention_projection_in_phase_A.json 2>/dev/null
+RN_ADAM_EPILOGUE=0 python3 bench.py $x > $O/bench_c2_adam_kernel_instead_of_epilogue.json 2>/dev/null
+RN_WAIT_CHAIN=0 python3 bench.py $x > $O/bench_c2_no_residency_waits.json 2>/dev/null
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --force-allreduce $x 2>/dev/null | tail -1 > $O/bench_c2_dp_one_rank_one_graph.json
+RN_DP_ONE_GRAPH=0 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --force-allreduce $x 2>/dev/null | tail -1 > $O/bench_c2_dp_one_rank_three_graphs.json
+for i in 1 2 3; do python3 bench.py --feed 1 $x 2>/dev/null | tail -1 > $O/bench_c2_host_feed_$i.json; python3 bench.py $x > $O/bench_c2_resident_$i.json 2>/dev/null; done
+python3 tools/soak.py 20000 > $O/soak.json 2> $O/soak.err
+ls $O | wc -l
