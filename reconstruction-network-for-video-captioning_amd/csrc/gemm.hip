@@ -105,10 +105,16 @@ int rn_pick_splitk(int prec, int M, int N, int K, int max_split, int chain) {
 
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
-                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag, int c_bf16, void* c2, int ldc2) {
+                    int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag, int c_bf16, void* c2, int ldc2,
+                    const RnMse* mse) {
   if (M <= 0 || N <= 0) return;
   GemmArgs a;
   a.c_bf16 = c_bf16; a.C2 = c2; a.ldc2 = ldc2; a.cnt = nullptr; a.ad_p = nullptr;
+  a.mse_ref = nullptr; a.mse_part = nullptr; a.mse_bstride = a.mse_sstride = 0; a.mse_B = 1; a.mse_gcoef = a.mse_lp = 0.f;
+  if (mse) {      // (the caller has checked: bf16 operands, N % 4 == 0, 16-byte aligned rows of C / ref, c2 set)
+    a.mse_ref = mse->ref; a.mse_part = mse->part; a.mse_bstride = mse->bstride; a.mse_sstride = mse->sstride; a.mse_B = mse->B;
+    a.mse_gcoef = mse->gcoef; a.mse_lp = mse->lp;
+  }
   if (c_bf16 || c2) splitk = 1;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -275,7 +281,7 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
     const size_t slab = (size_t)e.M * e.N;
     if (s > 1 && (ws_off + (size_t)s * slab > ws_floats || cnt_off + pr[k].tiles > cnt_words || (size_t)s * slab * 4 >= ((size_t)1 << 31))) s = 1;
     a.splitk = s; a.kchunk = (s > 1 ? per : pr[k].nkt) * 64;
-    a.ws = nullptr; a.cnt = nullptr;
+    a.ws = nullptr; a.cnt = nullptr; a.mse_ref = nullptr; a.mse_part = nullptr;
     if (s > 1) { a.ws = ws + ws_off; a.cnt = cnt + cnt_off; ws_off += (size_t)s * slab; cnt_off += pr[k].tiles; }
     g.first[k] = blocks;
     blocks += pr[k].tiles * s;

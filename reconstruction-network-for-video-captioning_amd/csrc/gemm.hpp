@@ -30,6 +30,10 @@ struct GemmArgs {
   float* ad_p; float* ad_m; float* ad_v; float* ad_vmax; void* ad_img; void* ad_imgt; const float* ad_pnorm; int ad_ld_img, ad_ld_imgt;
   unsigned* cnt;              // grouped launches (gemm_group_kernel) with splitk > 1: one arrival counter per output tile —
                               // the slice that arrives last sums the slabs and runs the epilogue (no reduction launch)
+  // MSE in the epilogue (gemm_lds.hpp, direct fp32 epilogue, splitk == 1; the local reconstructor's output layer, train.py:126-128):
+  // row = s * mse_B + b is compared with ref[b * bstride + s * sstride + col]; C <- gcoef * diff (d loss / d out), C2 <- bf16
+  // (lp * gcoef * diff), mse_part[tile] <- sum diff^2 of the tile (summed in tile order by rec_loss_finalize_kernel).  null: off
+  const float* mse_ref; float* mse_part; size_t mse_bstride, mse_sstride; int mse_B; float mse_gcoef, mse_lp;
 };
 
 template <typename CT> struct GemmCfg;

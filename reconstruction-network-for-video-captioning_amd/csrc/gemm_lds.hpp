@@ -378,6 +378,7 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
       return;
     }
   }
+  float msq = 0.f;               // MSE epilogue: this lane's sum of squared differences
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -408,6 +409,18 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
           if (vec4 && col + 3 < p.N) {
             f32x4 w = f32x4{o[0], o[1], o[2], o[3]};
             if (p.accumulate) { const f32x4 old = *reinterpret_cast<const f32x4*>(dst); w += old; }
+            if (p.mse_ref) {      // (host: N % 4 == 0, aligned reference rows, C2 set — see GemmArgs)
+              const int s_ = row / p.mse_B, b_ = row - s_ * p.mse_B;
+              const f32x4 e = *reinterpret_cast<const f32x4*>(p.mse_ref + (size_t)b_ * p.mse_bstride + (size_t)s_ * p.mse_sstride + col);
+              const f32x4 d = w - e;
+              msq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+              w = p.mse_gcoef * d;
+              *reinterpret_cast<f32x4*>(dst) = w;
+              const f32x4 wl = p.mse_lp * w;
+              bf16x4 hb; hb[0] = (bf16_t)wl[0]; hb[1] = (bf16_t)wl[1]; hb[2] = (bf16_t)wl[2]; hb[3] = (bf16_t)wl[3];
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C2) + (size_t)row * p.ldc2 + col) = hb;
+              continue;
+            }
             *reinterpret_cast<f32x4*>(dst) = w;
             if (p.C2) {
               bf16x4 hb; hb[0] = (bf16_t)w[0]; hb[1] = (bf16_t)w[1]; hb[2] = (bf16_t)w[2]; hb[3] = (bf16_t)w[3];
@@ -424,6 +437,15 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
         }
       }
     }
+  }
+  if (p.mse_ref && !to_slab) {      // (block-uniform) the tile's sum of squares -> its slot of the partial sums
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) msq += __shfl_down(msq, off, 64);
+    __syncthreads();               // every wave is done with its staging block
+    float* red = reinterpret_cast<float*>(gl_smem);
+    if (lane == 0) red[wave] = msq;
+    __syncthreads();
+    if (tid == 0) p.mse_part[(size_t)by * ((p.N + BN - 1) / BN) + bx] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 

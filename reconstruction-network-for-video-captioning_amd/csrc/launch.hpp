@@ -25,10 +25,12 @@ int rn_pick_splitk(int prec, int M, int N, int K, int max_split, int chain);
 int rn_effective_splitk(int prec, int K, int splitk);
 // a_bf16 / b_bf16: operand memory holds bf16 (pre-packed) instead of fp32.  reduce_after: when splitk > 1,
 // run the slab reduction (otherwise the caller's fused consumer sums ws[z][M][N] itself).
+// MSE epilogue of the bf16 DMA kernel (GemmArgs::mse_*): row = s * B + b against ref[b * bstride + s * sstride + col]
+struct RnMse { const float* ref; float* part; size_t bstride, sstride; int B; float gcoef, lp; };
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
                     int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag = 0, int c_bf16 = 0,
-                    void* c2 = nullptr, int ldc2 = 0);
+                    void* c2 = nullptr, int ldc2 = 0, const RnMse* mse = nullptr);
 
 // Grouped launch: up to 8 products of ONE operand layout (a_col, b_col) with bf16 operands in one grid (gemm_lds.hpp:
 // gemm_group_kernel).  Split factors are chosen here from a list-scheduling estimate over 2 workgroups per CU; a split
