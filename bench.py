@@ -161,8 +161,10 @@ def phase_table(eng, run, replays=12):
     end of the step's last kernel; between_steps = ms_per_step - span (graph launch + the ungraphed part of the replay)."""
     import statistics
     rows = []
+    burst = int(os.environ.get("RN_PHASE_BURST", "1"))      # (diagnostic: stamps of the LAST of `burst` back-to-back replays)
     for _ in range(replays):
-        run()
+        for _ in range(burst):
+            run()
         rows.append(eng.read_stamps())
     rows = [r for r in rows if r["end"] and r["chains"]]
     if not rows:
