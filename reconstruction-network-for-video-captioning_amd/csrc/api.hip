@@ -108,6 +108,7 @@ struct recnet_handle {
   int side_pending = 0, side_T = 0, side_phase = 0, side_err = 0;   // side_after_decoder_fwd (abi_step.inc)
   const int64_t* side_targets = nullptr; const float* side_stepw = nullptr; const float* side_enc = nullptr;
   int late_join = 0;
+  int bgrp_loc = 0;              // ... of the local reconstructor's chains (<= 64 rows where more do not fit: recnet_create)
   int bgrp = 0;                  // rows per launch of the persistent chain kernels: B for B <= RC_PAN_ROWS, else B split evenly into ceil(B / 112) row groups
   // deferred reconstructor update (recnet_set_deferred_reconstructor_update): ctrl[2] on the device says whether an update is
   // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
@@ -373,9 +374,20 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     const char* eb = getenv("RN_PERSIST_REC_BWD");
     h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
   }
+  h->bgrp_loc = h->bgrp;
   {
     // loc_chain.hpp: the local reconstructor's forward chain as one launch (unit-owner + caption workgroups + relay)
     const char* e = getenv("RN_PERSIST_LOC");
+    // Row groups of the LOCAL chains (round 4): above 64 rows the forward chain splits its unit owners into two row parts
+    // (2 R / 16 workgroups) and the backward chain's U' role takes all rows — at R = 2048 that is 279 workgroups, more than the
+    // chip has CUs, and a batch (or row group) of more than 64 captions ran the per-step kernels there.  It now runs the local chains
+    // in groups of at most 64 rows (more, smaller groups than the decoder's chains, which take up to 112): every [s][B][.] tensor is
+    // indexed by the caption's row in the whole batch, so the two groupings do not have to agree.
+    int Bg = h->bgrp;      // (shadows the decoder's group size inside this block)
+    if (h->kind == RECNET_REC_LOCAL && Bg > 64 && h->R <= 2048 && (h->R / 16) * 2 + (Bg + LC_CPW - 1) / LC_CPW + 1 > h->ncu) {
+      const int ngl = (h->B + 63) / 64;
+      if (ngl <= 2 * RN_MAX_ROW_GROUPS) { Bg = (h->B + ngl - 1) / ngl; h->bgrp_loc = Bg; }
+    }
     h->lc_ms = Bg > 64 ? 2 : 1; h->lc_rb = (Bg <= 32) ? 2 : 4;
     h->lc_ng = h->R / 16; h->lc_nc = (Bg + LC_CPW - 1) / LC_CPW;
     // (the relay workgroup is dropped when there is no CU left for it: nwg - 1 == CU count, R = 3584 with 64 captions)

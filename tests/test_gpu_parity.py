@@ -338,13 +338,17 @@ EDGE = {
 }
 # K = 4R = 4096: two K parts in the backward chain's X' role (lcb_xsplit_role), second row part with two rows
 EDGE_KSPLIT = {"LOC_R1024_B34_two_k_parts": ([34, 2, 1024, 29, 8, 64, 16, 16], [(5 * i) % 6 for i in range(34)])}
+# round 4: at R = 2048 the local chains do not fit the chip with more than 64 rows (279 workgroups): such a batch runs them in row
+# groups of <= 64 captions of their own — 70 captions as 35 + 35 beside ONE decoder group; 130 as 44 + 44 + 42 beside two of 65
+EDGE_LOC_GROUPS = {"LOC_R2048_B70_two_local_groups": ([70, 2, 2048, 29, 8, 32, 16, 16], [(5 * i) % 7 for i in range(70)], 2),
+                   "LOC_R2048_B130_three_local_groups": ([130, 2, 2048, 29, 8, 64, 16, 8], [(3 * i) % 5 for i in range(130)], 3)}
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
 @pytest.mark.parametrize("kind", ["global", "local"])
 @pytest.mark.parametrize("case", sorted(EDGE))
 def test_fused_step_vs_oracle_edge_shapes(case, kind, prec):
-    dims, lens = EDGE[case] if case in EDGE else EDGE_KSPLIT[case]
+    dims, lens = EDGE[case] if case in EDGE else (EDGE_KSPLIT[case] if case in EDGE_KSPLIT else EDGE_LOC_GROUPS[case][:2])
     B, F, D, V, E, H, A, RA = dims
     if H > 512 and kind == "local":
         pytest.skip("the H > 512 case exercises the decoder cell kernels; one reconstructor is enough")
@@ -478,6 +482,27 @@ def test_local_backward_chain_with_k_split_forced(case, monkeypatch):
     """lcb_xsplit_role is selected from R = 512 up; forced here so the small ragged shapes run through it as well."""
     monkeypatch.setenv("RN_LOC_XSPLIT", "2")
     test_fused_step_vs_oracle_edge_shapes(case, "local", "bf16")
+
+
+@pytest.mark.parametrize("case", sorted(EDGE_LOC_GROUPS))
+def test_local_chains_in_row_groups_of_their_own(case):
+    """The bf16 step against the oracle, and that the local chain kernels are what ran: one forward and one backward launch per
+    LOCAL row group (recnet_create: bgrp_loc), whatever the decoder's grouping is.  (The fp32 path has no chain kernels, and at
+    R = 2048 its loss bar of 1e-5 is below the error of the ORACLE's float32 norm over the 16.7 M elements of W_hh — 1.2e-4 of the
+    reconstructor's loss, see tests/test_gpu_configs.py.)"""
+    test_fused_step_vs_oracle_edge_shapes(case, "local", "bf16")
+    dims, lens, ngroups = EDGE_LOC_GROUPS[case]
+    B, F, D, V, E, H, A, RA = dims
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 31)
+    recP = GU.formula_params(GU.rec_shapes("local", H, D, RA), 32)
+    enc, targets = GU.make_batch(B, F, D, V, lens, 78)
+    C, dec, rec = make_models(dims, "local", "bf16", decP, recP)
+    step = R.TrainStep(dec, rec)
+    T, w = step.prepare(targets.numpy())
+    e, t = enc.cuda(), targets.cuda()
+    assert step.engine.profile_site(7, lambda: step.fwd_bwd(e, t, T, w, seed=6), 1)[0] == ngroups
+    assert step.engine.profile_site(8, lambda: step.fwd_bwd(e, t, T, w, seed=6), 1)[0] == ngroups
+    assert step.engine.chain_status() == 0
 
 
 @pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 37, 256)])
