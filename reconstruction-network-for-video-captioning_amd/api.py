@@ -427,6 +427,8 @@ class TrainStep:
         # config.py:71 decoder_teacher_forcing_ratio, handed to forward_decoder at train.py:251.  Every call of the step draws
         # `random.random() <= ratio` from Python's global generator like train.py:38 does (also at ratio 1, where the draw is
         # always True — the generator advances as the reference's does).  A False draw runs the free-running iteration.
+        # (Data parallel with a ratio below 1: every rank has to make the same draws — seed Python's generator identically on all
+        # ranks, random.seed(...), as a multi-process run of the reference would have to.)
         self.teacher_forcing_ratio = float(getattr(C, "decoder_teacher_forcing_ratio", 1.0) if teacher_forcing_ratio is None
                                            else teacher_forcing_ratio)
         self.output_indices = None        # [T, B] tokens the last free-running iteration fed back (train.py:50), else None
