@@ -305,7 +305,7 @@ def main():
             e, t, T_, wd = next(feeder)
             if not args.graph:
                 return step(e, t, T_, wd)
-            key = e.data_ptr()
+            key = (e.data_ptr(), int(T_))      # (a captured graph is specific to the slot's buffers AND the decode length)
             g_ = slot_graphs.get(key)
             if g_ is None:      # (first use of a slot, inside the warm-up: one capture per slot)
                 g_ = slot_graphs[key] = R.GraphedStep(step, e, t, T_, wd, warmup=0,

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define RECNET_ABI_VERSION 6
+#define RECNET_ABI_VERSION 7
 #define RECNET_ATTN_NONE 0
 #define RECNET_ATTN_SOFTMAX 1
 #define RECNET_OK 0
@@ -268,10 +268,8 @@ int recnet_optimizer_step_dev(recnet_handle* h, int32_t flags, recnet_scalars* s
  * 119 CUs idle) without delaying that step's reconstructor, and this step's BPTT window is not overfilled. */
 int recnet_set_deferred_reconstructor_update(recnet_handle* h, int32_t on, void* stream);
 int recnet_flush(recnet_handle* h, void* stream);
-/* A hipGraph that captured a fused step was replayed (replays run no host code): tells the handle that the reconstructor's
- * derived weight images are stale again (the fused step refreshes them lazily, at the start of its next run) and — with the
- * deferred update on — that an update may be pending, so that its other entry points catch up before they touch the
- * reconstructor. */
+/* A hipGraph that captured a fused step was replayed (replays run no host code): tells the handle that — with the deferred
+ * update on — an update may be pending, so that its other entry points catch up before they touch the reconstructor. */
 int recnet_mark_pending(recnet_handle* h);
 
 /* Data-parallel step inside ONE stream-ordered sequence (or one captured graph): with on != 0, part 1 of
@@ -281,6 +279,11 @@ int recnet_mark_pending(recnet_handle* h);
  * products itself (+0.2 ms in front of the BPTT at the benchmark shape).  train.py:264-273; SURVEY.md section 8e. */
 int recnet_set_dp_overlap(recnet_handle* h, int32_t on);
 int recnet_join_side(recnet_handle* h, void* stream);
+/* A stream capture that contained calls of this library was abandoned (e.g. api.GraphedStep: a collective could not be captured,
+ * train.py:264-273 under data parallelism): the enqueue-time bookkeeping of the step those calls were part of — open side
+ * branches, recorded-but-unjoined fork events, the data-parallel overlap switch — is put back to "between two steps".  No device
+ * work, no effect on parameters, gradients or a pending deferred update. */
+int recnet_abort_step(recnet_handle* h);
 
 /* ---- plumbing exposed for tests and profiling */
 /* Between begin and end every recurrent-step GEMM launch of one site (the dependent-chain kernels: one
@@ -378,6 +381,12 @@ int recnet_debug_raise_give_up(recnet_handle* h, int32_t chain_bit, void* stream
 /* Test hook: a kernel of `n_workgroups` workgroups that each take a whole CU (160 KB of LDS) and spin for `microseconds` —
  * what a resident collective (RCCL) kernel looks like to the persistent chain kernels.  Launch it on another stream. */
 int recnet_debug_occupy(recnet_handle* h, int32_t n_workgroups, int32_t microseconds, void* stream);
+/* Test hook: the packed operand images of the weights (bf16 / fp32 copies, transposes, streamed fragments — what the kernels
+ * read instead of the master parameters; rewritten by the optimiser kernels, by the Adam epilogue of the pending d W_hh product
+ * and by recnet_pack_weights) are copied aside, re-packed from the master parameters, and compared: *n_diff_out = number of
+ * 16-bit words that differ (0 = every image was up to date).  Completes a pending deferred update first; synchronises the
+ * stream; leaves the images freshly packed.  Holds train.py:271-273 "the next forward uses the updated weights" for the images. */
+int recnet_debug_images_stale(recnet_handle* h, int64_t* n_diff_out, void* stream);
 /* Test hook: byte offset inside the bound workspace of a saved tensor of the local reconstructor's forward pass
  * (0: Whr [F][B][RA], 1: beta [F][B][T], 2: Hr [F][B][R], 3: acts [F][B][4R]); -1 if unknown. */
 int64_t recnet_debug_offset(const recnet_handle* h, int32_t which);

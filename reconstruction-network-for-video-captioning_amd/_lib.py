@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RN_LIB_PROBE=1: the probe build (in-kernel time stamps); RN_LIB_VARIANT=acqinv: the cross-check build with acquire fences
 _VARIANT = "_probe" if os.environ.get("RN_LIB_PROBE") == "1" else ("_" + os.environ["RN_LIB_VARIANT"] if os.environ.get("RN_LIB_VARIANT") else "")
 LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip%s.so" % _VARIANT)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 REC_NONE, REC_GLOBAL, REC_LOCAL = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
@@ -137,6 +137,8 @@ EXPORTS["recnet_gemm_group_bf16"] = (_i, [_i, _i, _i, C.POINTER(C.c_void_p), C.P
                                          C.POINTER(_i), C.POINTER(C.c_float), C.POINTER(_i), C.c_void_p, C.c_int64, C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_set_dp_overlap"] = (_i, [C.c_void_p, _i])
 EXPORTS["recnet_join_side"] = (_i, [C.c_void_p, C.c_void_p])
+EXPORTS["recnet_abort_step"] = (_i, [C.c_void_p])
+EXPORTS["recnet_debug_images_stale"] = (_i, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p])
 EXPORTS["recnet_read_stamps"] = (_i, [C.c_void_p, C.POINTER(C.c_uint64), _i, C.c_void_p])
 EXPORTS["recnet_gemm_bf16"] = (_i, [C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _f, _i, _i,
                                   C.c_void_p, _i, C.c_void_p])

@@ -427,11 +427,12 @@ class TrainStep:
         # config.py:71 decoder_teacher_forcing_ratio, handed to forward_decoder at train.py:251.  Every call of the step draws
         # `random.random() <= ratio` from Python's global generator like train.py:38 does (also at ratio 1, where the draw is
         # always True — the generator advances as the reference's does).  A False draw runs the free-running iteration.
-        # (Data parallel with a ratio below 1: every rank has to make the same draws — seed Python's generator identically on all
-        # ranks, random.seed(...), as a multi-process run of the reference would have to.)
+        # (Data parallel with a ratio below 1: rank 0's draw is broadcast, see _draw.  GraphedStep replays the teacher-forced step
+        # and makes NO draw — it refuses a ratio below 1 — so Python's generator advances per eager step only.)
         self.teacher_forcing_ratio = float(getattr(C, "decoder_teacher_forcing_ratio", 1.0) if teacher_forcing_ratio is None
                                            else teacher_forcing_ratio)
         self.output_indices = None        # [T, B] tokens the last free-running iteration fed back (train.py:50), else None
+        self.sync_draw = None             # data parallel: callable(local draw) -> the draw every rank uses (dp.py)
         dm = decoder["model"]
         rm = reconstructor["model"] if reconstructor else None
         B = batch_size or C.batch_size
@@ -454,6 +455,16 @@ class TrainStep:
     def scalars(self):
         return self.engine.scalars
 
+    def _draw(self):
+        """The iteration's teacher-forcing draw, train.py:38: one `random.random()` from Python's global generator per call of the
+        step (also at ratio 1, where it is always True).  Under data parallelism every rank has to run the same kind of iteration:
+        dp.DataParallelTrainStep installs `sync_draw`, which replaces the local draw by rank 0's (each rank still consumes one
+        value of its own generator per step)."""
+        tf = random.random() <= self.teacher_forcing_ratio
+        if self.sync_draw is not None and self.teacher_forcing_ratio < 1.0:
+            tf = bool(self.sync_draw(tf))
+        return tf
+
     def prepare(self, targets_host):
         """Host-side, from the batch's (global) targets: (T, step weights as a device tensor)."""
         masks = np.asarray(targets_host) > PAD
@@ -466,7 +477,7 @@ class TrainStep:
         # dropout seed of optimiser step n (1-based) = seed_base + n, the same rule the device-side counter of
         # the graph-replay path applies (recnet_train_step_fwd_bwd_dev)
         seed = self.seed_base + ms.step + 1 if seed is None else seed
-        if random.random() <= self.teacher_forcing_ratio:                             # train.py:38
+        if self._draw():
             self.output_indices = None
             self.engine.train_step_fwd_bwd(enc, targets, T, step_weight, seed)
         else:
@@ -491,7 +502,7 @@ class TrainStep:
         ms.step += 1
         if self.reconstructor:
             self.reconstructor["_state"].step = ms.step
-        if random.random() <= self.teacher_forcing_ratio:                             # train.py:38
+        if self._draw():
             self.output_indices = None
             self.engine.train_step(enc, targets, T, step_weight, seed, ms.step)
         else:
@@ -558,11 +569,30 @@ class GraphedStep:
         self.defer_mode = ("recurrent" if defer_reconstructor_update in (2, "recurrent") else True) if self.deferred else False
         eng.set_deferred_reconstructor_update(self.defer_mode)
         eng.set_step(self.ms.step)
+        # Data parallel: ONE graph with the collectives captured inside it (RCCL kernels are capturable; round 4) — one replay per
+        # step instead of three with two eager collectives between them.  It has run on RCCL with ONE rank only (no multi-GPU box
+        # was available to any round), so it is the default at world size 1 and OPT-IN (RN_DP_ONE_GRAPH=1) above that, where the
+        # three-graph form with eager collectives is the default.  A backend whose collectives cannot be captured (gloo in the CPU
+        # tests) and the direct reduce-scatter transport (it stages through torch ops on a stream of its own) always take the
+        # three-graph form.
+        self.one_graph = False
+        want_one = False
+        if self.split:
+            import os as _os
+            import torch.distributed as _dist
+            nccl = _dist.is_available() and _dist.is_initialized() and _dist.get_backend(dp_step.group) == "nccl"
+            world = _dist.get_world_size(dp_step.group) if nccl else 1
+            want_one = bool(int(_os.environ.get("RN_DP_ONE_GRAPH", "1" if world == 1 else "0")) and self.enc.is_cuda and
+                            dp_step.transport.algo == "ring" and nccl)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up outside capture (lazy module loading, RCCL init)
             for _ in range(warmup):
-                self._eager()
+                if want_one:                               # the very sequence the capture records: its first execution is eager
+                    self._dp_body()
+                    self._bump()
+                else:
+                    self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # thread_local: the RCCL watchdog thread of torch.distributed issues event queries of its own; in the
@@ -575,26 +605,32 @@ class GraphedStep:
                 eng.train_step_dev(self.enc, self.targets, self.T, self.w, self.seed_base, self.flags)
             self.graphs = [g]
         else:
-            # ONE graph with the collectives captured inside it (RCCL kernels are capturable; round 4) — one replay per step
-            # instead of three with two eager collectives between them.  RN_DP_ONE_GRAPH=0, or a backend whose collectives
-            # cannot be captured (gloo in the CPU tests), takes the three-graph form.
-            import os as _os
-            self.one_graph = False
-            # (ring transport only: the direct reduce-scatter form stages through plain torch ops on a side stream of its own)
             import torch.distributed as _dist
-            nccl = _dist.is_available() and _dist.is_initialized() and _dist.get_backend(dp_step.group) == "nccl"
-            if int(_os.environ.get("RN_DP_ONE_GRAPH", "1")) and self.enc.is_cuda and dp_step.transport.algo == "ring" and nccl:
+            if want_one:
+                ok = 1
                 try:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, **mode):
                         self._dp_body()
-                    self.graphs = [g]
-                    self.one_graph = True
                 except Exception as e:          # noqa: BLE001  (the capture is abandoned; nothing ran)
                     import warnings
-                    warnings.warn("one-graph data-parallel step unavailable (%s): three graphs + eager collectives" % (e,))
+                    warnings.warn("one-graph data-parallel step unavailable on this rank (%s)" % (e,))
+                    ok = 0
                     torch.cuda.synchronize()
+                    eng.abort_step()             # the handle's enqueue-time flags back to "between two steps"
+                # every rank takes the SAME form: one rank replaying captured collectives against peers that issue eager ones
+                # would deadlock or, worse, pair up the wrong buffers
+                flag = torch.tensor([ok], device=self.enc.device, dtype=torch.int32)
+                _dist.all_reduce(flag, op=_dist.ReduceOp.MIN, group=dp_step.group)
+                torch.cuda.synchronize()
+                if int(flag.item()) == 1:
+                    self.graphs = [g]
+                    self.one_graph = True
+                else:
                     self.graphs = []
+                    if ok:
+                        import warnings
+                        warnings.warn("one-graph data-parallel step unavailable on a peer rank: three graphs + eager collectives")
             if not self.one_graph:
                 for part in (1, 2):
                     g = torch.cuda.CUDAGraph()

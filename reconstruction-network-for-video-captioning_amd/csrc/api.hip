@@ -112,9 +112,7 @@ struct recnet_handle {
   int bgrp = 0;                  // rows per launch of the persistent chain kernels: B for B <= RC_PAN_ROWS, else B split evenly into ceil(B / 112) row groups
   // deferred reconstructor update (recnet_set_deferred_reconstructor_update): ctrl[2] on the device says whether an update is
   // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
-  // lazy refresh of the reconstructor's derived weight images (transposes, streamed fragments): the fused step leaves them stale
-  // at its end and refreshes them in its next run's hoisted side work, under the decoder forward chain (host_common.inc)
-  int lazy_images = 0, in_fused = 0, rec_images_stale = 0, side_fork_recorded = 0;
+  int in_fused = 0, side_fork_recorded = 0;
   int dp_overlap = 0, side_open = 0;   // recnet_set_dp_overlap: part 1 of the data-parallel step leaves the side stream's weight-gradient products unjoined (recnet_join_side)
   int hoist_fork_recorded = 0;   // dec_fwd_chain recorded the fork events of hoist_side_work itself, in front of the chain launch
   int side_tail_open = 0;  // decoder-only: dec_bwd_out recorded the BPTT's join in front of the rest of the side branch (ev[18] covers the rest)
@@ -141,7 +139,7 @@ struct recnet_handle {
   unsigned* gcnt = nullptr;      // tile counters of the grouped launches' in-launch split-K sums: one block of RN_GCNT_WORDS per slab workspace
   int gg_site = 0;               // the next grouped launch stamps its start / end into this slot (1..8) of the group stamps
   int gg_slots = 0;              // workgroup slots the next grouped launches can expect (0 = whole chip): see host_common.inc
-  int gemm_single_group = 0;     // RN_GEMM_SINGLE=0: single products take gemm_lds_kernel + splitk_reduce_kernel (round-3 form)
+  int gemm_single_group = 0;     // set around a single product whose K slices are to be summed inside its launch (host_decoder.inc: the embedding branch)
   hipStream_t s2 = nullptr; hipEvent_t ev[24] = {}; int overlap = 1;
   // bindings
   recnet_decoder_tensors dP{}, dGd{}, dM{}, dV{}, dVm{};
@@ -342,10 +340,6 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->RA = c.reconstructor_type == RECNET_REC_LOCAL ? c.reconstructor_attn_size : 0;
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
-  // Lazy refresh of the reconstructor's derived weight images is OPT-IN: a caller that replays a captured fused step
-  // and then calls a non-fused reconstructor entry point would otherwise read stale transposes unless it calls recnet_mark_pending.
-  // The default step of this library — the split update, mode 2 — rewrites the images where it updates the weights.
-  h->lazy_images = 0;
   h->gemm_single_group = 0;
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
@@ -647,9 +641,7 @@ extern "C" {
 // A pending deferred reconstructor update (recnet_set_deferred_reconstructor_update) is completed before anything else
 // reads the reconstructor's parameters, packed images, gradients or Adam state.
 static void refresh_rec_images(recnet_handle* h, hipStream_t st);
-static int flush_pending(recnet_handle* h, hipStream_t st, int explicit_call = 0, int images = 1) {
-  // (images = 0: the fused step refreshes them itself, in its hoisted side work)
-  if (images && h->rec_images_stale && h->rec_bound) { refresh_rec_images(h, st); h->rec_images_stale = 0; }
+static int flush_pending(recnet_handle* h, hipStream_t st, int explicit_call = 0) {
   // maybe_pending is the host's shadow of the device's pending word: set when a deferred step is enqueued or captured, and
   // by recnet_mark_pending when a captured one is replayed.  An explicit recnet_flush also runs while the mode is on (the
   // device word decides whether the Adam step happens; the products are recomputed from the step's own operands either way).

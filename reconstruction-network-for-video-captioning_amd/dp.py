@@ -138,6 +138,16 @@ class DataParallelTrainStep:
         self.step_impl = TrainStep(decoder, reconstructor, batch_size=self.hi - self.lo, n_frames=n_frames,
                                    global_batch=global_batch, batch_offset=self.lo)
         self.decoder, self.reconstructor = decoder, reconstructor
+        if world_size > 1:
+            # train.py:38 draws `random.random() <= ratio` per iteration; ranks whose generators differ would silently mix a
+            # teacher-forced shard with free-running ones and all-reduce the result: every rank takes rank 0's draw
+            self.step_impl.sync_draw = self._rank0_draw
+
+    def _rank0_draw(self, tf):
+        import torch.distributed as dist
+        box = [bool(tf)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return box[0]
 
     @property
     def scalars(self):

@@ -281,6 +281,10 @@ class Engine:
     def set_dp_overlap(self, on):
         _lib.check(self.lib.recnet_set_dp_overlap(self.handle, int(bool(on))), "recnet_set_dp_overlap")
 
+    def abort_step(self):
+        """After an abandoned stream capture: the handle's enqueue-time bookkeeping back to "between two steps" (recnet_abort_step)."""
+        _lib.check(self.lib.recnet_abort_step(self.handle), "recnet_abort_step")
+
     def join_side(self):
         """The current stream waits for the library's side stream (recnet_join_side)."""
         _lib.check(self.lib.recnet_join_side(self.handle, _stream()), "recnet_join_side")
@@ -298,6 +302,13 @@ class Engine:
         assert off >= 0
         base = (self._ws_ptr - self.workspace.data_ptr()) + off
         return self.workspace[base:base + 4 * n].view(torch.float32).clone()
+
+    def images_stale(self):
+        """Test hook: number of 16-bit words in which the packed operand images differ from a fresh re-pack of the master
+        parameters (recnet_debug_images_stale); completes a pending update and synchronises."""
+        n = C.c_int64(-1)
+        _lib.check(self.lib.recnet_debug_images_stale(self.handle, C.byref(n), _stream()), "recnet_debug_images_stale")
+        return int(n.value)
 
     def debug_occupy(self, n_workgroups, microseconds, stream=None):
         """Test hook: n_workgroups CU-filling workgroups spinning for `microseconds` on `stream` (a torch stream; default: the current one)."""

@@ -106,7 +106,7 @@ ONLY = None   # --only a,b,c : regenerate just these cases
 
 def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None, rec_cell="LSTM",
              RA=None, train_mode=True, n_steps=3, seed=0, drop_seed=42, full=True, formula_seed=None,
-             tf_ratio=1.0, py_seed=None, out_scale=None):
+             tf_ratio=1.0, py_seed=None, out_scale=None, dec_lr=None, rec_lr=None):
     """tf_ratio < 1 (config.py:71 decoder_teacher_forcing_ratio): forward_decoder draws `random.random() <= ratio` once per
     iteration (train.py:38) from Python's global generator, seeded here with py_seed; the iterations that draw False feed the
     arg-max back (train.py:46-51) and are differentiated like the others.  out_scale: a decisive vocabulary projection, so the
@@ -116,8 +116,16 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
     RA = RA or A
     configure(B=B, F=F, D=D, V=V, E=E, H=H, A=A, dec_cell=dec_cell, rec_kind=rec_kind, rec_cell=rec_cell, RA=RA)
     torch.manual_seed(seed)
+    # dec_lr / rec_lr: the reference's own config attributes (config.py:86-87) read by build_decoder / build_reconstructor
+    # (train.py:149,186) — larger values make three updates move every parameter far beyond any comparison tolerance
+    lr_keep = (C.decoder_learning_rate, C.reconstructor_learning_rate)
+    if dec_lr is not None:
+        C.decoder_learning_rate = dec_lr
+    if rec_lr is not None:
+        C.reconstructor_learning_rate = rec_lr
     dec = ref_train.build_decoder(V)
     rec = ref_train.build_reconstructor() if rec_kind else None
+    C.decoder_learning_rate, C.reconstructor_learning_rate = lr_keep
     if formula_seed is not None:
         dec["model"].load_state_dict(formula_params(dec["model"].state_dict(), formula_seed))
         if rec:
@@ -142,6 +150,8 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
            "meta_train_mode": np.array(int(train_mode)), "meta_n_steps": np.array(n_steps),
            "meta_formula_seed": np.array(-1 if formula_seed is None else formula_seed),
            "meta_cells": np.array([int(dec_cell == "GRU"), int(rec_cell == "GRU")], dtype=np.int64)}
+    if dec_lr is not None or rec_lr is not None:
+        out["meta_lr"] = np.array([lr_keep[0] if dec_lr is None else dec_lr, lr_keep[1] if rec_lr is None else rec_lr], dtype=np.float64)
     if full:
         out["enc"] = enc.numpy()
     out["targets"] = targets.numpy()
@@ -232,6 +242,9 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
         if rec:
             rec["optimizer"].step()
         out["loss_step%d" % it] = np.array(loss.item(), dtype=np.float64)
+        out["dec_loss_step%d" % it] = np.array(dl.item(), dtype=np.float64)
+        if rec:
+            out["rec_loss_step%d" % it] = np.array(rl.item(), dtype=np.float64)
         if it == 0 and full:
             for k, v in dm.state_dict().items():
                 out["dec_after1/" + k] = v.detach().numpy().copy()
@@ -251,6 +264,11 @@ def run_case(name, *, B, F, D, V, E, H, A, lens, dec_cell="LSTM", rec_kind=None,
             out["dec_opt/exp_avg_sq/" + k] = s["exp_avg_sq"].numpy().copy()
             if "max_exp_avg_sq" in s:
                 out["dec_opt/max_exp_avg_sq/" + k] = s["max_exp_avg_sq"].numpy().copy()
+        if rec and (dec_lr is not None or rec_lr is not None):      # (the older cases keep their files byte for byte)
+            for k, p in rec["model"].named_parameters():
+                s = rec["optimizer"].state[p]
+                out["rec_opt/exp_avg/" + k] = s["exp_avg"].numpy().copy()
+                out["rec_opt/exp_avg_sq/" + k] = s["exp_avg_sq"].numpy().copy()
     else:
         for k, v in dm.state_dict().items():
             out["dec_pnorm_after%d/" % n_steps + k] = np.array(np.linalg.norm(v.numpy().astype(np.float64)))
@@ -336,6 +354,15 @@ if __name__ == "__main__":
     # random.seed(py_seed) — teacher-forced and free-running iterations mixed, every one differentiated and stepped
     run_case("tf_half_global", lens=[6, 9, 2, 4, 4], rec_kind="global", n_steps=4, tf_ratio=0.5, py_seed=3, out_scale=6.0, **SMALL)
     run_case("tf_half_local", lens=[7, 3, 8, 1, 5], rec_kind="local", RA=16, n_steps=4, tf_ratio=0.5, py_seed=10, out_scale=6.0, **SMALL)
+    # the update path the benchmark runs (GraphedStep, split reconstructor update, Adam in the GEMM epilogue): shapes the persistent
+    # chains take (H % 32 == 0, R % 32 == 0), four iterations at learning rates of 1e-2 (config.py:86-87 attributes) — every update
+    # moves every parameter by ~1e-2, so a missing update, a stale operand image or a wrong transpose is far outside any tolerance;
+    # the reconstructor's Adam moments are stored as well
+    CHAIN = dict(B=24, F=6, D=64, V=61, E=16, H=32, A=16)
+    lens24 = [30, 4, 11, 2, 9, 7, 3, 8, 1, 5, 6, 9, 2, 4, 4, 12, 7, 21, 4, 9, 16, 5, 13, 10]
+    run_case("lr_global_chain", lens=lens24, rec_kind="global", n_steps=4, dec_lr=1e-2, rec_lr=1e-2, **CHAIN)
+    run_case("lr_local_chain", lens=lens24, rec_kind="local", RA=16, n_steps=4, dec_lr=1e-2, rec_lr=1e-2, **CHAIN)
+    run_case("lr_gru_global_chain", lens=lens24, dec_cell="GRU", rec_kind="global", rec_cell="GRU", n_steps=4, dec_lr=1e-2, rec_lr=1e-2, **CHAIN)
     # full-shape cases (SURVEY.md §8a C1..C3 dims): parameters from formula_params(seed) so they can be
     # regenerated without the reference; only outputs / norms / slices are stored.
     FULL = dict(F=28, D=1536, V=4188, E=468, H=512, A=128)

@@ -17,13 +17,15 @@ TOL = {
 }
 
 
-def make_models(dims, kind, precision, decP, recP, device="cuda", batch=None, cells=("LSTM", "LSTM"), attn_normalize="none"):
+def make_models(dims, kind, precision, decP, recP, device="cuda", batch=None, cells=("LSTM", "LSTM"), attn_normalize="none",
+                **config):
+    """config: further TrainConfig attributes (e.g. decoder_learning_rate, reconstructor_learning_rate)."""
     B, F, D, V, E, H, A, RA = dims
     C = R.make_config(batch_size=B, encoder_output_len=F, encoder_output_size=D, embedding_size=E,
                       decoder_hidden_size=H, decoder_attn_size=A, use_recon=kind is not None,
                       reconstructor_type=kind or "local", reconstructor_hidden_size=D,
                       reconstructor_attn_size=RA, precision=precision, device=device, decoder_model=cells[0],
-                      reconstructor_model=cells[1], decoder_attn_normalize=attn_normalize)
+                      reconstructor_model=cells[1], decoder_attn_normalize=attn_normalize, **config)
     dec = R.build_decoder(V, C)
     dec["model"].load_state_dict({k: v.clone() for k, v in decP.items()})
     rec = None

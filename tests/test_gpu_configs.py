@@ -165,3 +165,63 @@ def test_all_eight_shards_sum_to_the_full_batch(full_batch_case, prec):
     print("%s %s all shards: ce %.6f/%.6f mse %.6f/%.6f worst grad rel err %.2e (%s)" % (
         name, prec, ce, ref["ce"], mse, ref["mse"], max(v[0] for v in worst.values()), max(worst, key=lambda k: worst[k][0])))
     assert not bad, (name, prec, bad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The mode bench.py times by default — GraphedStep with the split reconstructor update (`--defer 2`: d W_hh and its Adam step left
+# pending by replay n and run by replay n + 1 beside its decoder forward chain, Adam in the epilogue of that grouped product, both
+# operand images of W_hh written there) — at the FULL size of configs[1] / [2], against three oracle iterations
+# (train.py:248-273 with torch.optim.Adam).  Learning rates of 1e-3 for both optimisers (config.py:86-87 attributes; the defaults
+# 1e-5 / 1e-6 move a weight by less than any usable tolerance): every update moves every weight by ~4 % of its magnitude, so the
+# losses of replay 2 and 3 are those of the UPDATED weights and their operand images, and the parameters are compared relative to
+# how far they moved (a missing update = 1.0, one of three = 0.33).
+FULL_LR = 1e-3
+MOVE_TOL = 8e-2
+
+
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_replayed_default_bench_mode_against_the_oracle_at_full_size(name):
+    kind, B, F, D, Bg, off = CONFIGS[name]
+    torch.set_num_threads(min(32, torch.get_num_threads() * 4))
+    decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 31)
+    recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 32)
+    tg = synthetic_targets(B, V, seed=77)
+    enc = synthetic_features(B, F, D, seed=78)
+    st = O.TrainState(decP, recP, kind, dec_lr=FULL_LR, rec_lr=FULL_LR)
+    n, seed0 = 3, 5
+    ref = [st.step(enc, tg, tg > 0, O.Dropper("hash", seed=seed0 + it)) for it in range(n)]
+    _, dec, rec = make_models([B, F, D, V, E, H, A, RA], kind, "bf16", decP, recP, decoder_learning_rate=FULL_LR,
+                              reconstructor_learning_rate=FULL_LR)
+    step = R.DataParallelTrainStep(dec, rec, B, 0, 1, n_frames=F)
+    step.step_impl.seed_base = seed0 - 1              # device-side rule: dropout seed of optimiser step n (1-based) = base + n
+    T, w = step.prepare(tg.numpy())
+    run = R.GraphedStep(step, enc.cuda(), tg.cuda(), T, w, warmup=0, defer_reconstructor_update="recurrent")
+    eng = step.step_impl.engine
+    assert run.deferred and eng.lib.recnet_dim(eng.handle, 10) == 1, "the split update is applied at the benchmark shapes"
+    got = [run().clone() for _ in range(n)]
+    run.flush()
+    torch.cuda.synchronize()
+    assert eng.chain_status() == 0
+    assert eng.images_stale() == 0       # every operand image = a fresh pack of the updated parameters, word for word
+    tol = TOL["bf16"]
+    steps_differ = min(abs(ref[i + 1][2] - ref[i][2]) for i in range(n - 1))
+    assert steps_differ > 10 * tol["loss"] * abs(ref[0][2]), [r[2] for r in ref]
+    for it in range(n):
+        sc = got[it].cpu().numpy()
+        dl, rl, total, gn = ref[it]
+        # (the oracle's regulariser is a float32 CPU norm, 1e-4 off on these tensors: 3e-4 of the value on top of the bf16 bar)
+        assert abs(float(sc[2]) - dl) <= (tol["loss"] + 3e-4) * abs(dl), (name, it, float(sc[2]), dl)
+        assert abs(float(sc[5]) - rl) <= (tol["loss"] + 3e-4) * abs(rl), (name, it, float(sc[5]), rl)
+        assert abs(float(sc[6]) - total) <= (tol["loss"] + 3e-4) * abs(total), (name, it, float(sc[6]), total)
+    worst = {}
+    for grp, md, P, P0 in (("dec", dec, st.dec, decP), ("rec", rec, st.rec, recP)):
+        for k, v in P.items():
+            a = md["model"].state_dict()[k].cpu().numpy().astype(np.float64)
+            r, i0 = v.detach().numpy().astype(np.float64), P0[k].numpy().astype(np.float64)
+            d = np.linalg.norm(r - i0)
+            assert d > 0, (grp, k)
+            worst[grp + "." + k] = float(np.linalg.norm((a - i0) - (r - i0)) / d)
+    print("%s replayed split update, lr %g: losses %s / oracle %s; worst parameter-movement error %.3e (%s)" % (
+        name, FULL_LR, [round(float(g[6]), 5) for g in got], [round(r[2], 5) for r in ref], max(worst.values()), max(worst, key=worst.get)))
+    bad = {k: v for k, v in worst.items() if v > MOVE_TOL}
+    assert not bad, (name, bad)

@@ -40,11 +40,12 @@ def _same(a, b, name, exact):
     return torch.allclose(a, b, rtol=2e-4, atol=2e-8)
 
 
-def _run(kind, prec, dims, deferred, lens_sets, order):
+def _run(kind, prec, dims, deferred, lens_sets, order, lr=None):
     B, F, D, V, E, H, A, RA = dims
     decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 3)
     recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA), 4)
-    _, dec, rec = make_models(list(dims), kind, prec, decP, recP)
+    cfg = {} if lr is None else dict(decoder_learning_rate=lr, reconstructor_learning_rate=lr)
+    _, dec, rec = make_models(list(dims), kind, prec, decP, recP, **cfg)
     step = R.DataParallelTrainStep(dec, rec, B, 0, 1, n_frames=F)
     graphs, losses = [], []
     for i, lens in enumerate(lens_sets):
@@ -57,6 +58,9 @@ def _run(kind, prec, dims, deferred, lens_sets, order):
     graphs[0].flush()
     torch.cuda.synchronize()
     assert step.step_impl.engine.chain_status() == 0
+    import os
+    if not os.environ.get("RN_T_SKIP_IMAGES"):
+        assert step.step_impl.engine.images_stale() == 0      # the operand images follow the parameters, whichever path updated them
     return _state(dec), _state(rec), torch.stack(losses).cpu().numpy()
 
 
@@ -65,7 +69,13 @@ def _run(kind, prec, dims, deferred, lens_sets, order):
 @pytest.mark.parametrize("shape", list(SHAPES))
 @pytest.mark.parametrize("lengths", ["full", "alternating"])
 @pytest.mark.parametrize("mode", [True, "recurrent"])      # whole update deferred / only the recurrent weights' (mode 2)
-def test_deferred_update_equals_the_immediate_one_once_flushed(mode, lengths, shape, kind, prec):
+@pytest.mark.parametrize("lr", [None, 1e-2])
+def test_deferred_update_equals_the_immediate_one_once_flushed(lr, mode, lengths, shape, kind, prec):
+    """lr None: the reference's learning rates (1e-5 / 1e-6) — the updates are too small to feed rounding differences of the
+    atomically summed gradients back into the next step, so GEMM-produced tensors can be held BIT for bit.  lr 1e-2 (at
+    the defaults four steps move a weight by less than the tolerances, so a missing update would pass): every step moves every
+    parameter by ~1e-2, the two schedules are compared relative to that movement, and the losses of the later steps are those of
+    the updated weights."""
     if kind == "local" and mode is True:
         pytest.skip("the whole-update mode exists for the global reconstructor")
     dims = SHAPES[shape]
@@ -85,16 +95,32 @@ def test_deferred_update_equals_the_immediate_one_once_flushed(mode, lengths, sh
     # (mode "recurrent": the in-step half is a different grouped launch than the immediate update's — other split factors,
     # equal to fp32 rounding)
     exact = lengths == "full" and mode is True
-    d0, r0, l0 = _run(kind, prec, dims, False, sets, order)
-    d1, r1, l1 = _run(kind, prec, dims, mode, sets, order)
-    assert np.allclose(l0[:, :7], l1[:, :7], rtol=1e-6 if mode is True else 3e-6, atol=0), (l0[:, 6], l1[:, 6])
-    for k in d0:
-        assert _same(d0[k], d1[k], k, True), ("decoder", k, float((d0[k] - d1[k]).abs().max()))
-    for k in r0:
-        assert _same(r0[k], r1[k], k, exact), ("reconstructor", k, float((r0[k] - r1[k]).abs().max()))
-    # and the update really happened (the Adam steps moved the reconstructor)
+    d0, r0, l0 = _run(kind, prec, dims, False, sets, order, lr)
+    d1, r1, l1 = _run(kind, prec, dims, mode, sets, order, lr)
     recP = GU.formula_params(GU.rec_shapes(kind, dims[5], dims[2], dims[7]), 4)
-    assert any(not torch.equal(r1["p." + k].cpu(), v) for k, v in recP.items())
+    if lr is None:
+        assert np.allclose(l0[:, :7], l1[:, :7], rtol=1e-6 if mode is True else 3e-6, atol=0), (l0[:, 6], l1[:, 6])
+        for k in d0:
+            assert _same(d0[k], d1[k], k, True), ("decoder", k, float((d0[k] - d1[k]).abs().max()))
+        for k in r0:
+            assert _same(r0[k], r1[k], k, exact), ("reconstructor", k, float((r0[k] - r1[k]).abs().max()))
+        assert any(not torch.equal(r1["p." + k].cpu(), v) for k, v in recP.items())
+        return
+    # large updates: rounding differences of the atomically summed gradients (biases, embedding rows) are fed back through the
+    # parameters, so nothing stays bit-identical over four steps; the schedules agree to a small fraction of how far each tensor moved
+    assert np.allclose(l0[:, :7], l1[:, :7], rtol=2e-5, atol=0), (l0[:, 6], l1[:, 6])
+    decP = GU.formula_params(GU.decoder_shapes(dims[3], dims[4], dims[5], dims[6], dims[2]), 3)
+    for st0, st1, P in ((d0, d1, decP), (r0, r1, recP)):
+        for k, v in P.items():
+            a, b = st0["p." + k].cpu().double(), st1["p." + k].cpu().double()
+            moved = float((b - v.double()).norm())
+            assert moved > 3e-3 * np.sqrt(v.numel()), (k, moved)            # every update happened: a sizeable fraction of lr per element and step
+            assert float((a - b).norm()) <= 2e-3 * moved, (k, float((a - b).norm()), moved)
+            for name in ("exp_avg", "exp_avg_sq"):
+                a, b = st0[name + "." + k].cpu().double(), st1[name + "." + k].cpu().double()
+                assert float((a - b).norm()) <= 2e-3 * float(b.norm()), (name, k)
+    if lengths == "full":      # the same batch four times: the loss falls by far more than the bar above
+        assert abs(l1[-1, 6] - l1[0, 6]) > 1e-3 * abs(l1[0, 6]), l1[:, 6]
 
 
 def test_without_flush_the_last_update_is_pending_and_entry_points_flush_themselves():

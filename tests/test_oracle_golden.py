@@ -163,3 +163,33 @@ def test_teacher_forcing_ratio_below_one_in_training(name):
         np.testing.assert_allclose(st.dec[k].detach().numpy(), v.numpy(), atol=1e-6, rtol=0)
     for k, v in GU.group(g, "rec_after%d" % n_steps).items():
         np.testing.assert_allclose(st.rec[k].detach().numpy(), v.numpy(), atol=1e-6, rtol=0)
+
+
+LR_CASES = ["lr_global_chain", "lr_local_chain", "lr_gru_global_chain"]
+
+
+@pytest.mark.parametrize("name", LR_CASES)
+def test_large_learning_rate_runs_pin_the_update_rule(name):
+    """train.py:149,186,271-273 at learning rates of 1e-2 (config.py:86-87 set on the reference's own config by the generator): four
+    iterations move every parameter by ~4e-2, so the losses of iterations 2-4 depend on the updates before them.  The oracle is held
+    to every loss, the parameters and BOTH optimisers' moments after the fourth step; tests/test_gpu_parity.py holds the benchmarked
+    update path (replayed graph, split reconstructor update, Adam in the GEMM epilogue) to the same vectors."""
+    g, decP, recP, kind, cells, enc, targets = _setup(name)
+    masks = targets > 0
+    lr = g["meta_lr"]
+    st = O.TrainState(decP, recP, kind, cell=cells[0], rec_cell=cells[1], dec_lr=float(lr[0]), rec_lr=float(lr[1]))
+    n = int(g["meta_n_steps"])
+    for it in range(n):
+        dl, rl, loss, gn = st.step(enc, targets, masks, _drop(g, it))
+        assert abs(loss - float(g["loss_step%d" % it])) <= 2e-5 * max(1.0, abs(loss)), it
+    # the updates are large: the loss moved by far more than the comparison tolerance
+    assert abs(float(g["loss_step%d" % (n - 1)]) - float(g["loss_step0"])) > 1e-2
+    for grp, P, opt in (("dec", st.dec, st.dec_opt), ("rec", st.rec, st.rec_opt)):
+        init = GU.group(g, grp + "_init")
+        for k, v in GU.group(g, "%s_after%d" % (grp, n)).items():
+            moved = float((v - init[k]).abs().max())
+            assert moved > 5e-3, (grp, k, moved)
+            np.testing.assert_allclose(P[k].detach().numpy(), v.numpy(), atol=2e-3 * moved, rtol=0)
+            s = opt.state[P[k]]
+            np.testing.assert_allclose(s["exp_avg"].numpy(), g["%s_opt/exp_avg/%s" % (grp, k)], atol=2e-6, rtol=2e-3)
+            np.testing.assert_allclose(s["exp_avg_sq"].numpy(), g["%s_opt/exp_avg_sq/%s" % (grp, k)], atol=1e-9, rtol=4e-3)
