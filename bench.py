@@ -158,7 +158,7 @@ def phase_table(eng, run, replays=12):
     """Untraced decomposition of the replayed step: the chain kernels stamp the 100 MHz wall clock when their first workgroup
     starts and when it leaves, the step's first / last kernels stamp its start / end (Engine.read_stamps) — medians over
     `replays` replays, microseconds.  prologue = start -> first chain; gaps = between consecutive chains; tail = last chain ->
-    end of the step's last kernel; between_steps = ms_per_step - span (graph launch + the ungraphed part of the replay)."""
+    end of the step's last kernel.  (between_steps and the back-to-back span are added by the caller from Engine.step_ring.)"""
     import statistics
     rows = []
     burst = int(os.environ.get("RN_PHASE_BURST", "1"))      # (diagnostic: stamps of the LAST of `burst` back-to-back replays)
@@ -356,7 +356,19 @@ def main():
         if not step.reduce:
             phases = phase_table(eng, runner)
             if phases:
-                phases["between_steps_us"] = round(ms * 1e3 - phases["span_us"], 1)
+                # The phase table is taken from ISOLATED replays (a synchronisation after each, to read the stamps).  Back to back — the
+                # timed loop — a replay's span is 20-35 us LONGER than isolated (the successor's packets are already in the hardware
+                # queues) and the idle time between the last kernel of one replay and the first kernel of the next is only ~5-8 us:
+                # both read DIRECTLY from the rings of start / end stamps the step's first and last kernels keep (Engine.step_ring,
+                # round 5; rounds 3-4 reported ms_per_step - isolated span as "between steps", 35-54 us, and could not explain it).
+                for _ in range(8):
+                    runner()
+                ring = eng.step_ring()
+                if len(ring) >= 3:
+                    import statistics as _st
+                    phases["span_back_to_back_us"] = round(_st.median([b - a for a, b in ring[:-1]]), 1)
+                    phases["between_steps_us"] = round(_st.median([ring[i + 1][0] - ring[i][1] for i in range(len(ring) - 1)]), 1)
+                phases["ms_per_step_minus_isolated_span_us"] = round(ms * 1e3 - phases["span_us"], 1)
         for _ in range(int(os.environ.get("RN_BENCH_ROOFLINE_REPEATS", "1")) - 1):       # (stress of the measurement path: tools/crash_hunt.sh)
             roofline(eng, prof_pass, kind, args.precision, T=T, cell=args.cell)
         prof = roofline(eng, prof_pass, kind, args.precision, T=T, cell=args.cell)

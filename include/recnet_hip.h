@@ -373,6 +373,11 @@ int recnet_reconstructor_step(recnet_handle* h, const float* input, const float*
  * fwd/BPTT chain, 32/64 local reconstructor fwd/bwd chain gave up a wait; 256 the step's loss was poisoned (NaN) and the
  * optimiser kernels skip their updates.  Synchronises `stream`.  recnet_chain_reset clears the sticky words;
  * disable_persistent != 0 switches the handle to the per-step kernels for every later call. */
+/* Measurement hook: the last seven step-start stamps (out16[1..7], written by the step's first kernel; out16[0] = how many steps ever
+ * started) and step-end stamps (out16[9..15] / out16[8]) of recnet_train_step_dev, 100 MHz wall clock, slot of step n = 1 + (n - 1) % 7
+ * counting from the handle's first step: the idle time between back-to-back replays of a captured step, read directly.
+ * Synchronises the stream. */
+int recnet_read_step_ring(recnet_handle* h, uint64_t* out16, void* stream);
 int recnet_chain_status(recnet_handle* h, int32_t* status_out, void* stream);
 int recnet_chain_reset(recnet_handle* h, int32_t disable_persistent, void* stream);
 /* Test hook: what a chain kernel does when it gives up a bounded wait (rec_chain.hpp: rc_give_up) — raises the sticky word

@@ -82,18 +82,7 @@ bool launch_chain(const GemmArgs& a, int nkt, hipStream_t st, int tag) {
 inline int vec_ok(const void* p, int ld, int elem) {
   return (((uintptr_t)p) % 16 == 0) && (((size_t)ld * elem) % 16 == 0);
 }
-template <bool ACOL, bool BCOL>
-void launch_big_one(const GemmArgs& a, hipStream_t st) {
-  static bool attr_done = false;
-  auto fn = gemm_big_kernel<ACOL, BCOL>;
-  if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, GL_BIG_LDS); attr_done = true; }
-  hipLaunchKernelGGL(fn, dim3((a.N + 127) / 128, (a.M + 255) / 256, a.splitk), dim3(512), GL_BIG_LDS, st, a);
-}
 }  // namespace
-
-// 256-row tiles (gemm_lds.hpp: gemm_big_kernel, one 8-wave workgroup per CU, three stages) for the batched products.
-// RN_GEMM_BIG: 0 off, 1 single launches, 2 grouped launches, 3 both (read per call: the A/B tests flip it inside one process)
-int rn_gemm_big_mode() { const char* e = getenv("RN_GEMM_BIG"); return e ? atoi(e) : 3; }
 
 int rn_gemm_bk(int prec) { return prec == RN_PREC_BF16 ? GemmCfg<bf16_t>::BK : GemmCfg<float>::BK; }
 
@@ -161,13 +150,6 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
       }
       // both operands bf16 in memory: the DMA-staged ring kernel.  Chain launches (tag > 0) run ~1 block
       // per CU and want the deepest ring; batched GEMMs trade ring depth for 2 resident blocks per CU.
-      if (!tag && M >= 512 && !mse && (rn_gemm_big_mode() & 1)) {      // batched product: 256 x 128 tiles (the MSE epilogue counts 128-row tiles)
-        if (!a_col && !b_col) launch_big_one<false, false>(a, st);
-        else if (!a_col && b_col) launch_big_one<false, true>(a, st);
-        else if (a_col && !b_col) launch_big_one<true, false>(a, st);
-        else launch_big_one<true, true>(a, st);
-        goto after_launch;
-      }
       static int ns_chain = getenv("RN_GEMM_NS_CHAIN") ? atoi(getenv("RN_GEMM_NS_CHAIN")) : 4;
       static int ns_batch = 2;
       const int ns = tag ? ns_chain : ns_batch;
@@ -214,14 +196,7 @@ int rn_effective_splitk(int prec, int K, int splitk) {
 #include <vector>
 namespace {
 template <bool ACOL, bool BCOL, bool EPI = false>
-void launch_group_one(const GemmGroupArgs& g, int nblocks, hipStream_t st, bool big = false) {
-  if (big) {
-    static bool attr_big = false;
-    auto fb = gemm_group_kernel<ACOL, BCOL, GL_BIG_NS, EPI, 256>;
-    if (!attr_big) { hipFuncSetAttribute((const void*)fb, hipFuncAttributeMaxDynamicSharedMemorySize, GL_BIG_LDS); attr_big = true; }
-    hipLaunchKernelGGL(fb, dim3(nblocks), dim3(512), GL_BIG_LDS, st, g);
-    return;
-  }
+void launch_group_one(const GemmGroupArgs& g, int nblocks, hipStream_t st) {
   static bool attr_done = false;
   auto fn = gemm_group_kernel<ACOL, BCOL, 2, EPI>;
   if (!attr_done) { hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GL_STAGE_BYTES); attr_done = true; }
@@ -245,23 +220,11 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
   if (!on || n < 1 || n > GG_MAX) return 1;
   struct Prob { int idx, tiles, nkt, s; };
   std::vector<Prob> pr;
-  // 256-row tiles (one 8-wave workgroup per CU) when most of the group's work is in products of >= 512 rows
-  bool big = false;
-  if (rn_gemm_big_mode() & 2) {
-    double w_all = 0.0, w_big = 0.0;
-    for (int i = 0; i < n; ++i) {
-      if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0) continue;
-      const double w = (double)d[i].M * d[i].N * d[i].K;
-      w_all += w; if (d[i].M >= 512) w_big += w;
-    }
-    big = w_all > 0.0 && w_big >= 0.8 * w_all;
-  }
-  const int BMg = big ? 256 : GEMM_TILE;
   for (int i = 0; i < n; ++i) {
     if (d[i].M <= 0 || d[i].N <= 0 || d[i].K <= 0) continue;
     if (!vec_ok(d[i].A, d[i].lda, 2) || !vec_ok(d[i].B, d[i].ldb, 2)) return 1;
     Prob q; q.idx = i; q.s = 1; q.nkt = (d[i].K + 63) / 64;
-    q.tiles = ((d[i].M + BMg - 1) / BMg) * ((d[i].N + GEMM_TILE - 1) / GEMM_TILE);
+    q.tiles = ((d[i].M + GEMM_TILE - 1) / GEMM_TILE) * ((d[i].N + GEMM_TILE - 1) / GEMM_TILE);
     pr.push_back(q);
   }
   if (pr.empty()) return 0;
@@ -269,8 +232,7 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
   // and epilogue, a split product's slabs ~1 unit per slice more for the slice that sums them), 2 workgroups per CU
   static int slots_all = 0;
   if (!slots_all) { int dev = 0, ncu = 256; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); slots_all = 2 * (ncu > 0 ? ncu : 256); }
-  int slots = slots_hint > 0 ? slots_hint : slots_all;
-  if (big) slots = slots > 1 ? slots / 2 : 1;      // (the callers count two 4-wave workgroups per CU)
+  const int slots = slots_hint > 0 ? slots_hint : slots_all;
   auto per_slice = [](const Prob& q) { const int per = (q.nkt + q.s - 1) / q.s; return per; };
   auto estimate = [&]() {
     std::vector<std::pair<double, int>> runs;
@@ -327,12 +289,12 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
   for (int k = g.np; k <= GG_MAX; ++k) g.first[k] = blocks;
   if (any_epi) {
     if (!(a_col && b_col)) return 1;                       // (the fused update exists for the dY^T . X form only)
-    launch_group_one<true, true, true>(g, blocks, st, big);
+    launch_group_one<true, true, true>(g, blocks, st);
     return 0;
   }
-  if (!a_col && !b_col) launch_group_one<false, false>(g, blocks, st, big);
-  else if (!a_col && b_col) launch_group_one<false, true>(g, blocks, st, big);
-  else if (a_col && !b_col) launch_group_one<true, false>(g, blocks, st, big);
-  else launch_group_one<true, true>(g, blocks, st, big);
+  if (!a_col && !b_col) launch_group_one<false, false>(g, blocks, st);
+  else if (!a_col && b_col) launch_group_one<false, true>(g, blocks, st);
+  else if (a_col && !b_col) launch_group_one<true, false>(g, blocks, st);
+  else launch_group_one<true, true>(g, blocks, st);
   return 0;
 }

@@ -106,38 +106,26 @@ __device__ __forceinline__ bf16x8 gl_frag(const char* img, int row /*first of th
   }
 }
 
-// BN = columns per workgroup: 128, or 96 (row/row form only) — N = 6144 with 4 K slices is 192 workgroups of 128
-// columns but 256 of 96, one per CU, each with a quarter less weight data and MFMA work on the chain's critical path.
-// One output tile (bx, by) of K slice z.  FIX: the launch is a grouped one (gemm_group_kernel) and a split product is finished
-// inside it — see the fix-up block of the epilogue.
-// GL_PROBE (tools/micro/gemm_probe.hip only): shader-clock stamps around the segments of the K loop, summed per wave
+// GL_PROBE (tools/micro/gemm_probe.hip only): shader-clock stamps around the segments of the K loop and the epilogue, per wave
 #ifdef GL_PROBE
 __device__ unsigned long long gl_probe_buf[64 * 8 * 8];
 #define GL_PR(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pr_acc[i] += n_ - pr_t; pr_t = n_; } while (0)
 #else
 #define GL_PR(i)
 #endif
-// BM = rows per workgroup: 128 (4 waves, two workgroups per CU) or 256 (round 5: 8 waves = 512 threads, ONE workgroup per CU with a
-// ring of three 48 KiB stages — two tiles of 64 K-elements in flight across every barrier instead of one, a quarter less L2 -> LDS
-// traffic per FLOP; the A image is two stacked 128-row images, so every layout / swizzle rule below is unchanged).
-template <bool ACOL, bool BCOL, int NS, int BN, bool FIX, bool EPI = false, int BM = 128, typename ArgsT>
+// BN = columns per workgroup: 128, or 96 (row/row form only) — N = 6144 with 4 K slices is 192 workgroups of 128
+// columns but 256 of 96, one per CU, each with a quarter less weight data and MFMA work on the chain's critical path.
+// One output tile (bx, by) of K slice z.  FIX: the launch is a grouped one (gemm_group_kernel) and a split product is finished
+// inside it — see the fix-up block of the epilogue.
+template <bool ACOL, bool BCOL, int NS, int BN, bool FIX, bool EPI = false, typename ArgsT>
 __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, const int by, const int z, char* gl_smem,
                                               const AdamShared* sh = nullptr) {
   static_assert(BN == 128 || (BN == 96 && !BCOL), "96-column tiles: row-layout weights only");
-  static_assert(BM == 128 || (BM == 256 && BN == 128), "256-row tiles: 128 columns");
-  constexpr int NW = BM / 32;                  // waves: 2 along N, BM / 64 along M (64 x BN/2 per wave)
-  constexpr int NT = NW * 64;                  // threads
-  constexpr int NPB = BN / 32;                 // 16-column groups per wave
-  constexpr int NPBW = (BN / 8) / NW;          // DMA pieces per wave of the B tile
-  constexpr int ABYTES = BM * 128;             // A image(s)
-  constexpr int STAGE = ABYTES + BN * 128;     // A image(s) + B image
-  constexpr int STG_END = NW * 32 * 68 * 4;    // end of the per-wave epilogue staging blocks
+  constexpr int NPB = BN / 32;                 // DMA pieces per wave of the B tile = 16-column groups per wave
+  constexpr int STAGE = 16384 + BN * 128;      // A image 16 KiB + B image
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * (BN / 2);
-  const int ah = (BM == 256) ? (wave >> 2) : 0;            // staging: which 128-row half of the A tile this wave's DMA pieces belong to
-  const int aw = (BM == 256) ? (wave & 3) : wave;          // ... and its wave index inside that half
-  const int fh = wm >> 7, fr = wm & 127;                   // fragments: half and row inside it of this wave's 64 rows
-  const int m0 = by * BM, n0 = bx * BN;
+  const int m0 = by * GEMM_TILE, n0 = bx * BN;
   const int kbeg = z * p.kchunk;
   int kend = kbeg + p.kchunk;
   if (kend > p.K) kend = p.K;
@@ -160,15 +148,15 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
   for (int d = 0; d < D; ++d)
     if (d < nkt) {
       char* st = gl_smem + d * STAGE;
-      gl_stage<ACOL>(st + ah * 16384, A, p.lda, m0 + ah * 128, p.M, kbeg + d * 64, kend, aw, lane);
-      gl_stage<BCOL, NPBW>(st + ABYTES, B, p.ldb, n0, p.N, kbeg + d * 64, kend, wave, lane);
+      gl_stage<ACOL>(st, A, p.lda, m0, p.M, kbeg + d * 64, kend, wave, lane);
+      gl_stage<BCOL, NPB>(st + 16384, B, p.ldb, n0, p.N, kbeg + d * 64, kend, wave, lane);
     }
   for (int kt = 0; kt < nkt; ++kt) {
     // this wave's DMA of tile kt has landed once at most `ahead` later tiles (8 DMAs each) are outstanding
     const int issued = (kt + D < nkt) ? kt + D : nkt;
     const int ahead = issued - (kt + 1);
-    if (NS >= 4 && ahead >= 2) gl_wait_vmcnt<2 * (4 + NPBW)>();
-    else if (NS >= 3 && ahead >= 1) gl_wait_vmcnt<4 + NPBW>();
+    if (NS >= 4 && ahead >= 2) gl_wait_vmcnt<2 * (4 + NPB)>();
+    else if (NS >= 3 && ahead >= 1) gl_wait_vmcnt<4 + NPB>();
     else gl_wait_vmcnt<0>();
     GL_PR(0);
     __builtin_amdgcn_s_barrier();           // every wave's part of tile kt landed; everyone is done with tile kt-1
@@ -176,15 +164,15 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
     GL_PR(1);
     if (kt + D < nkt) {
       char* st = gl_smem + ((kt + D) % NS) * STAGE;
-      gl_stage<ACOL>(st + ah * 16384, A, p.lda, m0 + ah * 128, p.M, kbeg + (kt + D) * 64, kend, aw, lane);
-      gl_stage<BCOL, NPBW>(st + ABYTES, B, p.ldb, n0, p.N, kbeg + (kt + D) * 64, kend, wave, lane);
+      gl_stage<ACOL>(st, A, p.lda, m0, p.M, kbeg + (kt + D) * 64, kend, wave, lane);
+      gl_stage<BCOL, NPB>(st + 16384, B, p.ldb, n0, p.N, kbeg + (kt + D) * 64, kend, wave, lane);
     }
     char* cur = gl_smem + (kt % NS) * STAGE;
     const int k0 = kbeg + kt * 64;
     GL_PR(2);
     if (k0 + 64 > kend) {                    // partial last tile: zero what lies beyond K (block-uniform branch)
-      gl_zero_tail<ACOL>(cur + ah * 16384, k0, kend, aw, lane);
-      gl_zero_tail<BCOL, NPBW>(cur + ABYTES, k0, kend, wave, lane);
+      gl_zero_tail<ACOL>(cur, k0, kend, wave, lane);
+      gl_zero_tail<BCOL, NPB>(cur + 16384, k0, kend, wave, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -193,9 +181,9 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
     for (int ks = 0; ks < 64; ks += 32) {
       bf16x8 fa[4], fb[NPB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = gl_frag<ACOL>(cur + fh * 16384, fr + i * 16, ks, lane);
+      for (int i = 0; i < 4; ++i) fa[i] = gl_frag<ACOL>(cur, wm + i * 16, ks, lane);
 #pragma unroll
-      for (int j = 0; j < NPB; ++j) fb[j] = gl_frag<BCOL>(cur + ABYTES, wn + j * 16, ks, lane);
+      for (int j = 0; j < NPB; ++j) fb[j] = gl_frag<BCOL>(cur + 16384, wn + j * 16, ks, lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -209,7 +197,6 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
     if (bl < 64 && lane == 0 && z == 0) {
       pr_acc[4] = pr_t - pr_t0;      // prologue + K loop
       for (int i = 0; i < 5; ++i) gl_probe_buf[(bl * 8 + wave) * 8 + i] = pr_acc[i];
-      gl_probe_buf[(bl * 8 + wave) * 8 + 5] = pr_t0;
     }
   }
 #endif
@@ -257,7 +244,7 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned* flag = reinterpret_cast<unsigned*>(gl_smem + STG_END);      // behind the staging blocks
+    unsigned* flag = reinterpret_cast<unsigned*>(gl_smem + 4 * 32 * 68 * 4);      // behind the four staging blocks
     unsigned* cn = p.cnt + (size_t)by * ((p.N + BN - 1) / BN) + bx;
     if (tid == 0) *flag = __hip_atomic_fetch_add(cn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -267,18 +254,18 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
     const int S = p.splitk;
-    const int nrow = (p.M - m0 < BM) ? p.M - m0 : BM;
+    const int nrow = (p.M - m0 < GEMM_TILE) ? p.M - m0 : GEMM_TILE;
     const int ncol = (p.N - n0 < BN) ? p.N - n0 : BN;
     // 16 quads per thread and slab; 16 loads of 16 bytes in flight per thread at a time (NBQ quads x ZS slices): the sum is
     // bound by round trips, not by bytes — one quad at a time took 16 dependent trips per tile
     auto sum_tile = [&](auto nbq_c, auto zs_c) {
       constexpr int NBQ = decltype(nbq_c)::value, ZS = decltype(zs_c)::value;
-      for (int q0 = 0; q0 < BM * (BN / 4) / NT; q0 += NBQ) {
+      for (int q0 = 0; q0 < GEMM_TILE * (BN / 4) / 256; q0 += NBQ) {
         f32x4 part[NBQ * ZS];
         unsigned off[NBQ]; bool ok[NBQ];
 #pragma unroll
         for (int u = 0; u < NBQ; ++u) {
-          const int q = (q0 + u) * NT + tid;
+          const int q = (q0 + u) * 256 + tid;
           const int rl = q / (BN / 4), c4 = (q - rl * (BN / 4)) * 4;
           ok[u] = rl < nrow && c4 < ncol;
           off[u] = ((unsigned)(m0 + rl) * (unsigned)p.N + (unsigned)(n0 + c4)) * 4u;
@@ -292,7 +279,7 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
           f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int zz = 0; zz < ZS; ++zz) if (zz < S) sum += part[u * ZS + zz];
-          const int q = (q0 + u) * NT + tid;
+          const int q = (q0 + u) * 256 + tid;
           const int rl = q / (BN / 4), c4 = (q - rl * (BN / 4)) * 4;
           const int row = m0 + rl, col = n0 + c4;
           float o[4];
@@ -331,7 +318,7 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
       // quad of the tile is written as the gradient and, in the same pass, updates p / m / v and the bf16 operand image; the
       // transposed image (the chain kernels' K-contiguous form) goes through a per-wave LDS block so that every lane writes
       // 64 contiguous bytes.  What a separate Adam kernel (28 B per parameter through ~120 CUs) and two transpose kernels did.
-      float* hy = reinterpret_cast<float*>(gl_smem + STG_END + 16);
+      float* hy = reinterpret_cast<float*>(gl_smem + 4 * 32 * 68 * 4 + 16);
       if (tid == 0) {
         const double st = (double)(*sh->step_ptr + sh->step_off);
         const double bc1 = 1.0 - pow(sh->hp.beta1, st), bc2 = 1.0 - pow(sh->hp.beta2, st);
@@ -354,7 +341,7 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
       const float kreg = nrm > 0.f ? sh->hp.reg_coef / nrm : 0.f;
       const bool ams = sh->hp.amsgrad != 0;
       constexpr int TS = 40;                                  // row stride of the transposed block (bf16): 80 bytes
-      bf16_t* tT = reinterpret_cast<bf16_t*>(gl_smem + STG_END + 2048 + wave * (64 * TS * 2));
+      bf16_t* tT = reinterpret_cast<bf16_t*>(gl_smem + 36864 + wave * (64 * TS * 2));
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -483,6 +470,15 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
       }
     }
   }
+#ifdef GL_PROBE
+  {
+    const unsigned long long pe0 = __builtin_amdgcn_s_memtime();      // stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long pe1 = __builtin_amdgcn_s_memtime();      // ... and acknowledged
+    const int bl = by * gridDim.x + bx;
+    if (bl < 64 && lane == 0 && z == 0) { gl_probe_buf[(bl * 8 + wave) * 8 + 6] = pe0 - pr_t; gl_probe_buf[(bl * 8 + wave) * 8 + 7] = pe1 - pr_t; }
+  }
+#endif
   if (p.mse_ref && !to_slab) {      // (block-uniform) the tile's sum of squares -> its slot of the partial sums
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) msq += __shfl_down(msq, off, 64);
@@ -490,12 +486,7 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
     float* red = reinterpret_cast<float*>(gl_smem);
     if (lane == 0) red[wave] = msq;
     __syncthreads();
-    if (tid == 0) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; w += 2) t += red[w] + red[w + 1];
-      p.mse_part[(size_t)by * ((p.N + BN - 1) / BN) + bx] = t;
-    }
+    if (tid == 0) p.mse_part[(size_t)by * ((p.N + BN - 1) / BN) + bx] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -503,14 +494,6 @@ template <bool ACOL, bool BCOL, int NS, int TAG, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_lds_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
   gemm_lds_tile<ACOL, BCOL, NS, BN, false>(p, blockIdx.x, blockIdx.y, blockIdx.z, gl_smem);
-}
-// 256 x 128 tiles, 8 waves, three 48 KiB stages: one workgroup per CU (single products of the batched part of the step)
-#define GL_BIG_NS 3
-#define GL_BIG_LDS (GL_BIG_NS * (256 * 128 + 128 * 128))
-template <bool ACOL, bool BCOL>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char gl_smem[];
-  gemm_lds_tile<ACOL, BCOL, GL_BIG_NS, 128, false, false, 256>(p, blockIdx.x, blockIdx.y, blockIdx.z, gl_smem);
 }
 
 // ---- grouped launch: the tiles of up to GG_MAX products of one operand layout in ONE grid.  The hardware dispatcher deals the
@@ -522,8 +505,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const GemmArgs p) {
 #endif
 // stamp: optional pair of 100 MHz wall-clock words {first workgroup started, last workgroup left} (recnet_read_stamps)
 struct GemmGroupArgs { GemmArgs p[GG_MAX]; int first[GG_MAX + 1]; int np; AdamShared ad; unsigned long long* stamp; };
-template <bool ACOL, bool BCOL, int NS, bool EPI = false, int BM = 128>
-__global__ __launch_bounds__(BM * 2) void gemm_group_kernel(const GemmGroupArgs g) {
+template <bool ACOL, bool BCOL, int NS, bool EPI = false>
+__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmGroupArgs g) {
   extern __shared__ __attribute__((aligned(16))) char gl_smem[];
   int i = 0;
   const int bid = blockIdx.x;
@@ -531,11 +514,11 @@ __global__ __launch_bounds__(BM * 2) void gemm_group_kernel(const GemmGroupArgs 
   for (int k = 1; k < GG_MAX; ++k) if (k < g.np && bid >= g.first[k]) i = k;
   const GemmArgs& p = g.p[i];
   const int local = bid - g.first[i];
-  const int tn = (p.N + GEMM_TILE - 1) / GEMM_TILE, tm = (p.M + BM - 1) / BM;
+  const int tn = (p.N + GEMM_TILE - 1) / GEMM_TILE, tm = (p.M + GEMM_TILE - 1) / GEMM_TILE;
   // slices of a tile are neighbours in the queue (they finish together: the last arriver does not wait long for the others)
   const int z = local % p.splitk, t = local / p.splitk;
   if (g.stamp && bid == 0 && threadIdx.x == 0) __hip_atomic_store(g.stamp, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  gemm_lds_tile<ACOL, BCOL, NS, 128, true, EPI, BM>(p, t % tn, t / tn, z, gl_smem, &g.ad);
+  gemm_lds_tile<ACOL, BCOL, NS, 128, true, EPI>(p, t % tn, t / tn, z, gl_smem, &g.ad);
   if (g.stamp && threadIdx.x == 0) __hip_atomic_fetch_max(g.stamp + 1, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   (void)tm;
 }

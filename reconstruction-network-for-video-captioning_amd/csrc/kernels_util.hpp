@@ -12,9 +12,17 @@ __global__ void poison_mark_kernel(float* g0, const float* poison) { if (*poison
 __global__ void poison_collect_kernel(const float* g0, float* poison) { if (*g0 != *g0) *poison = __int_as_float(0x7fc00000); }
 __global__ void set_f32_kernel(float* p, float v) { *p = v; }
 // step counter += 1; seed slot = seed_base + step (graph-replay friendly train step)
+// A ring of the last seven stamps of a one-thread kernel (ring[0] = count): the step's first and last kernels keep one each, so that
+// the idle time BETWEEN back-to-back replayed steps can be read directly (recnet_read_step_ring) instead of as a difference of totals
+__device__ __forceinline__ void rn_ring_push(unsigned long long* ring, unsigned long long now) {
+  const unsigned long long c = ring[0];
+  ring[1 + (c % 7ull)] = now; ring[0] = c + 1ull;
+}
 __global__ void advance_step_kernel(int32_t* step, uint32_t* seed_slot, uint32_t seed_base) {
   int s = *step + 1; *step = s; *seed_slot = seed_base + (uint32_t)s;
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(seed_slot + 32), (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // phase stamp: step start (recnet_read_stamps, wait_chain_kernel)
+  const unsigned long long now = (unsigned long long)wall_clock64();
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(seed_slot + 32), now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // phase stamp: step start (recnet_read_stamps, wait_chain_kernel)
+  rn_ring_push(reinterpret_cast<unsigned long long*>(seed_slot + 34), now);      // ctrl[34 .. 49]
 }
 
 // step counter = step (host-numbered train step), with the step-start stamp of advance_step_kernel

@@ -281,6 +281,18 @@ class Engine:
     def set_dp_overlap(self, on):
         _lib.check(self.lib.recnet_set_dp_overlap(self.handle, int(bool(on))), "recnet_set_dp_overlap")
 
+    def step_ring(self):
+        """[(start, end)] of the last (up to seven) replayed steps in microseconds, oldest first (recnet_read_step_ring)."""
+        buf = (C.c_uint64 * 16)()
+        _lib.check(self.lib.recnet_read_step_ring(self.handle, buf, _stream()), "recnet_read_step_ring")
+        ns, ne = int(buf[0]), int(buf[8])
+        k = min(ns, ne, 7)
+        out = []
+        for i in range(k):
+            a, b = ns - k + i, ne - k + i
+            out.append((buf[1 + a % 7] * 0.01, buf[9 + b % 7] * 0.01))
+        return out
+
     def abort_step(self):
         """After an abandoned stream capture: the handle's enqueue-time bookkeeping back to "between two steps" (recnet_abort_step)."""
         _lib.check(self.lib.recnet_abort_step(self.handle), "recnet_abort_step")

@@ -94,25 +94,6 @@ def _bf16_operand(rows, cols, gen_int=False, g=None):
     return buf, buf[:, :cols]
 
 
-@pytest.mark.parametrize("big", ["0", "3"])      # RN_GEMM_BIG: 128 x 128 tiles only / 256 x 128 tiles (8 waves, 3 stages) from 512 rows
-@pytest.mark.parametrize("a_col,b_col", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(512, 128, 64), (513, 200, 1000), (777, 130, 4100), (3100, 1024, 1024), (1000, 96, 72), (640, 520, 200)])
-def test_gemm_big_tiles_exact_integers(big, a_col, b_col, M, N, K, monkeypatch):
-    """gemm_big_kernel (csrc/gemm_lds.hpp, BM = 256): partial row tiles in either half of the stacked A image, partial column
-    tiles, a K tail, one to three K slices — exact on integer operands in every operand layout, and identical to the 128-row
-    form.  The batched products of the train step take this kernel from 512 rows up."""
-    monkeypatch.setenv("RN_GEMM_BIG", big)
-    g = torch.Generator().manual_seed(M + N + K)
-    eng = _engine("bf16")
-    Ab, Av = _bf16_operand(K if a_col else M, M if a_col else K, True, g)
-    Bb, Bv = _bf16_operand(K if b_col else N, N if b_col else K, True, g)
-    ref = _ref(Av.float(), Bv.float(), a_col, b_col)
-    for splitk in (1, 2, 3):
-        C = eng.gemm_bf16(Ab, Bb, bool(a_col), bool(b_col), splitk=splitk, M=M, N=N, K=K, tag=0)
-        torch.cuda.synchronize()
-        assert torch.equal(C.double(), ref), (a_col, b_col, splitk, (C.double() - ref).abs().max().item())
-
-
 @pytest.mark.parametrize("tag_ns", [(0, "2"), (0, "3"), (3, "4")])
 @pytest.mark.parametrize("a_col,b_col", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (100, 6144, 1536), (37, 97, 41), (300, 130, 1000), (5, 288, 112),
