@@ -29,6 +29,19 @@ ms = burst(run, 28)
 ring = eng.step_ring()
 spans = [b - a for a, b in ring]; gaps = [ring[i + 1][0] - ring[i][1] for i in range(len(ring) - 1)]
 print("one step per graph : %.4f ms per step | spans %s | between steps %s" % (ms, " ".join("%.1f" % x for x in spans), " ".join("%.1f" % x for x in gaps)))
+# the host keeps at most `depth` replays queued behind the running one (an event per replay, waited for `depth` replays later)
+for depth in (1, 2, 4):
+    evs = [torch.cuda.Event() for _ in range(64)]
+    def paced(n):
+        for i in range(n):
+            if i >= depth: evs[(i - depth) % 64].synchronize()
+            run(); evs[i % 64].record()
+    paced(12); torch.cuda.synchronize()
+    t0 = time.perf_counter(); paced(28); torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 28 * 1e3
+    ring = eng.step_ring()
+    spans = [b - a for a, b in ring]; gaps = [ring[i + 1][0] - ring[i][1] for i in range(len(ring) - 1)]
+    print("at most %d queued     : %.4f ms per step | spans %s | between steps %s" % (depth, ms, " ".join("%.1f" % x for x in spans), " ".join("%.1f" % x for x in gaps)))
 # k steps per graph
 for k in (2, 4):
     g = torch.cuda.CUDAGraph()
