@@ -283,10 +283,20 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
           const int rl = q / (BN / 4), c4 = (q - rl * (BN / 4)) * 4;
           const int row = m0 + rl, col = n0 + c4;
           float o[4];
+          if (p.bias && ((((uintptr_t)p.bias) & 15) == 0)) {      // (N % 4 == 0 here: the quad is whole)
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = p.alpha * sum[e] + b4[e];
+          } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = p.alpha * sum[e] + ((p.bias && col + e < p.N) ? p.bias[col + e] : 0.f);
+          }
           if (p.c_bf16) {
             bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col;
+            if (((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 7) == 0) && col + 3 < p.N) {
+              bf16x4 hb; hb[0] = (bf16_t)o[0]; hb[1] = (bf16_t)o[1]; hb[2] = (bf16_t)o[2]; hb[3] = (bf16_t)o[3];
+              *reinterpret_cast<bf16x4*>(dst) = hb;
+            } else
             for (int e = 0; e < 4 && col + e < p.N; ++e) dst[e] = (bf16_t)o[e];
           } else {
             float* dst = p.C + (size_t)row * p.ldc + col;
@@ -410,6 +420,57 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
       return;
     }
   }
+  // ---- the common case on a straight path (round 5): whole 16-byte quads of an fp32 tile (or slab) or of a bf16 tile, nothing else
+  // to do per element.  The general loop below re-tests every option per quad and fetched the bias element by element behind
+  // branches — 16 dependent round trips per tile: 12.7k cycles of epilogue beside a 25k-cycle K loop at K = 1024, 12k beside 16k at
+  // K = 512 (tools/micro/gemm_probe.hip).  Here the lane's bias quad is loaded once (its four columns are the same in all 16 rows)
+  // and the 16 stores of a wave follow one another.
+  {
+    const bool plain = !p.accumulate && !p.C2 && !p.mse_ref && (p.N & 3) == 0 && (to_slab || !p.bias || ((((uintptr_t)p.bias) & 15) == 0));
+    const bool f32_ok = plain && vec4;
+    const bool b16_ok = plain && p.c_bf16 && !to_slab && ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 7) == 0);
+    if (f32_ok || b16_ok) {      // (block-uniform)
+      const int c4 = (lane & 15) * 4, col = n0 + wn + c4;
+      const bool colok = col < p.N && c4 < BN / 2;
+      f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!to_slab && p.bias && colok) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+      const float al = to_slab ? 1.f : p.alpha;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < NPB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(ii * 16 + cr + r) * 68 + j * 16 + cc] = acc[half * 2 + ii][j][r];
+        f32x4 v8[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) v8[it] = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * 68 + c4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = m0 + wm + half * 32 + it * 4 + (lane >> 4);
+          if (row >= p.M || !colok) continue;
+          const f32x4 w = al * v8[it] + b4;
+          if (b16_ok) {
+            bf16x4 hb; hb[0] = (bf16_t)w[0]; hb[1] = (bf16_t)w[1]; hb[2] = (bf16_t)w[2]; hb[3] = (bf16_t)w[3];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col) = hb;
+          } else {
+            *reinterpret_cast<f32x4*>(Cb + (size_t)row * ldc + col) = w;
+          }
+        }
+      }
+#ifdef GL_PROBE
+      {
+        const unsigned long long pe0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long pe1 = __builtin_amdgcn_s_memtime();
+        const int bl = by * gridDim.x + bx;
+        if (bl < 64 && lane == 0 && z == 0) { gl_probe_buf[(bl * 8 + wave) * 8 + 6] = pe0 - pr_t; gl_probe_buf[(bl * 8 + wave) * 8 + 7] = pe1 - pr_t; }
+      }
+#endif
+      return;
+    }
+  }
   float msq = 0.f;               // MSE epilogue: this lane's sum of squared differences
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -435,6 +496,12 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
         for (int q = 0; q < 4; ++q) o[q] = p.alpha * v[q] + ((p.bias && col + q < p.N) ? p.bias[col + q] : 0.f);
         if (p.c_bf16) {
           bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)row * p.ldc + col;
+          // one 8-byte store per lane (round 5: the element-wise form made this epilogue 40 % SLOWER than the fp32 one at half the
+          // bytes — 18.0k against 12.7k cycles per tile, tools/micro/gemm_probe.hip)
+          if (((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 7) == 0) && col + 3 < p.N) {
+            bf16x4 hb; hb[0] = (bf16_t)o[0]; hb[1] = (bf16_t)o[1]; hb[2] = (bf16_t)o[2]; hb[3] = (bf16_t)o[3];
+            *reinterpret_cast<bf16x4*>(dst) = hb;
+          } else
           for (int q = 0; q < 4 && col + q < p.N; ++q) dst[q] = (bf16_t)o[q];
         } else {
           float* dst = Cb + (size_t)row * ldc + col;
