@@ -152,6 +152,16 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
   if (threadIdx.x == 0) *out = s * scale;
 }
 
+// The decoder's loss scalars in one launch (round 5: a row-sum kernel and two one-thread kernels before): scal[0] = CE = sum of the
+// weighted row losses, scal[2] = dec_loss = CE + lambda_reg * reg (scal[1], from the parameter norms), scal[6] = total so far
+__global__ __launch_bounds__(256) void dec_loss_finalize_kernel(const float* __restrict__ rowloss, int n, float* scal, float lambda_reg) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += rowloss[i];
+  s = block_sum256(s, sm);
+  if (threadIdx.x == 0) { scal[0] = s; const float dl = s + lambda_reg * scal[1]; scal[2] = dl; scal[6] = dl + 0.f * dl; }
+}
+
 // out[c] (+)= sum_r X[r*ld + c].  grid (ceil(cols/64), RS); with RS > 1 `out` must be pre-zeroed (atomics).
 template <typename ST>
 __global__ __launch_bounds__(256) void colsum_kernel(const ST* __restrict__ X, int rows, int cols, int ld,
