@@ -373,6 +373,15 @@ int recnet_reconstructor_step(recnet_handle* h, const float* input, const float*
  * fwd/BPTT chain, 32/64 local reconstructor fwd/bwd chain gave up a wait; 256 the step's loss was poisoned (NaN) and the
  * optimiser kernels skip their updates.  Synchronises `stream`.  recnet_chain_reset clears the sticky words;
  * disable_persistent != 0 switches the handle to the per-step kernels for every later call. */
+/* Gradient transport of the data-parallel step in its direct form (one reduce-scatter message per peer, i.e. per xGMI link, then an
+ * all-gather: SURVEY.md section 8e; train.py:264-273 under data parallelism).  The collectives themselves are RCCL's; these are
+ * the staging kernels around them, on `stream`, no handle needed:
+ *   recnet_dp_cast    dst[i] = (dst type) src[i], n elements; *_bf16 = 0: fp32, 1: bf16 (fp32 -> wire type before the reduce-scatter,
+ *                     wire type -> the fp32 gradient buffer after the all-gather)
+ *   recnet_dp_reduce  red[j] = (wire type) sum_{r = 0 .. world-1, in rank order} (float) recv[r * chunk + j]: fp32 accumulation at the
+ *                     destination, one rounding of the sum (world <= 16) */
+int recnet_dp_cast(const void* src, int32_t src_bf16, void* dst, int32_t dst_bf16, int64_t n, void* stream);
+int recnet_dp_reduce(const void* recv, int32_t world, int64_t chunk, void* red, int32_t wire_bf16, void* stream);
 /* Measurement hook: the last seven step-start stamps (out16[1..7], written by the step's first kernel; out16[0] = how many steps ever
  * started) and step-end stamps (out16[9..15] / out16[8]) of recnet_train_step_dev, 100 MHz wall clock, slot of step n = 1 + (n - 1) % 7
  * counting from the handle's first step: the idle time between back-to-back replays of a captured step, read directly.

@@ -152,6 +152,38 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
   if (threadIdx.x == 0) *out = s * scale;
 }
 
+// ---- gradient transport of the data-parallel step, direct reduce-scatter form (dp.py: GradTransport): the
+// staging around the two collectives as two kernels instead of W + 3 torch launches.
+// dp_cast: dst[i] = (WT) src[i] (fp32 -> wire type), or fp32 <- wire type on the way back; 16 bytes of fp32 per lane and pass.
+template <typename DT, typename ST>
+__global__ __launch_bounds__(256) void dp_cast_kernel(const ST* __restrict__ src, DT* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+    const long i = q << 2;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)src[i + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[i + e] = (DT)v[e];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = (DT)(float)src[(n4 << 2) + threadIdx.x];
+}
+// dp_reduce: red[j] = (WT) (sum over ranks r = 0 .. W-1, IN RANK ORDER, of (float) recv[r * chunk + j]) — fp32 accumulation at the
+// destination, every contribution rounded to the wire type once by its sender and the sum once here: all ranks that reduce the
+// same chunk get the same bytes.  All W loads of an element are in flight together (W <= 16).
+template <typename WT>
+__global__ __launch_bounds__(256) void dp_reduce_kernel(const WT* __restrict__ recv, int W, long chunk, WT* __restrict__ red) {
+  for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < chunk; j += (long)gridDim.x * 256) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = r < W ? (float)recv[(long)r * chunk + j] : 0.f;
+    float a = v[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) if (r < W) a += v[r];
+    red[j] = (WT)a;
+  }
+}
+
 // The decoder's loss scalars in one launch (round 5: a row-sum kernel and two one-thread kernels before): scal[0] = CE = sum of the
 // weighted row losses, scal[2] = dec_loss = CE + lambda_reg * reg (scal[1], from the parameter norms), scal[6] = total so far
 __global__ __launch_bounds__(256) void dec_loss_finalize_kernel(const float* __restrict__ rowloss, int n, float* scal, float lambda_reg) {

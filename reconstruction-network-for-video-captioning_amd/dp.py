@@ -76,6 +76,20 @@ class GradTransport:
         else:
             import contextlib
             ctx = contextlib.nullcontext()
+        if cuda and W <= 16 and dist.get_backend(self.group) != "gloo":
+            # two HIP kernels around the collectives (csrc/kernels_util.hpp: dp_cast_kernel, dp_reduce_kernel) instead of W + 3 torch
+            # launches: cast + stage, W-way fp32 sum in rank order + one rounding; the same arithmetic as the torch form below
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            bf = 1 if self.dtype == "bf16" else 0
+            with ctx:
+                s_ = C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)
+                _lib.check(lib.recnet_dp_cast(C.c_void_p(buf.data_ptr()), 0, C.c_void_p(st["send"].data_ptr()), bf, n, s_), "recnet_dp_cast")
+                dist.all_to_all_single(st["recv"], st["send"], group=self.group)      # chunk r of every rank -> rank r
+                _lib.check(lib.recnet_dp_reduce(C.c_void_p(st["recv"].data_ptr()), W, chunk, C.c_void_p(st["red"].data_ptr()), bf, s_), "recnet_dp_reduce")
+                work = dist.all_gather_into_tensor(st["out"], st["red"], group=self.group, async_op=True)
+            return (work, buf, st)
         with ctx:
             st["send"][:n].copy_(buf)                          # one rounding per rank (bf16 wire) / plain copy (fp32 wire)
             if dist.get_backend(self.group) == "gloo":
@@ -107,6 +121,13 @@ class GradTransport:
                 with torch.cuda.stream(self._side):
                     work.wait()
                 torch.cuda.current_stream(buf.device).wait_stream(self._side)
+            if buf.is_cuda:
+                import ctypes as C
+                from . import _lib
+                lib = _lib.load()
+                _lib.check(lib.recnet_dp_cast(C.c_void_p(st["out"].data_ptr()), 1 if self.dtype == "bf16" else 0, C.c_void_p(buf.data_ptr()), 0,
+                                              buf.numel(), C.c_void_p(torch.cuda.current_stream(buf.device).cuda_stream)), "recnet_dp_cast")
+                return
             buf.copy_(st["out"][:buf.numel()])
 
 

@@ -160,3 +160,36 @@ def test_give_up_on_one_rank_skips_the_update_on_every_rank():
         assert moved and status_after == 0, (rank, moved, status_after)
     assert res[0][2] & 0xFF == 0 and "another rank" in res[0][3]       # rank 0's own chains were healthy
     assert res[1][2] & 1
+
+
+@pytest.mark.parametrize("wire", ["f32", "bf16"])
+@pytest.mark.parametrize("world", [1, 2, 8, 16])
+def test_direct_transport_staging_kernels_equal_the_torch_form(world, wire):
+    """csrc/kernels_util.hpp dp_cast_kernel / dp_reduce_kernel (recnet_dp_cast / recnet_dp_reduce: the staging around the two
+    collectives of the direct gradient transport) against the torch ops they replace in dp.GradTransport:
+    fp32 -> wire type, W-way fp32 accumulation IN RANK ORDER with one rounding of the sum, wire type -> fp32.  Bit for bit,
+    at a length that is a multiple of nothing."""
+    import ctypes as C
+    from recnet_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wt = torch.bfloat16 if wire == "bf16" else torch.float32
+    bf = 1 if wire == "bf16" else 0
+    g = torch.Generator().manual_seed(5 + world)
+    n = 100003
+    src = (torch.randn(n, generator=g) * 3).cuda()
+    send = torch.zeros(n + 5, dtype=wt, device="cuda")
+    _lib.check(lib.recnet_dp_cast(C.c_void_p(src.data_ptr()), 0, C.c_void_p(send.data_ptr()), bf, n, st), "recnet_dp_cast")
+    assert torch.equal(send[:n], src.to(wt)) and float(send[n:].float().abs().max()) == 0.0
+    chunk = 12504
+    recv = (torch.randn(world * chunk, generator=g) * 2).cuda().to(wt)
+    red = torch.empty(chunk, dtype=wt, device="cuda")
+    _lib.check(lib.recnet_dp_reduce(C.c_void_p(recv.data_ptr()), world, chunk, C.c_void_p(red.data_ptr()), bf, st), "recnet_dp_reduce")
+    acc = recv[:chunk].float()
+    for r in range(1, world):
+        acc = acc + recv[r * chunk:(r + 1) * chunk].float()
+    assert torch.equal(red, acc.to(wt))
+    back = torch.empty(n, device="cuda")
+    _lib.check(lib.recnet_dp_cast(C.c_void_p(send.data_ptr()), bf, C.c_void_p(back.data_ptr()), 0, n, st), "recnet_dp_cast")
+    torch.cuda.synchronize()
+    assert torch.equal(back, send[:n].float())
