@@ -551,27 +551,41 @@ __global__ __launch_bounds__(256) void dec_cell_bwd_kernel(const DecCellBwdArgs 
 template <typename AT>
 __global__ __launch_bounds__(256) void ctx_all_kernel(const float* __restrict__ att, const float* __restrict__ enc,
                                                       AT* __restrict__ ctx, int ld, int T, int B, int F, int D) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [32][F], zero padded beyond T
-  const int b = blockIdx.x, d = blockIdx.y * 256 + threadIdx.x;
+  // Round 5: the weights of a frame as [f][32 t] in LDS, read as eight 16-byte broadcasts per frame, and TWO feature columns per
+  // thread — 8 LDS instructions per frame and 64 multiply-adds instead of 32 four-byte LDS reads per 32 multiply-adds: the kernel was
+  // bound by LDS instruction issue (84 us beside the reconstructor's chains for 27 MB of traffic).  grid (B, ceil(ld / 512)).
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [F][32], zero padded beyond T
+  const int b = blockIdx.x, d = (blockIdx.y * 256 + threadIdx.x) * 2;
   for (int i = threadIdx.x; i < 32 * F; i += 256) {
     const int t = i / F, f = i % F;
-    smem[i] = t < T ? att[((size_t)t * B + b) * F + f] : 0.f;
+    smem[f * 32 + t] = t < T ? att[((size_t)t * B + b) * F + f] : 0.f;
   }
   __syncthreads();
   if (d >= ld) return;
-  float acc[32];
+  float a0[32], a1[32];
 #pragma unroll
-  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+  for (int t = 0; t < 32; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+  const bool two = (D & 1) == 0;      // (16-byte rows of an even width: the pair is one 8-byte load)
   if (d < D)
     for (int f = 0; f < F; ++f) {
-      const float e = enc[((size_t)b * F + f) * D + d];
+      const float* er = enc + ((size_t)b * F + f) * D + d;
+      float e0, e1;
+      if (two) { const float2 e2 = *reinterpret_cast<const float2*>(er); e0 = e2.x; e1 = e2.y; }
+      else { e0 = er[0]; e1 = d + 1 < D ? er[1] : 0.f; }
 #pragma unroll
-      for (int t = 0; t < 32; ++t) acc[t] += smem[t * F + f] * e;
+      for (int t4 = 0; t4 < 8; ++t4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(smem + f * 32 + t4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[t4 * 4 + j] += w[j] * e0; a1[t4 * 4 + j] += w[j] * e1; }
+      }
     }
   const float invF = 1.0f / (float)F;
 #pragma unroll
   for (int t = 0; t < 32; ++t)
-    if (t < T) ctx[((size_t)t * B + b) * ld + d] = (AT)(acc[t] * invF);
+    if (t < T) {
+      AT* dst = ctx + ((size_t)t * B + b) * ld + d;      // (ld is even: d + 1 < ld)
+      dst[0] = (AT)(a0[t] * invF); dst[1] = (AT)((d + 1 < D ? a1[t] : 0.f) * invF);
+    }
 }
 // general-T fallback (caption_max_len + 1 > 32)
 template <typename AT>
@@ -623,16 +637,18 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     for (int i = 0; i < NV; ++i) mx = fmaxf(mx, xs[i]);
     mx = block_max256(mx, sm);
     float s = 0.f;
+    // (round 5: the exponentials are kept — softmax = e_i / s instead of a second expf per element: the kernel is bound by its
+    // transcendentals and dropout hashes, not by its 78 MB)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) if (tid + 256 * i < V) s += expf(xs[i] - mx);
+    for (int i = 0; i < NV; ++i) { const float e = tid + 256 * i < V ? expf(xs[i] - mx) : 0.f; s += e; xs[i] = e; }
     s = block_sum256(s, sm);
     const float lse = mx + logf(s);
-    const float wgt = cw[t];
+    const float wgt = cw[t], inv_s = 1.0f / s;
     if (tid == 0) rowloss[row] = wgt * (lse - x[tgt] * drop_at(dd, key, t, b, V, (int)tgt));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int v = tid + 256 * i;
-      if (v < ld) dx[v] = (AT)(v < V ? wgt * (expf(xs[i] - lse) - (v == tgt ? 1.f : 0.f)) * ms[i] : 0.f);
+      if (v < ld) dx[v] = (AT)(v < V ? wgt * (xs[i] * inv_s - (v == tgt ? 1.f : 0.f)) * ms[i] : 0.f);
     }
     for (int v = NV * 256 + tid; v < ld; v += 256) dx[v] = (AT)0.f;
     return;
