@@ -400,7 +400,8 @@ int recnet_debug_occupy(recnet_handle* h, int32_t n_workgroups, int32_t microsec
  * and by recnet_pack_weights) are copied aside, re-packed from the master parameters, and compared: *n_diff_out = number of
  * 16-bit words that differ (0 = every image was up to date).  Completes a pending deferred update first; synchronises the
  * stream; leaves the images freshly packed.  Holds train.py:271-273 "the next forward uses the updated weights" for the images. */
-int recnet_debug_images_stale(recnet_handle* h, int64_t* n_diff_out, void* stream);
+int64_t recnet_debug_images_bytes(recnet_handle* h);       /* bytes of device scratch recnet_debug_images_stale needs (256-byte aligned) */
+int recnet_debug_images_stale(recnet_handle* h, void* scratch_dev, int64_t scratch_bytes, int64_t* n_diff_out, void* stream);
 /* Test hook: byte offset inside the bound workspace of a saved tensor of the local reconstructor's forward pass
  * (0: Whr [F][B][RA], 1: beta [F][B][T], 2: Hr [F][B][R], 3: acts [F][B][4R]); -1 if unknown. */
 int64_t recnet_debug_offset(const recnet_handle* h, int32_t which);

@@ -141,7 +141,8 @@ EXPORTS["recnet_abort_step"] = (_i, [C.c_void_p])
 EXPORTS["recnet_dp_cast"] = (_i, [C.c_void_p, _i, C.c_void_p, _i, C.c_int64, C.c_void_p])
 EXPORTS["recnet_dp_reduce"] = (_i, [C.c_void_p, _i, C.c_int64, C.c_void_p, _i, C.c_void_p])
 EXPORTS["recnet_read_step_ring"] = (_i, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p])
-EXPORTS["recnet_debug_images_stale"] = (_i, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p])
+EXPORTS["recnet_debug_images_bytes"] = (C.c_int64, [C.c_void_p])
+EXPORTS["recnet_debug_images_stale"] = (_i, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p])
 EXPORTS["recnet_read_stamps"] = (_i, [C.c_void_p, C.POINTER(C.c_uint64), _i, C.c_void_p])
 EXPORTS["recnet_gemm_bf16"] = (_i, [C.c_void_p, _i, _i, C.c_void_p, _i, _i, C.c_void_p, _i, C.c_void_p, _i, _i, _i, _f, _i, _i,
                                   C.c_void_p, _i, C.c_void_p])

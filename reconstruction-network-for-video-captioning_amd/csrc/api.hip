@@ -113,6 +113,12 @@ struct recnet_handle {
   // deferred reconstructor update (recnet_set_deferred_reconstructor_update): ctrl[2] on the device says whether an update is
   // pending; maybe_pending is the host's conservative shadow (replayed graphs do not run host code)
   int in_fused = 0, side_fork_recorded = 0;
+  // Deferred refresh of the reconstructor's DERIVED weight images (round 5; opt-in with the deferred-update modes, applies where the
+  // split update does not — 28 x 3584, row groups): the fused step skips the transposes / fragment packs behind its reconstructor
+  // Adam step (183 us at the end of the step at 28 x 3584) and runs them at the start of the NEXT fused step, on the third stream
+  // beside the decoder's forward chain; the reconstructor's chains wait for them (ev[12]).  The refresh is idempotent, so a captured
+  // step is correct behind any other; images_maybe_stale is the host's shadow for the non-fused entry points (flush_pending).
+  int img_defer_now = 0, images_maybe_stale = 0, s3_late = 0;
   int dp_overlap = 0, side_open = 0;   // recnet_set_dp_overlap: part 1 of the data-parallel step leaves the side stream's weight-gradient products unjoined (recnet_join_side)
   int hoist_fork_recorded = 0;   // dec_fwd_chain recorded the fork events of hoist_side_work itself, in front of the chain launch
   int side_tail_open = 0;  // decoder-only: dec_bwd_out recorded the BPTT's join in front of the rest of the side branch (ev[18] covers the rest)
@@ -642,6 +648,7 @@ extern "C" {
 // reads the reconstructor's parameters, packed images, gradients or Adam state.
 static void refresh_rec_images(recnet_handle* h, hipStream_t st);
 static int flush_pending(recnet_handle* h, hipStream_t st, int explicit_call = 0) {
+  if (h->images_maybe_stale && h->rec_bound) { refresh_rec_images(h, st); h->images_maybe_stale = 0; }      // (deferred image refresh)
   // maybe_pending is the host's shadow of the device's pending word: set when a deferred step is enqueued or captured, and
   // by recnet_mark_pending when a captured one is replayed.  An explicit recnet_flush also runs while the mode is on (the
   // device word decides whether the Adam step happens; the products are recomputed from the step's own operands either way).

@@ -318,8 +318,12 @@ class Engine:
     def images_stale(self):
         """Test hook: number of 16-bit words in which the packed operand images differ from a fresh re-pack of the master
         parameters (recnet_debug_images_stale); completes a pending update and synchronises."""
+        nb = int(self.lib.recnet_debug_images_bytes(self.handle))
+        assert nb > 0
+        scratch = torch.empty(nb + 256, dtype=torch.uint8, device=self.device)      # (the caller's allocator, like every other buffer)
+        base = (scratch.data_ptr() + 255) // 256 * 256
         n = C.c_int64(-1)
-        _lib.check(self.lib.recnet_debug_images_stale(self.handle, C.byref(n), _stream()), "recnet_debug_images_stale")
+        _lib.check(self.lib.recnet_debug_images_stale(self.handle, C.c_void_p(base), nb, C.byref(n), _stream()), "recnet_debug_images_stale")
         return int(n.value)
 
     def debug_occupy(self, n_workgroups, microseconds, stream=None):

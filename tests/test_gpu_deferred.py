@@ -15,7 +15,9 @@ from tests.gpu_util import make_models
 pytestmark = pytest.mark.gpu
 
 # persistent-chain shape (H % 32, R % 32) and a ragged one that takes the per-step kernels
-SHAPES = {"chains": [24, 6, 64, 61, 16, 32, 16, 16], "per_step": [9, 5, 40, 61, 12, 24, 8, 8]}
+# "row_groups": 120 captions = two row groups of 60 — the split update is not applied there (recnet_create), the step updates at once
+# and defers only the refresh of the derived weight images to the next step's start (round 5: img_defer_now, csrc/api.hip)
+SHAPES = {"chains": [24, 6, 64, 61, 16, 32, 16, 16], "per_step": [9, 5, 40, 61, 12, 24, 8, 8], "row_groups": [120, 6, 64, 61, 16, 32, 16, 16]}
 
 
 def _state(md):
@@ -101,7 +103,9 @@ def test_deferred_update_equals_the_immediate_one_once_flushed(lr, mode, lengths
     if lr is None:
         assert np.allclose(l0[:, :7], l1[:, :7], rtol=1e-6 if mode is True else 3e-6, atol=0), (l0[:, 6], l1[:, 6])
         for k in d0:
-            assert _same(d0[k], d1[k], k, True), ("decoder", k, float((d0[k] - d1[k]).abs().max()))
+            # (the decoder sees the reconstructor's parameters through d loss / d hiddens: bit-identical only where they are)
+            # (B = 120 on the fp32 path: the per-step backward sums d Uv over frame chunks with float atomics — reproducible to rounding)
+            assert _same(d0[k], d1[k], k, shape != "row_groups"), ("decoder", k, float((d0[k] - d1[k]).abs().max()))
         for k in r0:
             assert _same(r0[k], r1[k], k, exact), ("reconstructor", k, float((r0[k] - r1[k]).abs().max()))
         assert any(not torch.equal(r1["p." + k].cpu(), v) for k, v in recP.items())

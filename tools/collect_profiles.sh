@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): bench lines, rocprofv3 kernel statistics, step timelines and PMC traffic passes of the GPU
-# configurations of BASELINE.json, written under gpurun_out/r04/ (copied into profiles/ afterwards).
+# configurations of BASELINE.json, written under gpurun_out/r05/ (copied into profiles/ afterwards).
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-RND=r04
+RND=r05
 O=gpurun_out/$RND; mkdir -p $O
 run() {  # name "bench args" extra
   local n=$1 args="$2"
@@ -75,3 +75,9 @@ for cfg in c2 c5; do
 done
 rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/prof_*
 ls -la $O
+# round 5 additions: GEMM K-loop / epilogue stamps, cold / warm shapes against the vendor library, the idle time between replays
+./tools/micro/gemm_probe > $O/gemm_probe.txt 2>&1
+python3 tools/gemm_cold_probe.py > $O/gemm_cold_vs_hipblaslt.txt 2>&1
+python3 tools/between_steps_probe.py global > $O/between_steps_c2.txt 2>&1
+python3 tools/soak.py 5000 > $O/soak.json 2> $O/soak.err
+ls $O | wc -l
