@@ -174,13 +174,23 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       // wave = two 16-column groups of the 128 attention columns
       f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
       const int cg0 = 2 * wave;
+      // (every k-step unconditionally: attn_W in LDS and hl are zero beyond H — the run-time test per k-step made the compiler branch
+      // around every pair of MFMAs and shuffle the accumulators between the register files, see dec_chain_bwd_kernel's da product)
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        if (ks * 32 < H) {
-          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(hl + ks * 32 + (lane >> 4) * 8);
+      for (int k4 = 0; k4 < 16; k4 += 4) {
+        bf16x8 fa[4], f0[4], f1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ks = k4 + j;
+          fa[j] = *reinterpret_cast<const bf16x8*>(hl + ks * 32 + (lane >> 4) * 8);
           const bf16_t* wp = wlds + ((size_t)(ks * 4 + (lane >> 4)) * 128 + (lane & 15)) * 8;
-          w0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, *reinterpret_cast<const bf16x8*>(wp + (cg0 * 16) * 8), w0, 0, 0, 0);
-          w1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, *reinterpret_cast<const bf16x8*>(wp + (cg0 * 16 + 16) * 8), w1, 0, 0, 0);
+          f0[j] = *reinterpret_cast<const bf16x8*>(wp + (cg0 * 16) * 8);
+          f1[j] = *reinterpret_cast<const bf16x8*>(wp + (cg0 * 16 + 16) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j], f0[j], w0, 0, 0, 0);
+          w1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j], f1[j], w1, 0, 0, 0);
         }
       }
       if (lane < 16) { swh[cg0 * 16 + lane] = w0[0]; swh[cg0 * 16 + 16 + lane] = w1[0]; }
@@ -766,16 +776,27 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
         f32x4 acc[NFB];
 #pragma unroll
         for (int fb = 0; fb < NFB; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Every k-step unconditionally (round 5): the P fragments beyond H are zeros and the dgates operand falls on the row buffer's
+        // zero tail there, so a skipped step and an executed one give the same sums.  The run-time test `ks * 32 < H` around each
+        // pair of MFMAs made the compiler branch per k-step and move both accumulators between the register files around EVERY
+        // MFMA (s_nop 7 + 8 v_accvgpr moves, the LDS read waited for in between): 2.1 us per step for 32 MFMAs — a fifth of the BPTT
+        // step.  Straight-line: the 16 LDS reads in two batches, two independent accumulation chains.
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const int ku = ks * 32 + kq;
-          const bf16x8 bv = (ks * 32 < H) ? *reinterpret_cast<const bf16x8*>(srow + (ku < H ? g * H + ku : W4 + 128)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (ks * 32 < H) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0][ks], bv, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1][ks], bv, acc[1], 0, 0, 0);
+        for (int k8 = 0; k8 < 16; k8 += 8) {
+          bf16x8 bv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ku = (k8 + j) * 32 + kq;
+            bv[j] = *reinterpret_cast<const bf16x8*>(srow + (ku < H ? g * H + ku : W4 + 128));
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ks = k8 + j, ku = ks * 32 + kq;
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0][ks], bv[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1][ks], bv[j], acc[1], 0, 0, 0);
             if (XF) {
               const bf16x8 px = ku < H ? *reinterpret_cast<const bf16x8*>(plx + (size_t)(lane & 15) * DCB_PLD + g * H + ku) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-              acc[NFB - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(px, bv, acc[NFB - 1], 0, 0, 0);
+              acc[NFB - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(px, bv[j], acc[NFB - 1], 0, 0, 0);
             }
           }
         }
