@@ -176,7 +176,7 @@ static size_t carve(recnet_handle* h, char* base) {
   const size_t ldD = h->ldD, ldE = h->ldE, ldH = h->ldH, ldV = h->ldV, ldA = h->ldA, ld4H = h->ld4H, ldWS = h->ldWS,
                ldR = h->ldR, ld4R = h->ld4R, ldRA = h->ldRA, ldHR = h->ldHR;
   h->ctrl = (uint32_t*)take(64);
-  h->gbar = (uint32_t*)take(4096 + 64);   // (floats: 16 KB) per chain kernel 256 arrival flags + 256 release words; epochs behind   // up to four persistent launches x 256 flags, then the launch-epoch words
+  h->gbar = (uint32_t*)take(4096 + 64 + 2240);   // (floats: 16 KB) per chain kernel 256 arrival flags + 256 release words; epochs behind   // up to four persistent launches x 256 flags, then the launch-epoch words
   h->dc_G1 = take(2 * Tm * B * (4 * H + A));   // fp32, or 8-byte stamped words
   h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
   h->dc_G2 = take(2 * Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
@@ -539,7 +539,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   // gradients — by the fixed-shape products of a deferred reconstructor update, and 0 x NaN bit patterns would not be 0
   HIPCHK(hipMemset(h->ws, 0, h->need));
   // stamped exchange buffers and the launch-epoch words start from zero (a stamp is never zero)
-  HIPCHK(hipMemset(h->gbar, 0, (4096 + 64) * 4)); HIPCHK(hipMemset(h->scal, 0, 64 * 4)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
+  HIPCHK(hipMemset(h->gbar, 0, (4096 + 64 + 2240) * 4)); HIPCHK(hipMemset(h->scal, 0, 64 * 4)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
   HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * 4));
   h->gws_cur = h->gws;
   if (!h->s2) {

@@ -30,6 +30,7 @@ struct DecChainArgs {
   float* G1;                       // [T][B][4H + A] exchange: recurrent pre-activations (ll: 8-byte words {value, stamp})
   unsigned* epoch; int ll;         // ll = 1: phase A -> B hand-over through stamped words instead of a grid barrier
   int master;                      // 1: the last workgroup of the grid is the barrier master (rc_master_loop)
+  int partial; unsigned* rep;      // RP kernels: phase A waits for the captions of its row part only, through per-XCD replicas of the part's arrival line (see dec_chain_bwd_kernel)
   float* poison;                   // see rc_give_up (rec_chain.hpp)
   float* mp; float mp_scale;       // optional: mp_scale * sum_t h_t [B][H] (the global reconstructor's mean-pooled input)
   bf16_t* Xcat; int ld_xcat; DropDesc xdd;   // optional (global reconstructor, ld_xcat == 2H): its LSTM input operand [T][Bs][2H] = [h_t ; drop_t(mp)]
@@ -61,11 +62,17 @@ struct DecChainArgs {
 // bf16 = 128 KB) stays in LDS for the whole launch and h_{t-1}[b] never left the workgroup — so scores and context no longer
 // wait for phase A: the scores of step t + 1 are formed while the grid barrier of step t completes, the context MFMAs while
 // phase A's gate pre-activations travel, and only the cell waits for them.  Phase A shrinks to the 4H gate columns.
-template <bool XF, bool LW = false>
+// RP (round 5): phase A tiled as 64 columns x one of 4 row parts (28 rows) instead of 16 columns x all 112 rows — the same number of
+// workgroups and (almost) of MFMAs, but a workgroup pulls 32 rows x H of the h_{t-1} panel through its CU's 64 B/clk L1 path instead
+// of 112 (32 KB instead of 115 KB per step: 0.2 us instead of 0.75), and its consumers and producers all lie in ITS row part, so the
+// B -> A hand-over can be partial (DecChainArgs::partial, as in dec_chain_bwd_kernel).
+#define DCF_PARTS 4
+#define DCF_RLD 65
+template <bool XF, bool LW = false, bool RP = false>
 __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   static_assert(!(XF && LW), "the LDS-resident attn_W and the LDS frames 32..47 do not fit together");
-  // phase A: K-partials of the [112 x 16] tile (LW: two buffers, summed in two stages — the room attn_W needs)
-  __shared__ float red[(LW ? 2 : 4) * RC_PAN_ROWS * DC_RED_LD];
+  // phase A: K-partials of the [112 x 16] tile (LW: two buffers, summed in two stages — the room attn_W needs); RP: of the [32 x 64] tile
+  __shared__ float red[RP ? 2 * 32 * DCF_RLD : (LW ? 2 : 4) * RC_PAN_ROWS * DC_RED_LD];
   __shared__ __attribute__((aligned(16))) float spre[4 * 512];       // phase B: gate pre-activations
   __shared__ float swh[128];
   __shared__ __attribute__((aligned(16))) float sa[32 + DC_XF];
@@ -74,7 +81,9 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t hl[512];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, B = p.B, Bs = p.Bs, W4 = 4 * H, N = 4 * H + A;
-  const int NA = LW ? (W4 >> 4) : (N >> 4);
+  const int NN = LW ? W4 : N;                            // columns phase A produces
+  const int NCB = (NN + 63) >> 6;                        // RP: 64-column blocks
+  const int NA = RP ? NCB * DCF_PARTS : (NN >> 4);
   const int wg = blockIdx.x;
   bf16_t* wlds = reinterpret_cast<bf16_t*>(dc_dyn);      // LW: attn_W as [k / 8][128 a][8] (an MFMA B fragment = 16 bytes per lane, 256 contiguous bytes per 16 lanes)
   if (LW) {
@@ -90,14 +99,19 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   const int kq = (lane >> 4) * 8;
   const size_t pan_t = rc_pan_elems(H);
 
-  // ---- phase A residents: 16 weight rows x K = H (4 waves x 4 k-steps of 32)
-  bf16x8 wb[4];
-  {
-    const bf16_t* wrow = p.W + (size_t)((isA ? wg : 0) * 16 + (lane & 15)) * p.ldw + kq;
+  // ---- phase A residents: 16 weight rows x K = H (4 waves x 4 k-steps of 32); RP: 4 column groups of 16 rows
+  const int cb = RP && isA ? wg % NCB : 0, part = RP && isA ? wg / NCB : 0;
+  const int own = RC_PAN_ROWS / DCF_PARTS, own_lo = part * own;
+  const int r0 = own_lo < RC_PAN_ROWS - 32 ? own_lo : RC_PAN_ROWS - 32;
+  bf16x8 wb[4][RP ? 4 : 1];
+#pragma unroll
+  for (int gq = 0; gq < (RP ? 4 : 1); ++gq) {
+    const int n = RP ? cb * 64 + gq * 16 + (lane & 15) : (isA ? wg : 0) * 16 + (lane & 15);
+    const bf16_t* wrow = p.W + (size_t)(n < NN ? n : 0) * p.ldw + kq;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k = wave * 128 + s * 32;
-      wb[s] = (k + kq < H) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      wb[s][gq] = (k + kq < H && n < NN) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
   if ((H & 31) && wg == 0) {     // zero the k-groups that pad H to a multiple of 32 in every step's panel (see rec_chain.hpp)
@@ -166,6 +180,23 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
     rc_master_loop(p.bar, p.bar + 256, (int)gridDim.x - 1, fb, (p.ll ? 1 : 2) * (p.T - 1));
     return;
   }
+  // RP + partial: the B -> A hand-over inside a row part (the comment at dec_chain_bwd_kernel's wait_part has the measurements)
+  const bool partial = RP && p.partial;
+  auto wait_part = [&](unsigned target) {
+    if (isA && tid < 64) {
+      const int n = B - own_lo < own ? B - own_lo : own;
+      if (n > 0) {
+        const unsigned* f = p.rep + ((wg & 7) * DCF_PARTS + part) * 32 + (tid < n ? tid : n - 1);
+        unsigned spin = 0;
+        while (!__all((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0)) { if (rc_give_up(p.bar, spin)) break; }
+        if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+  };
+  auto arrive_part = [&](unsigned v) {
+    if (isB && tid < 8) __hip_atomic_store(p.rep + (tid * DCF_PARTS + b / own) * 32 + b % own, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
 
   // LW: attention projection and scores of step tt, from this caption's own h_{tt-1} (hl, bf16) — no other workgroup involved
   auto lw_scores = [&](const int tt) {
@@ -229,6 +260,67 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       // ================= phase A: G1[t][:, 16 columns] = h_{t-1} . W^T
       DC_TS(0);
       if (isA) {
+       if constexpr (RP) {
+        const bf16_t* Ap = p.Pan + (size_t)(t - 1) * pan_t + lane_off + r0 * 8;
+        bf16x8 fa[4][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int k = wave * 128 + s * 32;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            fa[s][i] = *reinterpret_cast<const bf16x8*>(Ap + ((k < H ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) acc[i][gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) acc[i][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], wb[s][gq], acc[i][gq], 0, 0, 0);
+        const int rr = (lane >> 4) * 4, cl = lane & 15;
+        // the four K quarters in two stages through two [32 x 64] buffers: waves 2, 3 store, waves 0, 1 add
+        float* part_ = red + (wave & 1) * (32 * DCF_RLD);
+        if (wave >= 2) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCF_RLD + gq * 16 + cl] = acc[i][gq][r];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCF_RLD + gq * 16 + cl] += acc[i][gq][r];
+        }
+        __syncthreads();
+        DC_TS(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = tid + j * 256, row = own_lo + (idx >> 5), pc = (idx & 31) * 2, rl = row - r0;
+          if (idx < own * 32 && row < B && cb * 64 + pc < NN) {
+            const float v0 = red[rl * DCF_RLD + pc] + red[32 * DCF_RLD + rl * DCF_RLD + pc];
+            const float v1 = red[rl * DCF_RLD + pc + 1] + red[32 * DCF_RLD + rl * DCF_RLD + pc + 1];
+            if (p.ll) {
+              uint64_t* L = reinterpret_cast<uint64_t*>(p.G1) + ((size_t)t * B + row) * N + cb * 64 + pc;
+              const unsigned st = ep | (unsigned)t;
+              rc_store16f(reinterpret_cast<float*>(L), f32x4{v0, __builtin_bit_cast(float, st), v1, __builtin_bit_cast(float, st)});
+            } else {
+              union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
+              __hip_atomic_store(reinterpret_cast<uint64_t*>(p.G1 + ((size_t)t * B + row) * N + cb * 64 + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+       } else {
         const bf16_t* Ap = p.Pan + (size_t)(t - 1) * pan_t + lane_off;
         bf16x8 fa[4][RC_MB];
 #pragma unroll
@@ -245,7 +337,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int i = 0; i < RC_MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], wb[s], acc[i], 0, 0, 0);
+          for (int i = 0; i < RC_MB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], wb[s][0], acc[i], 0, 0, 0);
         const int rr = (lane >> 4) * 4, cl = lane & 15;
         if (LW) {
           // waves 2, 3 hand their partials to waves 0, 1 through the two buffers, which then hold the two half sums
@@ -300,6 +392,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
             }
           }
         }
+       }
         if (!p.ll) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if (!p.ll) {
@@ -478,7 +571,7 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
       }
       if (t + 1 < p.T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // (the stores below are issued after the arrive, see the end of the loop body)
-      if (t + 1 < p.T) { __syncthreads(); DC_TS(6); ++ph; rc_arrive(p.bar, fb + ph); }
+      if (t + 1 < p.T) { __syncthreads(); DC_TS(6); ++ph; if (partial) arrive_part(fb + ph); else rc_arrive(p.bar, fb + ph); }
       bf16_t* Lt = p.Hlp + ((size_t)t * Bs + b) * p.ld_hlp;
       if (tid < (H >> 3)) *reinterpret_cast<bf16x8*>(Lt + tid * 8) = *reinterpret_cast<const bf16x8*>(hl + tid * 8);
       if (p.Xcat && tid < (H >> 3)) *reinterpret_cast<bf16x8*>(p.Xcat + ((size_t)t * Bs + b) * p.ld_xcat + tid * 8) = *reinterpret_cast<const bf16x8*>(hl + tid * 8);
@@ -495,14 +588,19 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
         }
       }
       if (LW && t + 1 < p.T) lw_scores(t + 1);      // from hl = h_t, while the barrier completes
-      if (t + 1 < p.T) { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
+      if (t + 1 < p.T) { if (partial) wait_part(fb + ph); else if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
       DC_TS(7);
     } else if (t + 1 < p.T) {
       __syncthreads();
       ++ph;
-      rc_arrive(p.bar, fb + ph);
-      { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
+      if (!partial) rc_arrive(p.bar, fb + ph);
+      { if (partial) wait_part(fb + ph); else if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
     }
+  }
+  if (partial) {      // the launch epoch may only move once every workgroup has read it: one full barrier at the end
+    __syncthreads();
+    rc_arrive(p.bar, fb + (unsigned)p.T);
+    if (wg == 0) rc_wait(p.bar, fb + (unsigned)p.T);
   }
   if (p.mp && isB) {
 #pragma unroll
@@ -547,6 +645,8 @@ struct DecChainBwdArgs {
   const float* att; int softmax;   // softmax mode: the saved attention weights [T][B][F]
   float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh (ll: stamped 8-byte words)
   unsigned* epoch; int ll; int master; float* poison;
+  int partial;                     // 1 (needs ll, excludes master): phase A' waits for the captions of ITS row part only (below)
+  unsigned* rep;                   // partial: [8 XCDs][DCB_PARTS][32] arrival words, a 128-byte line per (XCD, row part)
   bf16_t* Pan;                     // [T][rc_pan_elems(4H + A)] exchange (by chain step): rows [dgates | dWh]
   bf16_t* dGx; int ld_dgx;         // [T][B][ld_dgx]
   float* dUv; bf16_t* dUv_lp; int ld_dUv;                   // [B][F][A], [B F][ld_dUv]
@@ -649,6 +749,31 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
     rc_master_loop(p.bar, p.bar + 256, (int)gridDim.x - 1, fb, (p.ll ? 1 : 2) * (p.T - 1));
     return;
   }
+  // Partial hand-over B' -> A' (round 5).  A phase-A' workgroup reads only the `own` = 28 panel rows of its row part, i.e. the rows
+  // [dgates | dWh] of 28 captions, and phase B' of a caption polls the stamped words of the 32 unit groups of ITS part: the
+  // dependencies close inside a row part, so nothing needs the whole grid.  Arrive -> master sees all 128 -> release word -> waiter
+  // becomes arrive -> waiter: one memory round trip instead of two, and a part does not wait for the stragglers of the other three.
+  // A caption writes its arrival into EIGHT replicas of its part's flag line, one per XCD (p.rep: [8][DCB_PARTS][32] words, a 128-byte
+  // line per (XCD, part)); a waiter polls the replica of its own XCD (blockIdx % 8, like the release words) with one wave load.
+  // With ONE copy polled by all 128 workgroups the step got 0.9 us LONGER (measured: 315 against 288 us per launch) — a line that is
+  // written from eight XCDs and read from eight is the worst case for the L2s; in this form every line has its readers in one XCD,
+  // like the arrival flags (read by the master only) and the release words (one line per XCD) of the relayed barrier.
+  // Workgroups without a phase A' do not wait.
+  auto wait_part = [&](unsigned target) {
+    if (isA && tid < 64) {
+      const int n = B - own_lo < own ? B - own_lo : own;
+      if (n > 0) {
+        const unsigned* f = p.rep + ((wg & 7) * DCB_PARTS + part) * 32 + (tid < n ? tid : n - 1);
+        unsigned spin = 0;
+        while (!__all((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0)) { if (rc_give_up(p.bar, spin)) break; }
+        if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+  };
+  auto arrive_part = [&](unsigned v) {       // caption b = wg: its part, its slot in the part's line, all eight replicas
+    if (isB && tid < 8) __hip_atomic_store(p.rep + (tid * DCB_PARTS + b / own) * 32 + b % own, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
 
   // saved tensors of step t for this thread's two units, and Wh[t][b][kk]
   float d1[2], d2[2], av[2][4], cv[2], cpv[2], whk;
@@ -861,20 +986,26 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       for (int kg = tid; kg < (KA >> 3); kg += 256) {
         rc_store16(p.Pan + (size_t)s * pan_t + ((size_t)kg * RC_PAN_ROWS + b) * 8, srow + kg * 8);
       }
-      if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; rc_arrive(p.bar, fb + ph); }
+      if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ++ph; if (p.partial) arrive_part(fb + ph); else rc_arrive(p.bar, fb + ph); }
       DCB_TS(5);
       // ---- off the critical path: the row-major copy [dgates | dWh | 0 ..] for the deferred GEMMs
       bf16_t* Gt = p.dGx + ((size_t)t * Bs + b) * p.ld_dgx;
       for (int kg = tid; kg < (p.ld_dgx >> 3); kg += 256)
         *reinterpret_cast<bf16x8*>(Gt + kg * 8) = kg < (KA >> 3) ? *reinterpret_cast<const bf16x8*>(srow + kg * 8) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (more) { prefetch(t - 1); { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); } }
+      if (more) { prefetch(t - 1); { if (p.partial) wait_part(fb + ph); else if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); } }
       DCB_TS(6);
     } else if (s + 1 < p.T) {
       __syncthreads();
       ++ph;
-      rc_arrive(p.bar, fb + ph);
-      { if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
+      if (!p.partial) rc_arrive(p.bar, fb + ph);
+      { if (p.partial) wait_part(fb + ph); else if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
     }
+  }
+  if (p.partial) {
+    // the launch epoch may only move once every workgroup has read it: a full barrier, once, at the end (phase T: above every step's)
+    __syncthreads();
+    rc_arrive(p.bar, fb + (unsigned)p.T);
+    if (wg == 0) rc_wait(p.bar, fb + (unsigned)p.T);
   }
   // ---- the accumulators: dUv (+ operand copy, zero padded), dw
   if (isB) {
