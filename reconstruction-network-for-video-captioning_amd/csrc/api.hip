@@ -179,7 +179,7 @@ static size_t carve(recnet_handle* h, char* base) {
   h->gbar = (uint32_t*)take(4096 + 64 + 2240);   // (floats: 16 KB) per chain kernel 256 arrival flags + 256 release words; epochs behind   // up to four persistent launches x 256 flags, then the launch-epoch words
   h->dc_G1 = take(2 * Tm * B * (4 * H + A));   // fp32, or 8-byte stamped words
   h->dc_pan = takev(Tm * rc_pan_elems((int)H) / 2 + 64);
-  h->dc_G2 = take(2 * Tm * B * H); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
+  h->dc_G2 = take(2 * Tm * B * H * DCB_KS); h->dc_pan2 = takev(Tm * rc_pan_elems((int)(4 * H + A)) / 2 + 64);
   h->scal = take(64);
   h->lc_ts = (unsigned long long*)take(2 * (2 * 8 * 64 * 8));   // 8192 u64 entries (take counts floats): local chains [8 roles][64][8], decoder chains at +4096 / +4608
   h->stepw = take(Tm);
@@ -433,7 +433,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     int dev = 0, ncu = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    const int NAb = (h->H / 16) * DCB_PARTS;
+    const int NAb = DCB_NA(h->H);
     // RN_RESERVE_CUS: CUs left to a collective kernel (RCCL) that is resident while this chain runs — data parallel runs
     // all-reduce the reconstructor bucket under the decoder's BPTT (dp.py sets 64).  The chain would still complete
     // without the reserve (the collective does not wait for it), but its first steps would spin until CUs free up.
@@ -540,7 +540,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   HIPCHK(hipMemset(h->ws, 0, h->need));
   // stamped exchange buffers and the launch-epoch words start from zero (a stamp is never zero)
   HIPCHK(hipMemset(h->gbar, 0, (4096 + 64 + 2240) * 4)); HIPCHK(hipMemset(h->scal, 0, 64 * 4)); HIPCHK(hipMemset(h->dc_G1, 0, (size_t)2 * h->Tm * h->B * (4 * h->H + h->A) * 4));
-  HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * 4));
+  HIPCHK(hipMemset(h->dc_G2, 0, (size_t)2 * h->Tm * h->B * h->H * DCB_KS * 4));
   h->gws_cur = h->gws;
   if (!h->s2) {
     h->overlap = 1;

@@ -68,6 +68,11 @@ struct DecChainArgs {
 // B -> A hand-over can be partial (DecChainArgs::partial, as in dec_chain_bwd_kernel).
 #define DCF_PARTS 4
 #define DCF_RLD 65
+// XCD-aware roles: workgroup i runs on XCD i % 8 (rec_chain.hpp), and every XCD fetches what its workgroups read into its own L2.
+// Row part = (i % 8) / 2: the two XCDs of a part read only that part's 28 panel rows (a quarter of h_{t-1}) — with the column block
+// as the fast index every XCD pulled the whole panel every step, eight copies of it over the fabric.  The column blocks are dealt
+// to (i % 2, i / 8); a part's arrival line is polled from its two XCDs only.
+#define DCF_NA(NN) (8 * (((((NN) + 63) >> 6) + 1) >> 1))
 template <bool XF, bool LW = false, bool RP = false>
 __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   static_assert(!(XF && LW), "the LDS-resident attn_W and the LDS frames 32..47 do not fit together");
@@ -82,8 +87,8 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, B = p.B, Bs = p.Bs, W4 = 4 * H, N = 4 * H + A;
   const int NN = LW ? W4 : N;                            // columns phase A produces
-  const int NCB = (NN + 63) >> 6;                        // RP: 64-column blocks
-  const int NA = RP ? NCB * DCF_PARTS : (NN >> 4);
+  const int NCB = (NN + 63) >> 6, NCBH = (NCB + 1) >> 1;  // RP: 64-column blocks, and half of them (below)
+  const int NA = RP ? DCF_NA(NN) : (NN >> 4);
   const int wg = blockIdx.x;
   bf16_t* wlds = reinterpret_cast<bf16_t*>(dc_dyn);      // LW: attn_W as [k / 8][128 a][8] (an MFMA B fragment = 16 bytes per lane, 256 contiguous bytes per 16 lanes)
   if (LW) {
@@ -95,18 +100,18 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
     }
     for (int j = tid; j < 512; j += 256) hl[j] = (bf16_t)0.f;
   }
-  const bool isA = wg < NA, isB = wg < B;
+  const int cb = RP ? (wg & 1) * NCBH + (wg >> 3) : 0, part = RP ? (wg & 7) >> 1 : 0;
+  const bool isA = wg < NA && (!RP || cb < NCB), isB = wg < B;
   const int kq = (lane >> 4) * 8;
   const size_t pan_t = rc_pan_elems(H);
 
   // ---- phase A residents: 16 weight rows x K = H (4 waves x 4 k-steps of 32); RP: 4 column groups of 16 rows
-  const int cb = RP && isA ? wg % NCB : 0, part = RP && isA ? wg / NCB : 0;
   const int own = RC_PAN_ROWS / DCF_PARTS, own_lo = part * own;
   const int r0 = own_lo < RC_PAN_ROWS - 32 ? own_lo : RC_PAN_ROWS - 32;
   bf16x8 wb[4][RP ? 4 : 1];
 #pragma unroll
   for (int gq = 0; gq < (RP ? 4 : 1); ++gq) {
-    const int n = RP ? cb * 64 + gq * 16 + (lane & 15) : (isA ? wg : 0) * 16 + (lane & 15);
+    const int n = RP ? (isA ? cb : 0) * 64 + gq * 16 + (lane & 15) : (isA ? wg : 0) * 16 + (lane & 15);
     const bf16_t* wrow = p.W + (size_t)(n < NN ? n : 0) * p.ldw + kq;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
     }
     __syncthreads();
   };
-  auto arrive_part = [&](unsigned v) {
-    if (isB && tid < 8) __hip_atomic_store(p.rep + (tid * DCF_PARTS + b / own) * 32 + b % own, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto arrive_part = [&](unsigned v) {      // the replicas of the part's two XCDs
+    if (isB && tid < 2) __hip_atomic_store(p.rep + ((2 * (b / own) + tid) * DCF_PARTS + b / own) * 32 + b % own, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
   // LW: attention projection and scores of step tt, from this caption's own h_{tt-1} (hl, bf16) — no other workgroup involved
@@ -643,7 +648,7 @@ struct DecChainBwdArgs {
   const float* acts; const float* Cs; const float* Hs;      // [T][B][4H], [T][B][H], [T][B][H]
   const float* Wh;                 // [T][B][A]
   const float* att; int softmax;   // softmax mode: the saved attention weights [T][B][F]
-  float* G2;                       // [T][B][H] exchange (by chain step): recurrent part of dh (ll: stamped 8-byte words)
+  float* G2;                       // [T][B][DCB_KS][H] exchange (by chain step): the K parts of the recurrent part of dh (ll: stamped 8-byte words)
   unsigned* epoch; int ll; int master; float* poison;
   int partial;                     // 1 (needs ll, excludes master): phase A' waits for the captions of ITS row part only (below)
   unsigned* rep;                   // partial: [8 XCDs][DCB_PARTS][32] arrival words, a 128-byte line per (XCD, row part)
@@ -660,16 +665,24 @@ struct DecChainBwdArgs {
 #else
 #define DCB_TS(i) do { } while (0)
 #endif
-#define DCB_STEPS 17          // k32-steps per wave: 4 x 17 x 32 = 2176 >= 4H + A
 #define DCB_RB 2              // 32 rows per workgroup in phase A', 4 row parts
 #define DCB_PARTS 4
+// Phase A' tiling (round 5): workgroup = (64 output units, one of 4 row parts, one of DCB_KS parts of K = 4H + A) instead of
+// (16 units, row part, all of K) — the same number of workgroups (128 at H = 512) and 40 instead of 34 MFMAs per wave, but a
+// workgroup pulls 32 rows x K / 4 of the panel through its CU's 64 B/clk L1 path per step instead of 32 rows x K (35 KB instead of
+// 139 KB: the forward chain's phase A went from 2.16 to 1.22 us per step with the same change of ratio).  The DCB_KS partial sums of
+// a (row, unit) are separate stamped words; phase B' polls all of them and adds them in K order.
+#define DCB_KS 4
+#define DCB_WS 5              // k32-steps per wave: 4 waves x 5 >= ceil(68 / DCB_KS) = 17 k-steps per K part at H = 512, A = 128
+#define DCB_RLD 65
+#define DCB_NA(H) ((((H) + 63) >> 6) * DCB_PARTS * DCB_KS)
 
 // XF: frames 32 .. 47 — the third 16-frame block of P as MFMA A fragments read from (dynamic) LDS (rows padded by 8
 // elements: the 16 lanes of a fragment load then fall into different banks), their Uv rows and dUv accumulators in LDS.
 #define DCB_PLD (4 * 512 + 8)
 template <bool XF>
 __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArgs p) {
-  __shared__ float red[4 * DCB_RB * 16 * DC_RED_LD];
+  __shared__ float red[2 * 32 * DCB_RLD];      // phase A': the K quarters of the workgroup's [32 x 64] tile, summed in two stages
   __shared__ __attribute__((aligned(16))) bf16_t srow[4 * 512 + 128 + 64];   // [dgates | dWh] of this step (+ zero tail)
   __shared__ float spartf[4 * (32 + DC_XF)], sda[32 + DC_XF], spart[256];
   extern __shared__ __attribute__((aligned(16))) float dc_dyn[];     // XF: [DC_XF][DCB_PLD] bf16, [DC_XF][128] Uv, [DC_XF][128] dUv
@@ -678,23 +691,30 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
   float* sdux = suvx + DC_XF * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, A = p.A, F = p.F, B = p.B, Bs = p.Bs, W4 = 4 * H, KA = 4 * H + A;
-  const int NU = H >> 4, NA = NU * DCB_PARTS;
+  const int NUB = (H + 63) >> 6, NA = DCB_NA(H);
   const int wg = blockIdx.x;
   const bool isA = wg < NA, isB = wg < B;
   const int kq = (lane >> 4) * 8;
   const size_t pan_t = rc_pan_elems(KA);
 
   // ---- phase A' residents
-  const int ug = isA ? wg % NU : 0, part = isA ? wg / NU : 0;
+  // XCD-aware roles (see DCF_NA): row part = (wg % 8) / 2, so the two XCDs of a part fetch 2 / 16 of the panel (its rows, half of K each)
+  // instead of all of it; K part = 2 (wg % 2) + (wg / 8) / NUB, unit block = (wg / 8) % NUB
+  const int ub = isA ? (wg >> 3) % NUB : 0, part = isA ? (wg & 7) >> 1 : 0, kp = isA ? ((wg & 1) << 1) | ((wg >> 3) / NUB) : 0;
   const int own = RC_PAN_ROWS / DCB_PARTS, own_lo = part * own;
   const int r0 = own_lo < RC_PAN_ROWS - DCB_RB * 16 ? own_lo : RC_PAN_ROWS - DCB_RB * 16;
-  bf16x8 wb[DCB_STEPS];
-  {
-    const bf16_t* wrow = p.Wt + (size_t)(ug * 16 + (lane & 15)) * p.ldwt + kq;
+  const int KT = (KA + 31) >> 5, KPP = (KT + DCB_KS - 1) / DCB_KS;      // k32-steps in all / per K part
+  // slot j of this wave = k-step kp KPP + wave + 4 j of the K part (-1: none)
+  auto kstep = [&](int j) { const int o = wave + 4 * j; return (o < KPP && kp * KPP + o < KT) ? kp * KPP + o : -1; };
+  bf16x8 wb[DCB_WS][4];
 #pragma unroll
-    for (int s = 0; s < DCB_STEPS; ++s) {
-      const int k = (wave * DCB_STEPS + s) * 32;
-      wb[s] = (k + kq < KA) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int gq = 0; gq < 4; ++gq) {
+    const int n = ub * 64 + gq * 16 + (lane & 15);
+    const bf16_t* wrow = p.Wt + (size_t)(n < H ? n : 0) * p.ldwt + kq;
+#pragma unroll
+    for (int j = 0; j < DCB_WS; ++j) {
+      const int ks = kstep(j), k = ks * 32;
+      wb[j][gq] = (ks >= 0 && n < H && k + kq < KA) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
   if ((KA & 31) && wg == 0) {    // zero the k-groups that pad KA to a multiple of 32 in every step's panel
@@ -753,8 +773,8 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
   // [dgates | dWh] of 28 captions, and phase B' of a caption polls the stamped words of the 32 unit groups of ITS part: the
   // dependencies close inside a row part, so nothing needs the whole grid.  Arrive -> master sees all 128 -> release word -> waiter
   // becomes arrive -> waiter: one memory round trip instead of two, and a part does not wait for the stragglers of the other three.
-  // A caption writes its arrival into EIGHT replicas of its part's flag line, one per XCD (p.rep: [8][DCB_PARTS][32] words, a 128-byte
-  // line per (XCD, part)); a waiter polls the replica of its own XCD (blockIdx % 8, like the release words) with one wave load.
+  // A caption writes its arrival into one replica of its part's flag line per XCD that hosts the part's phase-A' workgroups (p.rep:
+  // [8][DCB_PARTS][32] words, a 128-byte line per (XCD, part)); a waiter polls the replica of its own XCD (blockIdx % 8) with one wave load.
   // With ONE copy polled by all 128 workgroups the step got 0.9 us LONGER (measured: 315 against 288 us per launch) — a line that is
   // written from eight XCDs and read from eight is the worst case for the L2s; in this form every line has its readers in one XCD,
   // like the arrival flags (read by the master only) and the release words (one line per XCD) of the relayed barrier.
@@ -771,8 +791,8 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
     }
     __syncthreads();
   };
-  auto arrive_part = [&](unsigned v) {       // caption b = wg: its part, its slot in the part's line, all eight replicas
-    if (isB && tid < 8) __hip_atomic_store(p.rep + (tid * DCB_PARTS + b / own) * 32 + b % own, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto arrive_part = [&](unsigned v) {       // caption b = wg: its part, its slot in the part's line, the replicas of the part's two XCDs
+    if (isB && tid < 2) __hip_atomic_store(p.rep + ((2 * (b / own) + tid) * DCB_PARTS + b / own) * 32 + b % own, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
   // saved tensors of step t for this thread's two units, and Wh[t][b][kk]
@@ -801,52 +821,61 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       DCB_TS(0);
       if (isA) {
         const bf16_t* Ap = p.Pan + (size_t)(s - 1) * pan_t + lane_off;
-        bf16x8 fa[DCB_STEPS][DCB_RB];
+        bf16x8 fa[DCB_WS][DCB_RB];
 #pragma unroll
-        for (int ks = 0; ks < DCB_STEPS; ++ks) {
-          const int k = (wave * DCB_STEPS + ks) * 32;
+        for (int j = 0; j < DCB_WS; ++j) {
+          const int ks = kstep(j);
 #pragma unroll
           for (int i = 0; i < DCB_RB; ++i)
-            fa[ks][i] = *reinterpret_cast<const bf16x8*>(Ap + ((k < KA ? (k >> 3) : 0) * RC_PAN_ROWS + i * 16) * 8);
+            fa[j][i] = *reinterpret_cast<const bf16x8*>(Ap + ((ks >= 0 ? ks * 4 : 0) * RC_PAN_ROWS + i * 16) * 8);
         }
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc[DCB_RB];
-#pragma unroll
-        for (int i = 0; i < DCB_RB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < DCB_STEPS; ++ks)
-#pragma unroll
-          for (int i = 0; i < DCB_RB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], wb[ks], acc[i], 0, 0, 0);
-        float* prt = red + wave * (DCB_RB * 16 * DC_RED_LD);
-        const int rr = (lane >> 4) * 4, cl = lane & 15;
+        f32x4 acc[DCB_RB][4];
 #pragma unroll
         for (int i = 0; i < DCB_RB; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) prt[(i * 16 + rr + r) * DC_RED_LD + cl] = acc[i][r];
-        __syncthreads();
-        {
-          const int rg = own_lo + (tid >> 3), pc = (tid & 7) * 2, rl = rg - r0;
-          if (tid < own * 8 && rg < B) {
-            float v0 = 0.f, v1 = 0.f;
+          for (int gq = 0; gq < 4; ++gq) acc[i][gq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              v0 += red[w * (DCB_RB * 16 * DC_RED_LD) + rl * DC_RED_LD + pc];
-              v1 += red[w * (DCB_RB * 16 * DC_RED_LD) + rl * DC_RED_LD + pc + 1];
-            }
+        for (int j = 0; j < DCB_WS; ++j)
+#pragma unroll
+          for (int i = 0; i < DCB_RB; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) acc[i][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][i], wb[j][gq], acc[i][gq], 0, 0, 0);
+        const int rr = (lane >> 4) * 4, cl = lane & 15;
+        float* part_ = red + (wave & 1) * (32 * DCB_RLD);      // waves 2, 3 store, waves 0, 1 add
+        if (wave >= 2) {
+#pragma unroll
+          for (int i = 0; i < DCB_RB; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCB_RLD + gq * 16 + cl] = acc[i][gq][r];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+          for (int i = 0; i < DCB_RB; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCB_RLD + gq * 16 + cl] += acc[i][gq][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = tid + j * 256, rg = own_lo + (idx >> 5), pc = (idx & 31) * 2, rl = rg - r0, un = ub * 64 + pc;
+          if (idx < own * 32 && rg < B && un < H) {
+            const float v0 = red[rl * DCB_RLD + pc] + red[32 * DCB_RLD + rl * DCB_RLD + pc];
+            const float v1 = red[rl * DCB_RLD + pc + 1] + red[32 * DCB_RLD + rl * DCB_RLD + pc + 1];
+            const size_t widx = (((size_t)s * B + rg) * DCB_KS + kp) * H + un;
             if (p.ll) {
-              uint64_t* L = reinterpret_cast<uint64_t*>(p.G2) + ((size_t)s * B + rg) * H + ug * 16 + pc;
-              const uint64_t st = (uint64_t)(ep | (unsigned)s) << 32;
               // two stamped words = 16 contiguous, 16-byte-aligned bytes: one store (each 8-byte word lies inside one 32-byte
-              // sector, which is what its reader's 8-byte load observes as a unit — DC_STAMP_PAIR=0 restores two 8-byte atomics)
-              if (DC_STAMP_PAIR) {
-                rc_store16f(reinterpret_cast<float*>(L), f32x4{v0, __builtin_bit_cast(float, (unsigned)(st >> 32)), v1, __builtin_bit_cast(float, (unsigned)(st >> 32))});
-              } else {
-                __hip_atomic_store(L, st | __builtin_bit_cast(unsigned, v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(L + 1, st | __builtin_bit_cast(unsigned, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
+              // sector, which is what its reader's 8-byte load observes as a unit)
+              const unsigned st = ep | (unsigned)s;
+              rc_store16f(reinterpret_cast<float*>(reinterpret_cast<uint64_t*>(p.G2) + widx), f32x4{v0, __builtin_bit_cast(float, st), v1, __builtin_bit_cast(float, st)});
             } else {
               union { float f[2]; uint64_t q; } pk; pk.f[0] = v0; pk.f[1] = v1;
-              __hip_atomic_store(reinterpret_cast<uint64_t*>(p.G2 + ((size_t)s * B + rg) * H + ug * 16 + pc), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(reinterpret_cast<uint64_t*>(p.G2 + widx), pk.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
@@ -865,22 +894,36 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       DCB_TS(1);
       float grec[2] = {0.f, 0.f};
       if (s > 0 && p.ll) {
-        const uint64_t* L = reinterpret_cast<const uint64_t*>(p.G2) + ((size_t)s * B + b) * H;
+        const uint64_t* L = reinterpret_cast<const uint64_t*>(p.G2) + ((size_t)s * B + b) * DCB_KS * H;
         const uint64_t* l0 = L + (tid < H ? tid : 0);
         const uint64_t* l1 = L + (tid + 256 < H ? tid + 256 : 0);
         const unsigned want = ep | (unsigned)s;
-        uint64_t w0, w1;
+        uint64_t w0[DCB_KS], w1[DCB_KS];
         unsigned spin = 0;
         for (;;) {
-          w0 = __hip_atomic_load(l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          w1 = __hip_atomic_load(l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (__all((unsigned)(w0 >> 32) == want && (unsigned)(w1 >> 32) == want)) break;
+          bool ok = true;
+#pragma unroll
+          for (int kk2 = 0; kk2 < DCB_KS; ++kk2) {
+            w0[kk2] = __hip_atomic_load(l0 + (size_t)kk2 * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1[kk2] = __hip_atomic_load(l1 + (size_t)kk2 * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int kk2 = 0; kk2 < DCB_KS; ++kk2) ok = ok && (unsigned)(w0[kk2] >> 32) == want && (unsigned)(w1[kk2] >> 32) == want;
+          if (__all(ok)) break;
           if (rc_give_up(p.bar, spin)) break;
         }
-        grec[0] = __builtin_bit_cast(float, (unsigned)w0); grec[1] = __builtin_bit_cast(float, (unsigned)w1);
+        // (K order, whoever arrived last)
+        grec[0] = (__builtin_bit_cast(float, (unsigned)w0[0]) + __builtin_bit_cast(float, (unsigned)w0[1])) + (__builtin_bit_cast(float, (unsigned)w0[2]) + __builtin_bit_cast(float, (unsigned)w0[3]));
+        grec[1] = (__builtin_bit_cast(float, (unsigned)w1[0]) + __builtin_bit_cast(float, (unsigned)w1[1])) + (__builtin_bit_cast(float, (unsigned)w1[2]) + __builtin_bit_cast(float, (unsigned)w1[3]));
       } else if (s > 0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { const int u = tid + 256 * q; if (u < H) grec[q] = p.G2[((size_t)s * B + b) * H + u]; }
+        for (int q = 0; q < 2; ++q) {
+          const int u = tid + 256 * q;
+          if (u < H) {
+            const float* gp = p.G2 + ((size_t)s * B + b) * DCB_KS * H + u;
+            grec[q] = (gp[0] + gp[H]) + (gp[2 * (size_t)H] + gp[3 * (size_t)H]);
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
