@@ -203,9 +203,32 @@ __device__ __forceinline__ void rc_master_loop(unsigned* flags, unsigned* releas
     if (threadIdx.x < 8) __hip_atomic_store(release + threadIdx.x * 32, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+// XCD-aware roles of a (unit groups x row parts) grid (round 5).  Workgroup L = blockIdx.y * gridDim.x + blockIdx.x runs on XCD L % 8
+// and every XCD fetches what its workgroups read into its own L2.  With the unit group as the fast index every XCD hosts workgroups
+// of every row part and pulls the WHOLE h_{t-1} / dG panel across the fabric each step (eight copies of it); here a row part lives on
+// 8 / MS XCDs: part = (L % 8) / (8 / MS), unit group = (L / 8) (8 / MS) + L % (8 / MS).  The last workgroup of the grid is the barrier
+// master, workgroups left over leave at once.  Falls back to the plain (blockIdx.x, blockIdx.y) roles where the numbers do not fit.
+struct RcRole { int vx, vy; bool master, idle; };
+__device__ __forceinline__ RcRole rc_role(int nwx, int has_master) {
+  const int ms = (int)gridDim.y, total = (int)(gridDim.x * gridDim.y), L = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  RcRole r;
+  const int per = ms <= 8 && (8 % ms) == 0 ? 8 / ms : 0;
+  if (per > 0 && ((nwx + per - 1) / per) * 8 <= total - (has_master ? 1 : 0)) {
+    const int x = L & 7, j = (L >> 3) * per + (x % per);
+    r.vy = x / per; r.vx = j;
+    r.master = has_master && L == total - 1;
+    r.idle = !r.master && (j >= nwx || L >= ((nwx + per - 1) / per) * 8);
+    if (r.master || r.idle) { r.vx = 0; r.vy = 0; }
+  } else {
+    r.vx = (int)blockIdx.x; r.vy = (int)blockIdx.y;
+    r.master = has_master && (int)blockIdx.x == nwx && blockIdx.y == 0;
+    r.idle = has_master && (int)blockIdx.x == nwx && blockIdx.y != 0;
+  }
+  return r;
+}
 __device__ __forceinline__ void rc_wait_release(const unsigned* release, unsigned step) {
   if (threadIdx.x < 64) {
-    const unsigned* r = release + (blockIdx.x & 7) * 32;
+    const unsigned* r = release + ((blockIdx.y * gridDim.x + blockIdx.x) & 7) * 32;      // the line of this workgroup's XCD
     unsigned spin = 0;
     while ((int)(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) { if (rc_give_up(const_cast<unsigned*>(release) - 256, spin)) break; }
     if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -226,20 +249,21 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
   float* red = rc_smem;                                            // [4 waves][ROWS][RED_LD]
   bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD);   // [ROWS][UW] this step's columns of h_t (16-byte aligned: ROWS % 16 == 0)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
-  const int u0 = blockIdx.x * UW, R = p.R, B = p.B, Bs = p.Bs;
+  const int nwx = (int)gridDim.x - (p.master ? 1 : 0);   // workers per row part
+  const RcRole role = rc_role(nwx, p.master);
+  const int vx = role.vx, vy = role.vy;
+  const int u0 = vx * UW, R = p.R, B = p.B, Bs = p.Bs;
   // rows: this workgroup owns panel rows [own_lo, own_lo + own) and computes [r0, r0 + ROWS) (a superset)
-  const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
+  const int own = RC_PAN_ROWS / gridDim.y, own_lo = vy * own;
   const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
   const int kw0 = wave * (STEPS * 32);                   // this wave's K range
   const int kq = (lane >> 4) * 8;
   constexpr int NP = STEPS / 2;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
-  const int nwx = (int)gridDim.x - (p.master ? 1 : 0), widx = blockIdx.y * nwx + blockIdx.x;   // workers per row, my flag
-  if (p.master && (int)blockIdx.x == nwx) {
-    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1 + p.epi);
-    return;
-  }
-  const int rot = blockIdx.x % NP;                       // workgroups start at different k: spreads the L2 channels
+  const int widx = vy * nwx + vx;                        // my flag
+  if (role.master) { rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1 + p.epi); return; }
+  if (role.idle) return;
+  const int rot = vx % NP;                               // workgroups start at different k: spreads the L2 channels
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
   // ---- resident weights: tile column g*16 + c  <->  gate (g*16+c) / UW, unit u0 + (g*16+c) % UW
@@ -380,7 +404,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     const bool it_on = tid < KG * own && it_rg < B;
     const bf16_t* it_src = hl + (it_rg - r0) * UW + it_j * 8;
     if (it_on) {
-      rc_store16(p.Pan + (size_t)t * pan_t + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, it_src);
+      rc_store16(p.Pan + (size_t)t * pan_t + ((size_t)(vx * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, it_src);
     }
     const bool more = t + 1 < p.T;
     if (more) {
@@ -448,7 +472,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     {
       const int it_j = tid / own, it_rg = own_lo + tid % own;
       if (tid < KG * own && it_rg < B)
-        rc_store16(p.PanM + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, hl + (it_rg - r0) * UW + it_j * 8);
+        rc_store16(p.PanM + ((size_t)(vx * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, hl + (it_rg - r0) * UW + it_j * 8);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -543,7 +567,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
       {
         const int it_j = tid / own, it_rg = own_lo + tid % own;
         if (tid < KG * own && it_rg < B)
-          rc_store16(p.PanD + ((size_t)(blockIdx.x * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, hl + (it_rg - r0) * UW + it_j * 8);
+          rc_store16(p.PanD + ((size_t)(vx * KG + it_j) * RC_PAN_ROWS + it_rg) * 8, hl + (it_rg - r0) * UW + it_j * 8);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -640,18 +664,19 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD + (4 - (4 * ROWS * RED_LD) % 4) % 4);   // [ROWS][4][UW]
   bf16x8* wl = reinterpret_cast<bf16x8*>(hl + (size_t)ROWS * 4 * UW);     // [KL][CG][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
-  const int u0 = blockIdx.x * UW, R = p.R, B = p.B, Bs = p.Bs, K = 4 * R;
-  const int own = RC_PAN_ROWS / gridDim.y, own_lo = blockIdx.y * own;
+  const int nwx = (int)gridDim.x - (p.master ? 1 : 0);
+  const RcRole role = rc_role(nwx, p.master);
+  const int vx = role.vx, vy = role.vy;
+  const int u0 = vx * UW, R = p.R, B = p.B, Bs = p.Bs, K = 4 * R;
+  const int own = RC_PAN_ROWS / gridDim.y, own_lo = vy * own;
   const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
   const int kw0 = wave * (STEPS * 32);
   const int kq = (lane >> 4) * 8;
   const unsigned ep = rc_epoch_read(p.epoch), fb = ep << 7;
-  const int nwx = (int)gridDim.x - (p.master ? 1 : 0), widx = blockIdx.y * nwx + blockIdx.x;
-  if (p.master && (int)blockIdx.x == nwx) {
-    if (blockIdx.y == 0) rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1);
-    return;
-  }
-  const int rot = blockIdx.x % NP;
+  const int widx = vy * nwx + vx;
+  if (role.master) { rc_master_loop(p.bar, p.bar + 256, nwx * (int)gridDim.y, fb, p.T - 1); return; }
+  if (role.idle) return;
+  const int rot = vx % NP;
   auto k_of = [&](int pr, int hh) { int prr = pr + rot; prr = prr >= NP ? prr - NP : prr; return kw0 + (prr * 2 + hh) * 32; };
 
   bf16x8 wb[KREG > 0 ? KREG : 1][CG];
