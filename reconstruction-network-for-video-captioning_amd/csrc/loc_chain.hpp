@@ -289,7 +289,10 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
   float* red = lc_smem;                                                       // [4 waves][ROWS][RED_LD]; reused as the [ROWS][A + 4] Whr tile
   bf16_t* hl = reinterpret_cast<bf16_t*>(lc_smem + 4 * ROWS * RED_LD);        // [ROWS][UW]
   bf16x8* wih = reinterpret_cast<bf16x8*>(lc_smem + 4 * ROWS * RED_LD + ROWS * UW / 2);   // [4 waves][SX][CG][64] B fragments of W_ih
-  const int ug = wg % p.NG, part = wg / p.NG;
+  // XCD-aware roles (rec_chain.hpp: rc_role): workgroup i runs on XCD i % 8; with two row parts, part = (i % 8) / 4 — the four XCDs of a
+  // part fetch its rows of the hr / x panels only (with the unit group as the fast index every XCD pulled both halves every step)
+  const bool xmap = p.MS == 2 && (p.NG & 3) == 0;
+  const int ug = xmap ? (wg >> 3) * 4 + (wg & 3) : wg % p.NG, part = xmap ? (wg & 7) >> 2 : wg / p.NG;
   const int u0 = ug * UW;
   const int own = RC_PAN_ROWS / p.MS, own_lo = part * own;
   const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
@@ -644,7 +647,13 @@ __device__ __forceinline__ void lcb_xsplit_role(const LocChainBwdArgs& p, float*
   constexpr int CG = 4, RB = 2, UWX = 16 * CG, ROWS = RB * 16, RED_LD = UWX + 1, NP = XS / 2, OWN = ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int R = p.R, B = p.B, H = p.H, F = p.F, K = 4 * R;
-  const int xg = xi % p.NGX, rest = xi / p.NGX, part = rest % p.MSX, kp = rest / p.MSX;
+  // XCD-aware roles: X' workgroup xi runs on XCD (NU + xi) % 8.  With four row parts a part lives on two XCDs, which share its
+  // NGX KSX tiles: each then fetches a quarter of the rows and about half of K of the gate-gradient panel (1.4 MB at R = 1536)
+  // instead of all of it, every step
+  const int NUx = p.NGU * p.MSU, per2 = p.NGX * p.KSX;
+  const bool xmap = p.MSX == 4 && (NUx & 7) == 0 && (per2 & 1) == 0 && p.NGX * p.MSX * p.KSX == 4 * per2;
+  const int xidx = xmap ? (xi & 1) * (per2 >> 1) + (xi >> 3) : 0;
+  const int xg = xmap ? xidx % p.NGX : xi % p.NGX, rest = xi / p.NGX, part = xmap ? (xi & 7) >> 1 : rest % p.MSX, kp = xmap ? xidx / p.NGX : rest / p.MSX;
   const int j0 = xg * UWX, own_lo = part * OWN;
   const int r0 = own_lo < RC_PAN_ROWS - ROWS ? own_lo : RC_PAN_ROWS - ROWS;
   const int kq = (lane >> 4) * 8, kw0 = kp * (XS * 128) + wave * (XS * 32);
