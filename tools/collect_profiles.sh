@@ -58,6 +58,8 @@ RN_GEMM_GROUP=0 python3 bench.py $x > $O/bench_c2_no_grouped_launches.json 2>/de
 RN_DEC_LOCAL_WH=0 python3 bench.py $x > $O/bench_c2_attention_projection_in_phase_A.json 2>/dev/null
 RN_ADAM_EPILOGUE=0 python3 bench.py $x > $O/bench_c2_adam_kernel_instead_of_epilogue.json 2>/dev/null
 RN_WAIT_CHAIN=0 python3 bench.py $x > $O/bench_c2_no_residency_waits.json 2>/dev/null
+RN_DEC_PARTIAL=0 python3 bench.py $x > $O/bench_c2_relayed_barrier_in_decoder_chains.json 2>/dev/null
+RN_DEC_ROWPARTS=0 python3 bench.py $x > $O/bench_c2_forward_phase_A_all_rows.json 2>/dev/null
 # the data-parallel step at ONE rank (no byte crosses xGMI): one captured graph with the collectives inside / three graphs
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --force-allreduce $x > $O/bench_c2_dp_one_rank_one_graph.json 2>/dev/null
 RN_DP_ONE_GRAPH=0 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --force-allreduce $x > $O/bench_c2_dp_one_rank_three_graphs.json 2>/dev/null
