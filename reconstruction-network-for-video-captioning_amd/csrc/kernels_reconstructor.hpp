@@ -225,16 +225,30 @@ __global__ void bcast_drop_bwd_kernel(const float* __restrict__ dmpd, float* __r
 }
 // Global reconstructor, d loss / d decoder states from the merged input-side product tmp[t,b,0:2H) = dG_t . W_ih:
 //   dmp[b,h] = sum_t tmp[t,b,H+h] * dropmask(t,b,h) ;  dhid[t,b,h] = tmp[t,b,h] + c * dmp[b,h]     (c = caption_max_len / T^2)
-__global__ void global_dhid_kernel(const float* __restrict__ tmp, float* __restrict__ dhid, int T, int B, int H, float c, DropDesc dd) {
+// Block = 64 consecutive (b, h) x 4 slices of t: a thread's loads are independent and issued eight at a time (the one-thread-per-(b, h)
+// form walked its 2 T strided loads one by one on four waves per CU: 16.6 us in front of the decoder's BPTT; this one 5)
+__global__ __launch_bounds__(256) void global_dhid_kernel(const float* __restrict__ tmp, float* __restrict__ dhid, int T, int B, int H, float c, DropDesc dd) {
+  __shared__ float part[4][64];
   const uint32_t key = drop_key(dd);
   const size_t n = (size_t)B * H;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int h = (int)(i % H), b = (int)(i / H);
-    const float* row = tmp + (size_t)b * 2 * H + h;
-    float s = 0.f;
-    for (int t = 0; t < T; ++t) s += row[(size_t)t * B * 2 * H + H] * drop_at(dd, key, t, b, H, h);
-    s *= c;
-    for (int t = 0; t < T; ++t) dhid[(size_t)t * n + i] = row[(size_t)t * B * 2 * H] + s;
+  const int q = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool on = i < n;
+  const int h = on ? (int)(i % H) : 0, b = on ? (int)(i / H) : 0;
+  const float* row = tmp + (size_t)b * 2 * H + h;
+  const int tq = (T + 3) >> 2, t0 = q * tq, t1 = t0 + tq < T ? t0 + tq : T;
+  float s = 0.f;
+  if (on) {
+#pragma unroll 8
+    for (int t = t0; t < t1; ++t) s += row[(size_t)t * B * 2 * H + H] * drop_at(dd, key, t, b, H, h);
+  }
+  part[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  // (slice order: the sum does not depend on the schedule)
+  s = ((part[0][threadIdx.x & 63] + part[1][threadIdx.x & 63]) + (part[2][threadIdx.x & 63] + part[3][threadIdx.x & 63])) * c;
+  if (on) {
+#pragma unroll 8
+    for (int t = t0; t < t1; ++t) dhid[(size_t)t * n + i] = row[(size_t)t * B * 2 * H] + s;
   }
 }
 // Y[t*n + i] (+)= c * x[i]

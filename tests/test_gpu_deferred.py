@@ -107,7 +107,8 @@ def test_deferred_update_equals_the_immediate_one_once_flushed(lr, mode, lengths
             # (B = 120 on the fp32 path: the per-step backward sums d Uv over frame chunks with float atomics — reproducible to rounding)
             assert _same(d0[k], d1[k], k, shape != "row_groups"), ("decoder", k, float((d0[k] - d1[k]).abs().max()))
         for k in r0:
-            assert _same(r0[k], r1[k], k, exact), ("reconstructor", k, float((r0[k] - r1[k]).abs().max()))
+            # (row groups: the reconstructor reads the decoder's states, which are reproducible to rounding only there — see above)
+            assert _same(r0[k], r1[k], k, exact and shape != "row_groups"), ("reconstructor", k, float((r0[k] - r1[k]).abs().max()))
         assert any(not torch.equal(r1["p." + k].cpu(), v) for k, v in recP.items())
         return
     # large updates: rounding differences of the atomically summed gradients (biases, embedding rows) are fed back through the
