@@ -42,8 +42,11 @@ for depth in (1, 2, 4):
     ring = eng.step_ring()
     spans = [b - a for a, b in ring]; gaps = [ring[i + 1][0] - ring[i][1] for i in range(len(ring) - 1)]
     print("at most %d queued     : %.4f ms per step | spans %s | between steps %s" % (depth, ms, " ".join("%.1f" % x for x in spans), " ".join("%.1f" % x for x in gaps)))
-# k steps per graph
-for k in (2, 4):
+# k steps per graph — only on request (`... global multi`): capturing several steps into ONE graph records the handle's fork / join events
+# more than once inside a capture, and about one run in eight of this section then aborts inside the HIP runtime's heap (free():
+# invalid pointer in hipGraphLaunch or at exit; 2 of 16 runs with and without the vendor-library products) — the pattern round 4 found
+# with the profile brackets.  The product captures ONE step per graph.
+for k in ((2, 4) if len(sys.argv) > 2 and sys.argv[2] == "multi" else ()):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for _ in range(k):
