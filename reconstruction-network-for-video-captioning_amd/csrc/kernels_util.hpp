@@ -4,6 +4,12 @@
 // =============================================================================================
 // small utilities
 // =============================================================================================
+// one 100 MHz wall-clock stamp (recnet_read_stamps: start / end of a phase that is not one grouped launch)
+__global__ void stamp_u64_kernel(unsigned long long* slot, int take_max) {
+  const unsigned long long t = wall_clock64();
+  if (take_max) __hip_atomic_fetch_max(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ void set_u32_kernel(uint32_t* p, uint32_t v) { *p = v; }
 // Data parallel: a rank whose chain kernel gave up (rec_chain.hpp: the poison word is NaN, else 0) marks one element of the
 // gradient bucket that is all-reduced LAST; after the SUM every rank sees the NaN and raises its own poison word, so all

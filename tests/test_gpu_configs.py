@@ -179,8 +179,13 @@ FULL_LR = 1e-3
 MOVE_TOL = 8e-2
 
 
-@pytest.mark.parametrize("name", ["C2", "C3"])
-def test_replayed_default_bench_mode_against_the_oracle_at_full_size(name):
+@pytest.mark.parametrize("name", ["C2", "C3", "C2-adam-epilogue"])
+def test_replayed_default_bench_mode_against_the_oracle_at_full_size(name, monkeypatch):
+    # C2 (default): the pending d W_hh product goes through the vendor library and the optimiser kernel (RN_PENDING_LT, round 5);
+    # "C2-adam-epilogue": the same step with the grouped launch + Adam epilogue the smaller shapes and the local reconstructor keep
+    if name == "C2-adam-epilogue":
+        monkeypatch.setenv("RN_PENDING_LT", "0")
+        name = "C2"
     kind, B, F, D, Bg, off = CONFIGS[name]
     torch.set_num_threads(min(32, torch.get_num_threads() * 4))
     decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 31)

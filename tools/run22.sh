@@ -1,6 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-ROUNDS=6 bash tools/ab.sh "" "RN_LIB_VARIANT=base" "RN_LIB_VARIANT=" 2>&1 | cut -c1-150
-ROUNDS=3 bash tools/ab.sh "--rec local" "RN_LIB_VARIANT=base" "RN_LIB_VARIANT=" 2>&1 | cut -c1-150
-ROUNDS=3 bash tools/ab.sh "--rec none" "RN_LIB_VARIANT=base" "RN_LIB_VARIANT=" 2>&1 | cut -c1-150
-timeout 900 python3 -m pytest tests/test_gpu_parity.py -q -x 2>&1 | tail -2
+timeout 2400 python3 -m pytest tests/test_gpu_deferred.py tests/test_gpu_knobs.py tests/test_gpu_faults.py tests/test_gpu_configs.py tests/test_gpu_parity.py -q -x 2>&1 | tail -4
+ROUNDS=5 bash tools/ab.sh "" "RN_PENDING_LT=0" "RN_PENDING_LT=1" 2>&1 | cut -c1-330
