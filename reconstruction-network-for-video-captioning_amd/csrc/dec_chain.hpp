@@ -12,6 +12,8 @@
 //            bytes), its rows of Uv, c_{t-1}; reads its 4H + A pre-activations, computes scores, context, gates and the
 //            cell, publishes h_t (bf16) for phase A of the next step and writes everything the backward needs.
 // A workgroup takes part in both phases (grid = max(NA, B) <= CU count, one workgroup per CU).
+// Round 5 (template parameter RP, the default): phase A is tiled as 64 columns x one of 4 row parts (28 captions) instead of 16 columns x
+// all rows, the roles are laid out XCD-aware, and the B -> A hand-over stays inside a row part (see DCF_PARTS / DCF_NA below).
 // Limits: bf16 path, H % 8 == 0, H <= 512, F <= 32, A <= 128, (4H + A) % 16 == 0, B <= 112.
 #pragma once
 #ifndef DC_STAMP_PAIR
