@@ -122,8 +122,6 @@ struct recnet_handle {
   int dp_overlap = 0, side_open = 0;   // recnet_set_dp_overlap: part 1 of the data-parallel step leaves the side stream's weight-gradient products unjoined (recnet_join_side)
   int hoist_fork_recorded = 0;   // dec_fwd_chain recorded the fork events of hoist_side_work itself, in front of the chain launch
   int rec_loss_defer = 0, rec_loss_late = 0;   // fused step: the reconstructor's loss scalars are formed beside the BPTT (rec_loss_scalars) instead of between its two chains
-  int pending_lt_now = 0, pending_lt_step = 0;   // split update: the pending d W_hh product goes through the vendor library (rec_pending_update) / did so in this step
-  int lt_next = 0;         // the next gemm() call may go to the vendor library (it runs alone on the chip): host_common.inc
   int rec_norm_late = 0;   // mode 2: the norm of the pending-updated W_hh is joined in front of the loss scalars (ev[21]), not in front of the chain
   int side_tail_open = 0;  // decoder-only: dec_bwd_out recorded the BPTT's join in front of the rest of the side branch (ev[18] covers the rest)
   int total_late = 0;      // the total-loss scalar is formed on the side stream behind the BPTT's fork (fwd_bwd_impl)

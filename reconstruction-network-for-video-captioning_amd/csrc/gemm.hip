@@ -298,64 +298,3 @@ int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float
   else launch_group_one<true, true>(g, blocks, st);
   return 0;
 }
-
-// ---------------------------------------------------------------------------------------------- vendor library, plain products only
-// hipBLASLt for the PLAIN batched products (bf16 operands, fp32 result, optional bias row, optional accumulate; nothing fused behind
-// them): the library's 256-row kernels with a tile count fitted to the chip run the step's large shapes 1.2 - 1.7 x faster than
-// gemm_lds_kernel's 128 x 128 tiles (tools/micro/blaslt_f32out.hip), and a 256-row tile of our own lost to
-// tile-count quantisation.  Every product that has something fused into it (Adam / MSE epilogue, in-launch split sums, the chains'
-// recurrent steps, grouped queues) stays on the hand-written kernels.  Row-major C[M][N] is the column-major N x M matrix C^T:
-//   C^T = op(B') . op(A')   with B' / A' our operands seen column-major (their leading dimensions unchanged).
-#include <hipblaslt/hipblaslt.h>
-#include <map>
-#include <tuple>
-namespace {
-struct LtPlan { hipblasLtMatmulDesc_t d = nullptr; hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr; hipblasLtMatmulAlgo_t algo; size_t ws = 0; bool ok = false; };
-hipblasLtHandle_t lt_handle() {
-  static hipblasLtHandle_t hnd = nullptr; static bool tried = false;
-  if (!tried) { tried = true; if (hipblasLtCreate(&hnd) != HIPBLAS_STATUS_SUCCESS) hnd = nullptr; }
-  return hnd;
-}
-}  // namespace
-// true: enqueued.  false: not applicable (no handle / no algorithm for the shape within `ws_bytes`): the caller runs its own kernel.
-bool rn_blaslt_gemm(const void* A, int a_col, int lda, const void* B, int b_col, int ldb, float* C, int ldc, const float* bias,
-                    int M, int N, int K, float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-  hipblasLtHandle_t lt = lt_handle();
-  if (!lt) return false;
-  typedef std::tuple<int, int, int, int, int, int, int, int, int> Key;
-  static std::map<Key, LtPlan> plans;
-  const Key key(M, N, K, a_col, b_col, lda, ldb, ldc, bias ? 1 : 0);
-  auto it = plans.find(key);
-  if (it == plans.end()) {
-    LtPlan pl;
-    bool ok = hipblasLtMatmulDescCreate(&pl.d, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
-    const hipblasOperation_t ta = b_col ? HIPBLAS_OP_N : HIPBLAS_OP_T, tb = a_col ? HIPBLAS_OP_T : HIPBLAS_OP_N;
-    ok = ok && hipblasLtMatmulDescSetAttribute(pl.d, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatmulDescSetAttribute(pl.d, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)) == HIPBLAS_STATUS_SUCCESS;
-    if (ok && bias) {
-      const hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS; const hipDataType bt = HIP_R_32F;
-      ok = hipblasLtMatmulDescSetAttribute(pl.d, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep)) == HIPBLAS_STATUS_SUCCESS &&
-           hipblasLtMatmulDescSetAttribute(pl.d, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)) == HIPBLAS_STATUS_SUCCESS &&
-           hipblasLtMatmulDescSetAttribute(pl.d, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS;
-    }
-    ok = ok && hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, b_col ? N : K, b_col ? K : N, ldb) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, a_col ? M : K, a_col ? K : M, lda) == HIPBLAS_STATUS_SUCCESS;
-    ok = ok && hipblasLtMatrixLayoutCreate(&pl.lc, HIP_R_32F, N, M, ldc) == HIPBLAS_STATUS_SUCCESS;
-    if (ok) {
-      hipblasLtMatmulPreference_t pref = nullptr;
-      ok = hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS &&
-           hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes, sizeof(ws_bytes)) == HIPBLAS_STATUS_SUCCESS;
-      hipblasLtMatmulHeuristicResult_t hr; int nh = 0;
-      ok = ok && hipblasLtMatmulAlgoGetHeuristic(lt, pl.d, pl.la, pl.lb, pl.lc, pl.lc, pref, 1, &hr, &nh) == HIPBLAS_STATUS_SUCCESS && nh > 0 && hr.workspaceSize <= ws_bytes;
-      if (ok) { pl.algo = hr.algo; pl.ws = hr.workspaceSize; }
-      if (pref) hipblasLtMatmulPreferenceDestroy(pref);
-    }
-    pl.ok = ok;
-    it = plans.emplace(key, pl).first;
-  }
-  LtPlan& pl = it->second;
-  if (!pl.ok) return false;
-  if (bias && hipblasLtMatmulDescSetAttribute(pl.d, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
-  const float beta = accumulate ? 1.f : 0.f;
-  return hipblasLtMatmul(lt, pl.d, &alpha, B, pl.la, A, pl.lb, &beta, C, pl.lc, C, pl.lc, &pl.algo, ws, ws_bytes, st) == HIPBLAS_STATUS_SUCCESS;
-}

@@ -19,6 +19,9 @@
 #include "gemm.hpp"
 #include <type_traits>
 
+#ifndef GL_TR_ASM
+#define GL_TR_ASM 1      // col-operand fragments through asm transposing reads (gl_frag_tr_asm below); 0: the builtin
+#endif
 #define GL_STAGE_BYTES 32768   // A image 16 KiB + B image 16 KiB
 #ifndef RC_ACQUIRE_INV
 #define RC_ACQUIRE_INV 0       // 1: cross-check build with the conventional acquire fences (rec_chain.hpp; Makefile: acqinv)
@@ -106,6 +109,35 @@ __device__ __forceinline__ bf16x8 gl_frag(const char* img, int row /*first of th
   }
 }
 
+// Col-operand fragments WITHOUT the transposing-read builtin (round 6).  hipcc's wait-count pass treats an LDS access that carries a
+// memory operand as a possible reader of every LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of it; ordinary ds_read_b128
+// fragment loads lose their memory operand on the way and are left alone, the ds_read_tr16_b64 builtin keeps it — so every k-tile of
+// a product with a col operand (the weight-gradient form dY^T . X, and dY . W) waited for the DMAs of the NEXT stage it had just
+// requested: no prefetch at all (the 1.3 - 1.6 x of the TN rows of r05_gemm_cold_vs_hipblaslt.txt).  The asm form is invisible to
+// that pass; its completion is waited for explicitly (gl_tr_wait: lgkmcnt(0) with the fragment halves as operands, so no consumer
+// can move above it) before the halves are put together.
+struct GlTrFrag { bf16x4 lo, hi; };
+__device__ __forceinline__ GlTrFrag gl_frag_tr_asm(const char* img, int row, int ks, int lane) {
+  const int li = lane & 15, q = li >> 2, pp = li & 3, g = lane >> 4;
+  const int kk = ks + 8 * g + q;
+  const int c = (row >> 3) + (pp >> 1);
+  const unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(img + kk * 256 + ((c ^ gl_col_swz(kk)) << 4) + ((pp & 1) << 3));
+  GlTrFrag f;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f.hi) : "v"(a) : "memory");
+  return f;
+}
+template <int N> __device__ __forceinline__ void gl_tr_wait(GlTrFrag (&f)[N]) {
+  static_assert(N == 3 || N == 4, "gl_tr_wait: operand list");
+  if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi), "+v"(f[3].lo), "+v"(f[3].hi) :: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[2].lo), "+v"(f[2].hi) :: "memory");
+}
+__device__ __forceinline__ bf16x8 gl_tr_join(const GlTrFrag& f) {
+  bf16x8 r;
+  r[0] = f.lo[0]; r[1] = f.lo[1]; r[2] = f.lo[2]; r[3] = f.lo[3]; r[4] = f.hi[0]; r[5] = f.hi[1]; r[6] = f.hi[2]; r[7] = f.hi[3];
+  return r;
+}
+
 // GL_PROBE (tools/micro/gemm_probe.hip only): shader-clock stamps around the segments of the K loop and the epilogue, per wave
 #ifdef GL_PROBE
 __device__ unsigned long long gl_probe_buf[64 * 8 * 8];
@@ -180,10 +212,34 @@ __device__ __forceinline__ void gemm_lds_tile(const ArgsT& p, const int bx, cons
 #pragma unroll
     for (int ks = 0; ks < 64; ks += 32) {
       bf16x8 fa[4], fb[NPB];
+#if GL_TR_ASM
+      GlTrFrag ta[4], tb[NPB];
+      if constexpr (ACOL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ta[i] = gl_frag_tr_asm(cur, wm + i * 16, ks, lane);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = gl_frag<false>(cur, wm + i * 16, ks, lane);
+      }
+      if constexpr (BCOL) {
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) tb[j] = gl_frag_tr_asm(cur + 16384, wn + j * 16, ks, lane);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) fb[j] = gl_frag<false>(cur + 16384, wn + j * 16, ks, lane);
+      }
+      if constexpr (ACOL) { gl_tr_wait(ta);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = gl_tr_join(ta[i]); }
+      if constexpr (BCOL) { gl_tr_wait(tb);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) fb[j] = gl_tr_join(tb[j]); }
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = gl_frag<ACOL>(cur, wm + i * 16, ks, lane);
 #pragma unroll
       for (int j = 0; j < NPB; ++j) fb[j] = gl_frag<BCOL>(cur + 16384, wn + j * 16, ks, lane);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll

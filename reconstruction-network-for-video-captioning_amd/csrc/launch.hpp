@@ -27,9 +27,6 @@ int rn_effective_splitk(int prec, int K, int splitk);
 // run the slab reduction (otherwise the caller's fused consumer sums ws[z][M][N] itself).
 // MSE epilogue of the bf16 DMA kernel (GemmArgs::mse_*): row = s * B + b against ref[b * bstride + s * sstride + col]
 struct RnMse { const float* ref; float* part; size_t bstride, sstride; int B; float gcoef, lp; };
-// vendor library for plain bf16 products (gemm.hip); false: not applicable, run the own kernel
-bool rn_blaslt_gemm(const void* A, int a_col, int lda, const void* B, int b_col, int ldb, float* C, int ldc, const float* bias,
-                    int M, int N, int K, float alpha, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, const void* B, int b_bf16, int b_col,
                     int ldb, float* C, int ldc, const float* bias, int M, int N, int K, float alpha,
                     int accumulate, int splitk, float* ws, int reduce_after, hipStream_t st, int tag = 0, int c_bf16 = 0,

@@ -179,12 +179,13 @@ FULL_LR = 1e-3
 MOVE_TOL = 8e-2
 
 
-@pytest.mark.parametrize("name", ["C2", "C3", "C2-adam-epilogue"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C2-optimiser-kernel"])
 def test_replayed_default_bench_mode_against_the_oracle_at_full_size(name, monkeypatch):
-    # C2 (default): the pending d W_hh product goes through the vendor library and the optimiser kernel (RN_PENDING_LT, round 5);
-    # "C2-adam-epilogue": the same step with the grouped launch + Adam epilogue the smaller shapes and the local reconstructor keep
-    if name == "C2-adam-epilogue":
-        monkeypatch.setenv("RN_PENDING_LT", "0")
+    # C2 / C3 (default): the pending d W_hh product is a grouped launch of gemm_lds.hpp with the Adam update in its epilogue;
+    # "C2-optimiser-kernel": the same step with the plain product and the optimiser kernel behind it (RN_ADAM_EPILOGUE=0).
+    # Round 6: every product of these steps runs on the hand-written kernels (the vendor library of round 5 is gone).
+    if name == "C2-optimiser-kernel":
+        monkeypatch.setenv("RN_ADAM_EPILOGUE", "0")
         name = "C2"
     kind, B, F, D, Bg, off = CONFIGS[name]
     torch.set_num_threads(min(32, torch.get_num_threads() * 4))

@@ -2,9 +2,8 @@
 the epilogue of the pending d W_hh product (RN_ADAM_EPILOGUE), the decoder forward chain with the attention projection formed by
 the caption's own workgroup (RN_DEC_LOCAL_WH), the residency waits of the side branches (RN_WAIT_CHAIN) and the MSE + d loss / d out
 of the local reconstructor's output layer in that product's epilogue (RN_MSE_EPILOGUE); round 5: the decoder chains' hand-over
-inside a row part (RN_DEC_PARTIAL), the forward chain's phase A tiled by row parts (RN_DEC_ROWPARTS) and the vendor library for the
-plain products that run alone on the chip (RN_BLASLT; the small test shape stays below its size threshold: tests/test_gpu_configs.py holds
-the full-size steps, where it applies, against the oracle).  Every switch changes
+inside a row part (RN_DEC_PARTIAL) and the forward chain's phase A tiled by row parts (RN_DEC_ROWPARTS).  (Round 6: the vendor-library switches of
+round 5 are gone with the library — every product runs on the hand-written kernels.)  Every switch changes
 the SCHEDULE or the summation order of a product, never the arithmetic: parameters after four replayed steps (split reconstructor
 update, flushed) agree to rounding with the default's, the losses of every step to 1e-4 (bf16 operands).
 Both optimisers run at a learning rate of 1e-2 here (at the defaults 1e-5 / 1e-6 four steps move a weight by less than
@@ -58,7 +57,7 @@ def _run(kind, env):
 
 
 @pytest.mark.parametrize("kind", ["global", "local"])
-@pytest.mark.parametrize("knob", ["RN_GEMM_GROUP", "RN_ADAM_EPILOGUE", "RN_DEC_LOCAL_WH", "RN_WAIT_CHAIN", "RN_MSE_EPILOGUE", "RN_DEC_PARTIAL", "RN_DEC_ROWPARTS", "RN_BLASLT"])
+@pytest.mark.parametrize("knob", ["RN_GEMM_GROUP", "RN_ADAM_EPILOGUE", "RN_DEC_LOCAL_WH", "RN_WAIT_CHAIN", "RN_MSE_EPILOGUE", "RN_DEC_PARTIAL", "RN_DEC_ROWPARTS"])
 def test_switch_off_equals_default(knob, kind):
     p0, l0 = _run(kind, {})
     p1, l1 = _run(kind, {knob: "0"})
