@@ -584,6 +584,12 @@ class GraphedStep:
             world = _dist.get_world_size(dp_step.group) if nccl else 1
             want_one = bool(int(_os.environ.get("RN_DP_ONE_GRAPH", "1" if world == 1 else "0")) and self.enc.is_cuda and
                             dp_step.transport.algo == "ring" and nccl)
+            if nccl and world > 1:
+                # rank 0's choice is everyone's (the environment is per rank; ranks that disagree about the form would
+                # hang in the agreement all-reduce below, which only the ranks that want one graph entered)
+                flag = torch.tensor([1 if want_one else 0], device=self.enc.device, dtype=torch.int32)
+                _dist.broadcast(flag, src=_dist.get_global_rank(dp_step.group, 0) if hasattr(_dist, "get_global_rank") else 0, group=dp_step.group)
+                want_one = bool(int(flag.item()))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up outside capture (lazy module loading, RCCL init)

@@ -146,6 +146,10 @@ struct recnet_handle {
   float* gws2 = nullptr; float* gws_cur = nullptr;   // the side stream's split-K slabs / the one gemm() uses now
   unsigned* gcnt = nullptr;      // tile counters of the grouped launches' in-launch split-K sums: one block of RN_GCNT_WORDS per slab workspace
   int gg_site = 0;               // the next grouped launch stamps its start / end into this slot (1..8) of the group stamps
+  // environment switches, read ONCE per handle in recnet_create (round 6: no getenv on any enqueue path; a test that flips one creates
+  // a new handle).  Each selects between two tested forms of one piece of the schedule, never the arithmetic (tests/test_gpu_knobs.py,
+  // tests/test_gpu_parity.py: _chain_variants).
+  struct RnSw { int wait_chain = 1, mse_epi = 1, adam_epi = 1, dec_lw = 1, dec_rp = 1, dec_partial = 1, dec_xcat = 1, rec_epi = 2, rec_wide = 1, persist_ms = 0, gemm_group = 1; } sw;
   int gg_slots = 0;              // workgroup slots the next grouped launches can expect (0 = whole chip): see host_common.inc
   int gemm_single_group = 0;     // set around a single product whose K slices are to be summed inside its launch (host_decoder.inc: the embedding branch)
   hipStream_t s2 = nullptr; hipEvent_t ev[24] = {}; int overlap = 1;
@@ -349,6 +353,13 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
   h->gemm_single_group = 0;
+  {
+    auto env = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    h->sw.wait_chain = env("RN_WAIT_CHAIN", 1); h->sw.mse_epi = env("RN_MSE_EPILOGUE", 1); h->sw.adam_epi = env("RN_ADAM_EPILOGUE", 1);
+    h->sw.dec_lw = env("RN_DEC_LOCAL_WH", 1); h->sw.dec_rp = env("RN_DEC_ROWPARTS", 1); h->sw.dec_partial = env("RN_DEC_PARTIAL", 1);
+    h->sw.dec_xcat = env("RN_DEC_XCAT", 1); h->sw.rec_epi = env("RN_REC_EPILOGUE", 2); h->sw.rec_wide = env("RN_REC_BWD_WIDE", 1);
+    h->sw.persist_ms = env("RN_PERSIST_MS", 0); h->sw.gemm_group = env("RN_GEMM_GROUP", 1);
+  }
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
   // equal size (at most RN_MAX_ROW_GROUPS of them) and every chain runs once per group, one launch after the other: a group is

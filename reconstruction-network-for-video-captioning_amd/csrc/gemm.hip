@@ -150,7 +150,7 @@ void rn_launch_gemm(int prec, const void* A, int a_bf16, int a_col, int lda, con
       }
       // both operands bf16 in memory: the DMA-staged ring kernel.  Chain launches (tag > 0) run ~1 block
       // per CU and want the deepest ring; batched GEMMs trade ring depth for 2 resident blocks per CU.
-      static int ns_chain = getenv("RN_GEMM_NS_CHAIN") ? atoi(getenv("RN_GEMM_NS_CHAIN")) : 4;
+      static const int ns_chain = 4;
       static int ns_batch = 2;
       const int ns = tag ? ns_chain : ns_batch;
       {
@@ -216,8 +216,7 @@ double list_makespan(const std::vector<std::pair<double, int>>& runs, int slots)
 
 int rn_launch_gemm_group(int a_col, int b_col, const RnGemmDesc* d, int n, float* ws, size_t ws_floats, unsigned* cnt, int cnt_words,
                          hipStream_t st, int slots_hint, const AdamShared* adam, unsigned long long* stamp) {
-  const int on = getenv("RN_GEMM_GROUP") ? atoi(getenv("RN_GEMM_GROUP")) : 1;      // (read per call: the tests flip it inside one process)
-  if (!on || n < 1 || n > GG_MAX) return 1;
+  if (n < 1 || n > GG_MAX) return 1;      // (RN_GEMM_GROUP=0 is a switch of the handle: host_common.inc)
   struct Prob { int idx, tiles, nkt, s; };
   std::vector<Prob> pr;
   for (int i = 0; i < n; ++i) {

@@ -76,7 +76,11 @@ class GradTransport:
         else:
             import contextlib
             ctx = contextlib.nullcontext()
-        if cuda and W <= 16 and dist.get_backend(self.group) != "gloo":
+        # RN_DP_STAGING=torch selects the torch form below on every backend (the HIP staging kernels have only ever
+        # run at world size 1 on hardware; both forms do the same arithmetic — tests/test_gpu_dp.py holds them bit for bit)
+        import os as _os
+        hip_staging = _os.environ.get("RN_DP_STAGING", "hip") != "torch"
+        if hip_staging and cuda and W <= 16 and dist.get_backend(self.group) != "gloo":
             # two HIP kernels around the collectives (csrc/kernels_util.hpp: dp_cast_kernel, dp_reduce_kernel) instead of W + 3 torch
             # launches: cast + stage, W-way fp32 sum in rank order + one rounding; the same arithmetic as the torch form below
             import ctypes as C

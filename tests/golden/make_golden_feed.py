@@ -3,6 +3,7 @@
 container) on seeded inputs.  Run:  python tests/golden/make_golden_feed.py"""
 import os
 import sys
+sys.dont_write_bytecode = True      # the reference tree under /root/reference stays untouched (no __pycache__ beside its modules)
 import types
 
 import numpy as np

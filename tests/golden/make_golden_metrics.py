@@ -6,6 +6,7 @@ import json
 import os
 import random
 import sys
+sys.dont_write_bytecode = True      # the reference tree under /root/reference stays untouched (no __pycache__ beside its modules)
 import types
 import warnings
 

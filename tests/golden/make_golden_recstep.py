@@ -9,6 +9,7 @@ stored: the per-step outputs and hidden states.  Plain arrays only.
 """
 import os
 import sys
+sys.dont_write_bytecode = True      # the reference tree under /root/reference stays untouched (no __pycache__ beside its modules)
 
 import numpy as np
 import torch
