@@ -227,12 +227,14 @@ __device__ __forceinline__ RcRole rc_role(int nwx, int has_master) {
   return r;
 }
 __device__ __forceinline__ void rc_wait_release(const unsigned* release, unsigned step) {
+#ifndef RC_PROBE_NO_BARRIER
   if (threadIdx.x < 64) {
     const unsigned* r = release + ((blockIdx.y * gridDim.x + blockIdx.x) & 7) * 32;      // the line of this workgroup's XCD
     unsigned spin = 0;
     while ((int)(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) < 0) { if (rc_give_up(const_cast<unsigned*>(release) - 256, spin)) break; }
     if (RC_ACQUIRE_INV) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
+#endif
   __syncthreads();
 }
 
@@ -244,10 +246,14 @@ __device__ __forceinline__ void rc_wait_release(const unsigned* release, unsigne
 // L2s) is what bounds the step: 7.6 us at 112 rows, 2.5 us at 64 (tools/micro/persist_probe.hip).
 template <int STEPS, int PF, int RB, int CG>
 __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
-  constexpr int UW = 4 * CG, ROWS = RB * 16, RED_LD = CG * 16 + 1, KG = UW / 8;
+  constexpr int UW = 4 * CG, ROWS = RB * 16, KG = UW / 8;
+  // K partials of the four waves, COLUMN-major (round 6): red[wave][col][RLD] — the four rows a lane holds of an accumulator fragment are
+  // contiguous, so a fragment is one ds_write_b128 (16 stores per wave instead of 64), and the cell threads' reads (lane = unit x 4 rows)
+  // fall on 64 different banks (4 ul + row mod 64)
+  constexpr int NCOL = CG * 16, RLD = ROWS + 4, RED_W = NCOL * RLD;
   extern __shared__ __attribute__((aligned(16))) float rc_smem[];
-  float* red = rc_smem;                                            // [4 waves][ROWS][RED_LD]
-  bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD);   // [ROWS][UW] this step's columns of h_t (16-byte aligned: ROWS % 16 == 0)
+  float* red = rc_smem;                                            // [4 waves][NCOL][RLD]
+  bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * RED_W);   // [ROWS][UW] this step's columns of h_t (16-byte aligned: ROWS % 16 == 0)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
   const int nwx = (int)gridDim.x - (p.master ? 1 : 0);   // workers per row part
   const RcRole role = rc_role(nwx, p.master);
@@ -280,14 +286,16 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
         wb[pr * 2 + hh][g] = (k + kq < R) ? *reinterpret_cast<const bf16x8*>(wrow + k) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       }
   }
-  // ---- this thread's cells: cell = tid + c*256 -> tile row cell / UW, unit u0 + cell % UW
+  // ---- this thread's cells: unit u0 + tid % UW, CPT CONSECUTIVE tile rows (tid / UW) CPT + c (round 6: the K partials of a unit's
+  // four rows are one 16-byte LDS read per gate and wave; cell = row * UW + unit as before, so cell / UW and cell % UW keep their meaning)
+#define RC_CELL(c) (((tid / UW) * CPT + (c)) * UW + tid % UW)
   constexpr int CPT = (ROWS * UW + 255) / 256;
   float xg[CPT][4], cpv[CPT];
   bool mine[CPT];
   float hsum[CPT];                                       // sum_t h_t of this thread's cells (the output layer wants the mean)
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
-    const int rg = r0 + (tid + c * 256) / UW;
+    const int rg = r0 + RC_CELL(c) / UW;
     mine[c] = rg >= own_lo && rg < own_lo + own && rg < B;
     cpv[c] = 0.f; hsum[c] = 0.f;
   }
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     const float* X = p.Xg + (size_t)t * Bs * 4 * R;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RC_CELL(c);
       const int row = mine[c] ? r0 + cell / UW : 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) xg[c][q] = X[(size_t)row * 4 * R + q * R + u0 + cell % UW];
@@ -361,32 +369,35 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      float* part = red + wave * (ROWS * RED_LD);
+      float* part = red + wave * RED_W;
       const int rr = (lane >> 4) * 4, cc = lane & 15;
 #pragma unroll
       for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int g = 0; g < CG; ++g)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + g * 16 + cc] = acc[i][g][r];
+        for (int g = 0; g < CG; ++g) *reinterpret_cast<f32x4*>(part + (g * 16 + cc) * RLD + i * 16 + rr) = acc[i][g];
       __syncthreads();
+    }
+    // ---- K partials of this thread's cells: per gate and wave the four rows are 16 contiguous bytes of the column-major buffer
+    static_assert(CPT == 4, "four consecutive rows per thread: one f32x4 per (gate, wave)");
+    f32x4 gsum[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gsum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t > 0) {
+      const float* rp = red + (tid % UW) * RLD + (tid / UW) * CPT;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) gsum[q] += *reinterpret_cast<const f32x4*>(rp + w * RED_W + q * UW * RLD);
     }
     // ---- cell pointwise for UW units x owned rows
     float hv[CPT], av[CPT][4];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RC_CELL(c);
       const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
       float g4[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v = xg[c][q];
-        if (t > 0) {
-#pragma unroll
-          for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + row * RED_LD + q * UW + ul];
-        }
-        g4[q] = v;
-      }
+      for (int q = 0; q < 4; ++q) g4[q] = xg[c][q] + gsum[q][c];
       if (p.gru) {
         const GruOut r = gru_point(g4[0], g4[1], g4[2], g4[3], cpv[c]);
         hv[c] = r.h; av[c][0] = r.r; av[c][1] = r.z; av[c][2] = r.n; av[c][3] = r.hn; cpv[c] = r.h;
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
 #ifndef RC_PROBE_SKIP_STORE
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RC_CELL(c);
       if (mine[c]) {
         const int row = r0 + cell / UW, u = u0 + cell % UW;
         const size_t o = (size_t)row * R + u;
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     const float sc = 1.0f / (float)p.T;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RC_CELL(c);
       if (mine[c]) {
         const int row = r0 + cell / UW, u = u0 + cell % UW;
         const float m = hsum[c] * sc;
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     const float sc = 1.0f / (float)p.T;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RC_CELL(c);
       if (cell < ROWS * UW) hl[cell] = (bf16_t)(hsum[c] * sc);
     }
     __syncthreads();
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
     float tg[CPT], ob[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RC_CELL(c);
       const int row = mine[c] ? r0 + cell / UW : 0, u = u0 + cell % UW;
       tg[c] = p.target[(size_t)row * R + u];
       ob[c] = p.obias[u];
@@ -523,23 +534,21 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
           }
         }
       }
-      float* part = red + wave * (ROWS * RED_LD);
+      float* part = red + wave * RED_W;
       const int rr = (lane >> 4) * 4, cc = lane & 15;
 #pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + cc] = acc[i][r];
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(part + cc * RLD + i * 16 + rr) = acc[i];
     }
     __syncthreads();
     float sq = 0.f;
     bf16_t gl[CPT];                       // this thread's cells of the scaled dout (operand copy)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RC_CELL(c);
       const int rowl = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
       float v = ob[c];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + rowl * RED_LD + ul];
+      for (int w = 0; w < 4; ++w) v += red[w * RED_W + ul * RLD + rowl];
       gl[c] = (bf16_t)0.f;
       if (mine[c]) {
         const float d = v - tg[c], g = p.gcoef * d;
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
       // ALL output columns against the W_o^T rows of its 16 hidden units
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
-        const int cell = tid + c * 256;
+        const int cell = RC_CELL(c);
         if (cell < ROWS * UW) hl[cell] = gl[c];
       }
       __syncthreads();
@@ -609,29 +618,28 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
             }
           }
         }
-        float* part = red + wave * (ROWS * RED_LD);
+        float* part = red + wave * RED_W;
         const int rr = (lane >> 4) * 4, cc = lane & 15;
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + cc] = acc[i][r];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(part + cc * RLD + i * 16 + rr) = acc[i];
       }
       __syncthreads();
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
-        const int cell = tid + c * 256;
+        const int cell = RC_CELL(c);
         const int rowl = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + rowl * RED_LD + ul];
+        for (int w = 0; w < 4; ++w) v += red[w * RED_W + ul * RLD + rowl];
         if (mine[c]) p.dhr[(size_t)(r0 + rowl) * R + u0 + ul] = v;
       }
     }
   }
+#undef RC_CELL
   rc_epoch_bump(p.epoch, ep);
   rc_poison(p.bar, p.poison);
 }
-template <int RB, int CG> constexpr size_t rc_smem_bytes() { return (size_t)4 * RB * 16 * (CG * 16 + 1) * 4 + (size_t)RB * 16 * 4 * CG * 2; }
+template <int RB, int CG> constexpr size_t rc_smem_bytes() { return (size_t)4 * (CG * 16) * (RB * 16 + 4) * 4 + (size_t)RB * 16 * 4 * CG * 2; }
 
 // =============================================================================================
 // The backward chain of the same LSTM / GRU, one launch:
