@@ -666,10 +666,11 @@ struct RecChainBwdArgs {
 // panel a workgroup reads every step, ROWS x 4R x 2 bytes through its CU's 64 B/clk L1 fill path, is halved.
 template <int STEPS, int PF, int RB, int CG, int KL = 0>
 __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArgs p) {
-  constexpr int UW = 16 * CG, ROWS = RB * 16, RED_LD = UW + 1, KG = UW / 8, NP = STEPS / 2, KREG = STEPS - KL;
+  constexpr int UW = 16 * CG, ROWS = RB * 16, KG = UW / 8, NP = STEPS / 2, KREG = STEPS - KL;
+  constexpr int RLD = ROWS + 4, RED_W = UW * RLD;      // K partials column-major, as in rec_chain_kernel (round 6)
   extern __shared__ __attribute__((aligned(16))) float rc_smem[];
-  float* red = rc_smem;                                                   // [4 waves][ROWS][RED_LD]
-  bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * ROWS * RED_LD + (4 - (4 * ROWS * RED_LD) % 4) % 4);   // [ROWS][4][UW]
+  float* red = rc_smem;                                                   // [4 waves][UW][RLD]
+  bf16_t* hl = reinterpret_cast<bf16_t*>(rc_smem + 4 * RED_W);            // [ROWS][4][UW]
   bf16x8* wl = reinterpret_cast<bf16x8*>(hl + (size_t)ROWS * 4 * UW);     // [KL][CG][256]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: every k below is wave-uniform
   const int nwx = (int)gridDim.x - (p.master ? 1 : 0);
@@ -701,11 +702,14 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
       }
   }
   constexpr int CPT = (ROWS * UW + 255) / 256;
+  static_assert(CPT == 4, "four consecutive rows per thread");
+  // this thread's cells: unit u0 + tid % UW, rows (tid / UW) CPT + c (cell = row * UW + unit: cell / UW and cell % UW as before)
+#define RCB_CELL(c) (((tid / UW) * CPT + (c)) * UW + tid % UW)
   bool mine[CPT];
   float direct[CPT], carry[CPT], av[CPT][4], cc[CPT], cp[CPT];
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
-    const int cell = tid + c * 256, rg = r0 + cell / UW;
+    const int cell = RCB_CELL(c), rg = r0 + cell / UW;
     mine[c] = cell < ROWS * UW && rg >= own_lo && rg < own_lo + own && rg < B;
     direct[c] = mine[c] ? p.dh_scale * p.dh_direct[(size_t)rg * R + u0 + cell % UW] : 0.f;
     carry[c] = 0.f;
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
   auto prefetch = [&](int t) {                            // saved activations and states of step t
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RCB_CELL(c);
       const size_t row = mine[c] ? r0 + cell / UW : 0;
       const int u = u0 + cell % UW;
       const float* a = p.acts + ((size_t)t * Bs + row) * 4 * R + u;
@@ -782,26 +786,26 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      float* part = red + wave * (ROWS * RED_LD);
+      float* part = red + wave * RED_W;
       const int rr = (lane >> 4) * 4, cl = lane & 15;
 #pragma unroll
       for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int g = 0; g < CG; ++g)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) part[(i * 16 + rr + r) * RED_LD + g * 16 + cl] = acc[i][g][r];
+        for (int g = 0; g < CG; ++g) *reinterpret_cast<f32x4*>(part + (g * 16 + cl) * RLD + i * 16 + rr) = acc[i][g];
       __syncthreads();
     }
-    // ---- cell pointwise backward for UW units x owned rows
+    // ---- cell pointwise backward for UW units x owned rows; the K partials of the thread's four rows: one 16-byte read per wave
+    f32x4 dsum = {0.f, 0.f, 0.f, 0.f};
+    if (s > 0) {
+      const float* rp = red + (tid % UW) * RLD + (tid / UW) * CPT;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) dsum += *reinterpret_cast<const f32x4*>(rp + w * RED_W);
+    }
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = RCB_CELL(c);
       const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
-      float dh = direct[c];
-      if (s > 0) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) dh += red[w * (ROWS * RED_LD) + row * RED_LD + ul];
-      }
+      const float dh = direct[c] + dsum[c];
       const LstmGrad g = p.gru ? gru_point_bwd(dh + carry[c], av[c][0], av[c][1], av[c][2], av[c][3], cp[c])
                                : lstm_point_bwd(dh, carry[c], av[c][0], av[c][1], av[c][2], av[c][3], cc[c], cp[c]);
       carry[c] = g.dc_prev;
@@ -838,9 +842,10 @@ __global__ __launch_bounds__(256) void rec_chain_bwd_kernel(const RecChainBwdArg
       if (p.master) rc_wait_release(p.bar + 256, fb + (unsigned)(s + 1)); else rc_wait(p.bar, fb + (unsigned)(s + 1));
     }
   }
+#undef RCB_CELL
   rc_epoch_bump(p.epoch, ep);
   rc_poison(p.bar, p.poison);
 }
 template <int RB, int CG, int KL = 0> constexpr size_t rc_bwd_smem_bytes() {
-  return ((size_t)4 * RB * 16 * (16 * CG + 1) + 3) / 4 * 4 * 4 + (size_t)RB * 16 * 4 * 16 * CG * 2 + (size_t)KL * CG * 256 * 16;
+  return (size_t)4 * (16 * CG) * (RB * 16 + 4) * 4 + (size_t)RB * 16 * 4 * 16 * CG * 2 + (size_t)KL * CG * 256 * 16;
 }
