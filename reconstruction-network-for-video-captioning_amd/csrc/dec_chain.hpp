@@ -69,7 +69,7 @@ struct DecChainArgs {
 // of 112 (32 KB instead of 115 KB per step: 0.2 us instead of 0.75), and its consumers and producers all lie in ITS row part, so the
 // B -> A hand-over can be partial (DecChainArgs::partial, as in dec_chain_bwd_kernel).
 #define DCF_PARTS 4
-#define DCF_RLD 65
+#define DCF_RLD 68      // (multiple of 4: an accumulator fragment of the TRANSPOSED product is four consecutive columns of one row = one ds_write_b128, round 6)
 // XCD-aware roles: workgroup i runs on XCD i % 8 (rec_chain.hpp), and every XCD fetches what its workgroups read into its own L2.
 // Row part = (i % 8) / 2: the two XCDs of a part read only that part's 28 panel rows (a quarter of h_{t-1}) — with the column block
 // as the fast index every XCD pulled the whole panel every step, eight copies of it over the fabric.  The column blocks are dealt
@@ -79,7 +79,7 @@ template <bool XF, bool LW = false, bool RP = false>
 __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
   static_assert(!(XF && LW), "the LDS-resident attn_W and the LDS frames 32..47 do not fit together");
   // phase A: K-partials of the [112 x 16] tile (LW: two buffers, summed in two stages — the room attn_W needs); RP: of the [32 x 64] tile
-  __shared__ float red[RP ? 2 * 32 * DCF_RLD : (LW ? 2 : 4) * RC_PAN_ROWS * DC_RED_LD];
+  __shared__ __attribute__((aligned(16))) float red[RP ? 2 * 32 * DCF_RLD : (LW ? 2 : 4) * RC_PAN_ROWS * DC_RED_LD];
   __shared__ __attribute__((aligned(16))) float spre[4 * 512];       // phase B: gate pre-activations
   __shared__ float swh[128];
   __shared__ __attribute__((aligned(16))) float sa[32 + DC_XF];
@@ -288,26 +288,24 @@ __global__ __launch_bounds__(256) void dec_chain_kernel(const DecChainArgs p) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) acc[i][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[s][i], wb[s][gq], acc[i][gq], 0, 0, 0);
-        const int rr = (lane >> 4) * 4, cl = lane & 15;
+            for (int gq = 0; gq < 4; ++gq) acc[i][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s][gq], fa[s][i], acc[i][gq], 0, 0, 0);
+        // (transposed product, round 6: the lane holds columns 4 (lane / 16) .. + 3 of row lane % 16 — one 16-byte LDS access per
+        //  fragment where the row-major fragment took four scalar ones; same sums)
+        const int rw = lane & 15, cq = (lane >> 4) * 4;
         // the four K quarters in two stages through two [32 x 64] buffers: waves 2, 3 store, waves 0, 1 add
         float* part_ = red + (wave & 1) * (32 * DCF_RLD);
         if (wave >= 2) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCF_RLD + gq * 16 + cl] = acc[i][gq][r];
+            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4*>(part_ + (i * 16 + rw) * DCF_RLD + gq * 16 + cq) = acc[i][gq];
         }
         __syncthreads();
         if (wave < 2) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCF_RLD + gq * 16 + cl] += acc[i][gq][r];
+            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4*>(part_ + (i * 16 + rw) * DCF_RLD + gq * 16 + cq) += acc[i][gq];
         }
         __syncthreads();
         DC_TS(1);
@@ -676,7 +674,7 @@ struct DecChainBwdArgs {
 // a (row, unit) are separate stamped words; phase B' polls all of them and adds them in K order.
 #define DCB_KS 4
 #define DCB_WS 5              // k32-steps per wave: 4 waves x 5 >= ceil(68 / DCB_KS) = 17 k-steps per K part at H = 512, A = 128
-#define DCB_RLD 65
+#define DCB_RLD 68      // (as DCF_RLD)
 #define DCB_NA(H) ((((H) + 63) >> 6) * DCB_PARTS * DCB_KS)
 
 // XF: frames 32 .. 47 — the third 16-frame block of P as MFMA A fragments read from (dynamic) LDS (rows padded by 8
@@ -684,7 +682,7 @@ struct DecChainBwdArgs {
 #define DCB_PLD (4 * 512 + 8)
 template <bool XF>
 __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArgs p) {
-  __shared__ float red[2 * 32 * DCB_RLD];      // phase A': the K quarters of the workgroup's [32 x 64] tile, summed in two stages
+  __shared__ __attribute__((aligned(16))) float red[2 * 32 * DCB_RLD];      // phase A': the K quarters of the workgroup's [32 x 64] tile, summed in two stages
   __shared__ __attribute__((aligned(16))) bf16_t srow[4 * 512 + 128 + 64];   // [dgates | dWh] of this step (+ zero tail)
   __shared__ float spartf[4 * (32 + DC_XF)], sda[32 + DC_XF], spart[256];
   extern __shared__ __attribute__((aligned(16))) float dc_dyn[];     // XF: [DC_XF][DCB_PLD] bf16, [DC_XF][128] Uv, [DC_XF][128] dUv
@@ -842,25 +840,21 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
 #pragma unroll
           for (int i = 0; i < DCB_RB; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) acc[i][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[j][i], wb[j][gq], acc[i][gq], 0, 0, 0);
-        const int rr = (lane >> 4) * 4, cl = lane & 15;
+            for (int gq = 0; gq < 4; ++gq) acc[i][gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][gq], fa[j][i], acc[i][gq], 0, 0, 0);
+        const int rw = lane & 15, cq = (lane >> 4) * 4;      // transposed product: four consecutive columns of one row per fragment (dec_chain_kernel)
         float* part_ = red + (wave & 1) * (32 * DCB_RLD);      // waves 2, 3 store, waves 0, 1 add
         if (wave >= 2) {
 #pragma unroll
           for (int i = 0; i < DCB_RB; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCB_RLD + gq * 16 + cl] = acc[i][gq][r];
+            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4*>(part_ + (i * 16 + rw) * DCB_RLD + gq * 16 + cq) = acc[i][gq];
         }
         __syncthreads();
         if (wave < 2) {
 #pragma unroll
           for (int i = 0; i < DCB_RB; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) part_[(i * 16 + rr + r) * DCB_RLD + gq * 16 + cl] += acc[i][gq][r];
+            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4*>(part_ + (i * 16 + rw) * DCB_RLD + gq * 16 + cq) += acc[i][gq];
         }
         __syncthreads();
 #pragma unroll
