@@ -286,9 +286,12 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
   }
 
   // ================================================================================== unit-owner workgroups
-  float* red = lc_smem;                                                       // [4 waves][ROWS][RED_LD]; reused as the [ROWS][A + 4] Whr tile
-  bf16_t* hl = reinterpret_cast<bf16_t*>(lc_smem + 4 * ROWS * RED_LD);        // [ROWS][UW]
-  bf16x8* wih = reinterpret_cast<bf16x8*>(lc_smem + 4 * ROWS * RED_LD + ROWS * UW / 2);   // [4 waves][SX][CG][64] B fragments of W_ih
+  // K partials of the four waves COLUMN-major, a thread's cells = consecutive rows of one unit (round 6, as rec_chain_kernel): an
+  // accumulator fragment is one ds_write_b128, a thread's partials one 16-byte (RB = 4) or 8-byte (RB = 2) read per gate and wave
+  constexpr int RLD = ROWS + 4, RED_W = CG * 16 * RLD;
+  float* red = lc_smem;                                                       // [4 waves][64 columns][RLD]
+  bf16_t* hl = reinterpret_cast<bf16_t*>(lc_smem + 4 * RED_W);               // [ROWS][UW]
+  bf16x8* wih = reinterpret_cast<bf16x8*>(lc_smem + 4 * RED_W + ROWS * UW / 2);   // [4 waves][SX][CG][64] B fragments of W_ih
   // XCD-aware roles (rec_chain.hpp: rc_role): workgroup i runs on XCD i % 8; with two row parts, part = (i % 8) / 4 — the four XCDs of a
   // part fetch its rows of the hr / x panels only (with the unit group as the fast index every XCD pulled both halves every step)
   const bool xmap = p.MS == 2 && (p.NG & 3) == 0;
@@ -330,11 +333,13 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     wr[q] = a < A ? *reinterpret_cast<const bf16x4*>(p.Wr + (size_t)a * p.ldwr + u0 + (lane >> 4) * 4) : bf16x4{0, 0, 0, 0};
   }
   constexpr int CPT = (ROWS * UW + 255) / 256;
+  static_assert(CPT == 4 || CPT == 2, "RB = 4 or 2");
+#define LCU_CELL(c) (((tid / UW) * CPT + (c)) * UW + tid % UW)
   float xb[CPT][4], cpv[CPT];
   bool mine[CPT];
 #pragma unroll
   for (int c = 0; c < CPT; ++c) {
-    const int cell = tid + c * 256, rg = r0 + cell / UW;
+    const int cell = LCU_CELL(c), rg = r0 + cell / UW;
     mine[c] = cell < ROWS * UW && rg >= own_lo && rg < own_lo + own && rg < B;
     cpv[c] = 0.f;
 #pragma unroll
@@ -373,33 +378,45 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
         }
     }
     {
-      float* prt = red + wave * (ROWS * RED_LD);
+      float* prt = red + wave * RED_W;
       const int rr = (lane >> 4) * 4, cc = lane & 15;
 #pragma unroll
       for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int g = 0; g < CG; ++g) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) prt[(i * 16 + rr + r) * RED_LD + g * 16 + cc] = acc[i][g][r];
+          *reinterpret_cast<f32x4*>(prt + (g * 16 + cc) * RLD + i * 16 + rr) = acc[i][g];
           acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     __syncthreads();
     if (wg == 0) LC_TS(0, s, 1);
     // ---- cell pointwise for UW units x owned rows
+    float gsum[4][CPT];
+    {
+      const float* rp = red + (tid % UW) * RLD + (tid / UW) * CPT;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) gsum[q][c] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if constexpr (CPT == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rp + w * RED_W + q * UW * RLD);
+            gsum[q][0] += v[0]; gsum[q][1] += v[1]; gsum[q][2] += v[2]; gsum[q][3] += v[3];
+          } else {
+            const float2 v = *reinterpret_cast<const float2*>(rp + w * RED_W + q * UW * RLD);
+            gsum[q][0] += v.x; gsum[q][1] += v.y;
+          }
+        }
+      }
+    }
     float hv[CPT], av[CPT][4];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
-      const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
+      const int cell = LCU_CELL(c);
       float g4[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v = xb[c][q];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[w * (ROWS * RED_LD) + row * RED_LD + q * UW + ul];
-        g4[q] = v;
-      }
+      for (int q = 0; q < 4; ++q) g4[q] = xb[c][q] + gsum[q][c];
       if (p.gru) {
         const GruOut r = gru_point(g4[0], g4[1], g4[2], g4[3], cpv[c]);
         hv[c] = r.h; av[c][0] = r.r; av[c][1] = r.z; av[c][2] = r.n; av[c][3] = r.hn; cpv[c] = r.h;
@@ -454,7 +471,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
     if (it_on) *reinterpret_cast<bf16x8*>(Lt + (size_t)it_rg * p.ld_hlp + u0 + it_j * 8) = *reinterpret_cast<const bf16x8*>(it_src);
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const int cell = tid + c * 256;
+      const int cell = LCU_CELL(c);
       if (mine[c]) {
         const int row = r0 + cell / UW, u = u0 + cell % UW;
         const size_t o = (size_t)row * R + u;
@@ -537,6 +554,7 @@ __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
 }
 // The streamed k-steps of the hybrid forward chain as MFMA B fragments, in the order loc_chain_kernel<STEPS, ., ., SR> consumes
 // them (pair NPR + i of its rotated sequence, i = 0 ..): dst[ug][wave][js][g][lane][8].  Run after every update of W_hh.
+#undef LCU_CELL
 __global__ __launch_bounds__(256) void lc_pack_stream_kernel(const bf16_t* __restrict__ W, int ldw, int R, int H, int STEPS, int SR, bf16_t* __restrict__ dst, size_t n_frag) {
   const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;       // one 16-byte fragment piece per thread
   if (f >= n_frag) return;
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(256) void lc_pack_stream_kernel(const bf16_t* __res
   *reinterpret_cast<bf16x8*>(dst + f * 8) = v;
 }
 template <int RB> constexpr size_t lc_smem_bytes() {
-  return (size_t)4 * RB * 16 * 65 * 4 + (size_t)RB * 16 * 16 * 2 + (size_t)4 * 4 * 4 * 64 * 16;
+  return (size_t)4 * 64 * (RB * 16 + 4) * 4 + (size_t)RB * 16 * 16 * 2 + (size_t)4 * 4 * 4 * 64 * 16;
 }
 
 // =============================================================================================
