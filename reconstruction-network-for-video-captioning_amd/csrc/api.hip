@@ -150,6 +150,7 @@ struct recnet_handle {
   // a new handle).  Each selects between two tested forms of one piece of the schedule, never the arithmetic (tests/test_gpu_knobs.py,
   // tests/test_gpu_parity.py: _chain_variants).
   struct RnSw { int wait_chain = 1, mse_epi = 1, adam_epi = 1, dec_lw = 1, dec_rp = 1, dec_partial = 1, dec_xcat = 1, rec_epi = 2, rec_wide = 1, persist_ms = 0, gemm_group = 1; } sw;
+  int tail_poll_now = 0, bptt_end_sync = 0;      // the step's tail continues behind the BPTT chain's end stamp (wait_chain_end_kernel); the stamp of the last BPTT launch covers all its stores
   int gg_slots = 0;              // workgroup slots the next grouped launches can expect (0 = whole chip): see host_common.inc
   int gemm_single_group = 0;     // set around a single product whose K slices are to be summed inside its launch (host_decoder.inc: the embedding branch)
   hipStream_t s2 = nullptr; hipEvent_t ev[24] = {}; int overlap = 1;
