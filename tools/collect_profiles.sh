@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): bench lines, rocprofv3 kernel statistics, step timelines and PMC traffic passes of the GPU
-# configurations of BASELINE.json, written under gpurun_out/r05/ (copied into profiles/ afterwards).
+# configurations of BASELINE.json, written under gpurun_out/$RND/ (copied into profiles/ afterwards).
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-RND=r05
+RND=${RND:-r06}
 O=gpurun_out/$RND; mkdir -p $O
 run() {  # name "bench args" extra
   local n=$1 args="$2"
@@ -35,8 +35,9 @@ run c2 "$C2" ""
 run c3 "$C3" "--no-cpu-baseline"
 run c4 "$C4" "--no-cpu-baseline --no-fp32-exact"
 run c5 "$C5" "--no-cpu-baseline --no-fp32-exact"
+# the exact-fp32 path under the tracer: how much of its step is launch / dependency latency
+run c2_f32 "--precision f32" "--no-cpu-baseline --no-fp32-exact"
 x="--no-cpu-baseline --no-fp32-exact"
-python3 bench.py --precision f32 $x > $O/bench_c2_f32.json 2>/dev/null
 python3 bench.py --rec local --precision f32 $x > $O/bench_c3_f32.json 2>/dev/null
 python3 bench.py --rec none $x > $O/bench_decoder_only.json 2>/dev/null
 python3 bench.py --lengths msvd $x > $O/bench_c2_msvd_lengths.json 2>/dev/null
@@ -77,7 +78,7 @@ for cfg in c2 c5; do
 done
 rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/prof_*
 ls -la $O
-# round 5 additions: GEMM K-loop / epilogue stamps, cold / warm shapes against the vendor library, the idle time between replays
+# round 5 additions (hipBLASLt only as the yardstick, through torch.matmul): GEMM K-loop / epilogue stamps, cold / warm shapes against the vendor library, the idle time between replays
 ./tools/micro/gemm_probe > $O/gemm_probe.txt 2>&1
 python3 tools/gemm_cold_probe.py > $O/gemm_cold_vs_hipblaslt.txt 2>&1
 python3 tools/between_steps_probe.py global > $O/between_steps_c2.txt 2>&1

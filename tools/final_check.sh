@@ -1,8 +1,8 @@
 #!/bin/bash
 # The round's closing run on the GPU box: the whole GPU suite, then the profile collection.   gpurun --timeout 3300 -- 'bash tools/final_check.sh'
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/r05
-timeout 2700 python3 -m pytest tests -x -q -m gpu > gpurun_out/r05/full_gpu_suite.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r05/full_gpu_suite.log
-tail -3 gpurun_out/r05/full_gpu_suite.log
-bash tools/collect_profiles.sh > gpurun_out/r05/collect.log 2>&1
-tail -2 gpurun_out/r05/collect.log
+mkdir -p gpurun_out/${RND:-r06}
+timeout 2700 python3 -m pytest tests -x -q -m gpu > gpurun_out/${RND:-r06}/full_gpu_suite.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${RND:-r06}/full_gpu_suite.log
+tail -3 gpurun_out/${RND:-r06}/full_gpu_suite.log
+bash tools/collect_profiles.sh > gpurun_out/${RND:-r06}/collect.log 2>&1
+tail -2 gpurun_out/${RND:-r06}/collect.log

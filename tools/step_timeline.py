@@ -13,6 +13,16 @@ idx = [i for i, r in enumerate(rows) if "advance_step" in r[0]]
 a, b = idx[-2], idx[-1]
 t0 = rows[a][1]
 print("step: %.1f us from advance_step to the next advance_step, %d kernels" % ((rows[b][1] - t0) / 1e3, b - a))
+# how much of the step has NO kernel running on any queue (launch / dependency latency), and the sum of kernel run times
+idle_all, busy_sum, fr = 0.0, 0.0, t0
+for n, s, e, q in rows[a:b]:
+    if s > fr:
+        idle_all += (s - fr) / 1e3
+    fr = max(fr, e)
+    busy_sum += (e - s) / 1e3
+idle_all += max(0.0, (rows[b][1] - fr) / 1e3)
+print("no kernel running on any queue: %.1f us of the step (%.1f %%); sum of kernel run times %.1f us" % (
+    idle_all, 100.0 * idle_all / ((rows[b][1] - t0) / 1e3), busy_sum))
 frontier = t0
 for n, s, e, q in rows[a:b]:
     nm = re.sub(r"\s+", " ", n).split("(")[0]
