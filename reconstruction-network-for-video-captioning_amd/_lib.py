@@ -7,8 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RN_LIB_PROBE=1: the probe build (in-kernel time stamps); RN_LIB_VARIANT=acqinv: the cross-check build with acquire fences
-_VARIANT = "_probe" if os.environ.get("RN_LIB_PROBE") == "1" else ("_" + os.environ["RN_LIB_VARIANT"] if os.environ.get("RN_LIB_VARIANT") else "")
+# RN_LIB_VARIANT=probe: the probe build (in-kernel time stamps); =acqinv: the cross-check build with acquire fences; =fault: fault injection
+_VARIANT = ("_" + os.environ["RN_LIB_VARIANT"] if os.environ.get("RN_LIB_VARIANT") else "")
 LIB_PATH = os.path.join(_HERE, "csrc", "librecnet_hip%s.so" % _VARIANT)
 ABI_VERSION = 7
 

@@ -150,7 +150,6 @@ struct recnet_handle {
   // a new handle).  Each selects between two tested forms of one piece of the schedule, never the arithmetic (tests/test_gpu_knobs.py,
   // tests/test_gpu_parity.py: _chain_variants).
   struct RnSw { int wait_chain = 1, mse_epi = 1, adam_epi = 1, dec_lw = 1, dec_rp = 1, dec_partial = 1, dec_xcat = 1, rec_epi = 2, rec_wide = 1, persist_ms = 0, gemm_group = 1; } sw;
-  int tail_poll_now = 0, bptt_end_sync = 0;      // the step's tail continues behind the BPTT chain's end stamp (wait_chain_end_kernel); the stamp of the last BPTT launch covers all its stores
   int gg_slots = 0;              // workgroup slots the next grouped launches can expect (0 = whole chip): see host_common.inc
   int gemm_single_group = 0;     // set around a single product whose K slices are to be summed inside its launch (host_decoder.inc: the embedding branch)
   hipStream_t s2 = nullptr; hipEvent_t ev[24] = {}; int overlap = 1;
@@ -286,7 +285,7 @@ static size_t carve(recnet_handle* h, char* base) {
     h->lc_panw = takev(F * rc_pan_elems((int)RA) / 2 + 64);
     h->lc_dx = take(F * 4 * B * H);     // up to 4 K parts (lcb_xsplit_role)
     h->WihhT = takev((H + R) * (size_t)h->ld4R);
-    if (R > 2048 && R % 128 == 0 && B <= 64) {     // the large-R backward chain (loc_big.hpp; eligibility: recnet_create)
+    if (R > 2048 && R % 128 == 0 && B <= 64 * 2 * RN_MAX_ROW_GROUPS) {     // the large-R backward chain (loc_big.hpp; eligibility: recnet_create; row groups of <= 64 captions)
       const int steps = (int)R / 128;
       h->lb_steps = steps; h->lb_sr = LB_SR(steps); h->lb_ncb = (int)(H + R) / 64;
       h->lb_part = take(F * 4 * 64 * (H + R));
@@ -354,12 +353,34 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   h->cml = c.caption_max_len; h->Tm = c.caption_max_len + 1;
   h->kind = c.reconstructor_type; h->prec = c.precision; h->lp = c.precision == RECNET_PREC_BF16;
   h->gemm_single_group = 0;
+  // Two list-valued switches (round 6: 23 variables -> 9), comma separated, read here once:
+  //   RN_PER_STEP  chains that run on the per-step kernels instead of their persistent launch: dec, dec_bwd, rec, rec_bwd, loc, loc_bwd,
+  //                loc_big — or all;
+  //   RN_ALT       alternative forms the tests hold the default against: dec_wh_in_phase_a, dec_all_rows, dec_relayed_barrier,
+  //                dec_no_xcat, rec_epilogue_0 / rec_epilogue_1, rec_bwd_narrow, rec_row_parts_1 / rec_row_parts_2, loc_no_hybrid,
+  //                loc_xsplit_never / loc_xsplit_always.
+  auto in_list = [](const char* var, const char* name, bool all_ok) {
+    const char* e = getenv(var);
+    if (!e) return false;
+    const size_t n = strlen(name);
+    for (const char* p = e; *p;) {
+      const char* q = strchr(p, ',');
+      const size_t len = q ? (size_t)(q - p) : strlen(p);
+      if ((len == n && !strncmp(p, name, n)) || (all_ok && len == 3 && !strncmp(p, "all", 3))) return true;
+      p = q ? q + 1 : p + len;
+    }
+    return false;
+  };
+  auto alt = [&](const char* name) { return in_list("RN_ALT", name, false); };
+  auto chain_on = [&](const char* name) { return !in_list("RN_PER_STEP", name, true); };
   {
     auto env = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
     h->sw.wait_chain = env("RN_WAIT_CHAIN", 1); h->sw.mse_epi = env("RN_MSE_EPILOGUE", 1); h->sw.adam_epi = env("RN_ADAM_EPILOGUE", 1);
-    h->sw.dec_lw = env("RN_DEC_LOCAL_WH", 1); h->sw.dec_rp = env("RN_DEC_ROWPARTS", 1); h->sw.dec_partial = env("RN_DEC_PARTIAL", 1);
-    h->sw.dec_xcat = env("RN_DEC_XCAT", 1); h->sw.rec_epi = env("RN_REC_EPILOGUE", 2); h->sw.rec_wide = env("RN_REC_BWD_WIDE", 1);
-    h->sw.persist_ms = env("RN_PERSIST_MS", 0); h->sw.gemm_group = env("RN_GEMM_GROUP", 1);
+    h->sw.gemm_group = env("RN_GEMM_GROUP", 1);
+    // RN_ALT: the tested alternative forms of the chain kernels, by name (see in_list below)
+    h->sw.dec_lw = !alt("dec_wh_in_phase_a"); h->sw.dec_rp = !alt("dec_all_rows"); h->sw.dec_partial = !alt("dec_relayed_barrier");
+    h->sw.dec_xcat = !alt("dec_no_xcat"); h->sw.rec_epi = alt("rec_epilogue_0") ? 0 : (alt("rec_epilogue_1") ? 1 : 2); h->sw.rec_wide = !alt("rec_bwd_narrow");
+    h->sw.persist_ms = alt("rec_row_parts_1") ? 1 : (alt("rec_row_parts_2") ? 2 : 0);
   }
   h->dgru = c.decoder_cell == RECNET_CELL_GRU; h->rgru = c.reconstructor_type != RECNET_REC_NONE && c.reconstructor_cell == RECNET_CELL_GRU;
   // The chain kernels exchange h_t / dgates_t through 112-row panels (RC_PAN_ROWS).  A larger batch is cut into row groups of
@@ -374,33 +395,31 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
   const int Bg = h->bgrp;     // rows of one chain launch
   {
     // rec_chain.hpp: every workgroup (8 hidden units) must be resident at once — one per CU
-    const char* e = getenv("RN_PERSIST_REC");
     int dev = 0, ncu = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     h->ncu = ncu;
     // Tm <= 60: stamped words carry epoch << 6 | step and barrier words epoch << 7 | phase (rec_chain.hpp) — a longer
     // caption limit would let one launch's values run into the next epoch's, so it takes the per-step kernels
-    h->persist_rec = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_GLOBAL && Bg <= RC_PAN_ROWS && h->Tm <= 60 &&
+    h->persist_rec = chain_on("rec") && h->lp && h->kind == RECNET_REC_GLOBAL && Bg <= RC_PAN_ROWS && h->Tm <= 60 &&
                      (h->R & 7) == 0 && h->R <= 2048 && h->R / 8 <= ncu;   // <= 16 k-steps of resident weights per wave
-    const char* ed = getenv("RN_PERSIST_DEC");
     const int N = 4 * h->H + h->A, NA = N / 16;
-    h->persist_dec = (ed ? atoi(ed) : 1) && h->lp && h->Tm <= 60 && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 + DC_XF && h->A <= 128 &&
+    h->persist_dec = chain_on("dec") && h->lp && h->Tm <= 60 && (h->H & 7) == 0 && h->H <= 512 && h->F <= 32 + DC_XF && h->A <= 128 &&
                      (N & 15) == 0 && Bg <= RC_PAN_ROWS && (NA > Bg ? NA : Bg) + 1 <= ncu;
-    const char* eb = getenv("RN_PERSIST_REC_BWD");
-    h->persist_rec_bwd = (eb ? atoi(eb) : 1) && h->persist_rec && (h->R & 15) == 0;
+    h->persist_rec_bwd = chain_on("rec_bwd") && h->persist_rec && (h->R & 15) == 0;
   }
   h->bgrp_loc = h->bgrp;
   {
     // loc_chain.hpp: the local reconstructor's forward chain as one launch (unit-owner + caption workgroups + relay)
-    const char* e = getenv("RN_PERSIST_LOC");
     // Row groups of the LOCAL chains (round 4): above 64 rows the forward chain splits its unit owners into two row parts
     // (2 R / 16 workgroups) and the backward chain's U' role takes all rows — at R = 2048 that is 279 workgroups, more than the
     // chip has CUs, and a batch (or row group) of more than 64 captions ran the per-step kernels there.  It now runs the local chains
     // in groups of at most 64 rows (more, smaller groups than the decoder's chains, which take up to 112): every [s][B][.] tensor is
     // indexed by the caption's row in the whole batch, so the two groupings do not have to agree.
     int Bg = h->bgrp;      // (shadows the decoder's group size inside this block)
-    if (h->kind == RECNET_REC_LOCAL && Bg > 64 && h->R <= 2048 && (h->R / 16) * 2 + (Bg + LC_CPW - 1) / LC_CPW + 1 > h->ncu) {
+    // (round 6: the same above R = 2048 — the hybrid forward chain has R / 16 >= 129 unit owners and no room for a second row part, and
+    // the phased backward chain of loc_big.hpp takes at most 64 rows: batches up to 256 captions run both in groups)
+    if (h->kind == RECNET_REC_LOCAL && Bg > 64 && (h->R > 2048 || (h->R / 16) * 2 + (Bg + LC_CPW - 1) / LC_CPW + 1 > h->ncu)) {
       const int ngl = (h->B + 63) / 64;
       if (ngl <= 2 * RN_MAX_ROW_GROUPS) { Bg = (h->B + ngl - 1) / ngl; h->bgrp_loc = Bg; }
     }
@@ -411,8 +430,8 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     if (nwg - 1 == h->ncu) nwg -= 1;
     // R above 2048 (a multiple of 256): the hybrid form of loc_chain_kernel (12 k-steps per wave resident in registers, the
     // rest streamed every step), forward chain only; the backward runs the per-step kernels
-    const int f_hyb = getenv("RN_LOC_HYBRID") ? atoi(getenv("RN_LOC_HYBRID")) : 1;   // (read per handle: the tests switch it)
-    h->persist_loc = (e ? atoi(e) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && Bg <= RC_PAN_ROWS && (h->R & 31) == 0 &&
+    const int f_hyb = !alt("loc_no_hybrid");
+    h->persist_loc = chain_on("loc") && h->lp && h->kind == RECNET_REC_LOCAL && Bg <= RC_PAN_ROWS && (h->R & 31) == 0 &&
                      (h->R <= 2048 || (f_hyb && h->R <= 4096 && (h->R & 255) == 0)) && h->lc_ng <= 256 && (h->H & 31) == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 3) == 0 && h->Tm <= 32 &&
                      h->F + 1 < LC_MAX_PHASE &&   // barrier words are epoch << 7 | phase, phase <= F + 1 (loc_chain.hpp)
 #ifdef LC_PROBE
@@ -420,30 +439,26 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
 #endif
                      nwg <= h->ncu && nwg - 1 <= 256;
     // ... and its backward chain: U' all rows (RB 7) + X' two row parts above 64 captions, one part of 64 rows below
-    const char* eb = getenv("RN_PERSIST_LOC_BWD");
     h->lcb_msx = Bg > 64 ? 2 : 1; h->lcb_rbu = Bg > 64 ? 7 : (Bg > 32 ? 4 : 2);
     int nwb = h->lc_ng + (h->H / 16) * h->lcb_msx + h->lc_nc + 1;
     {   // X' with K split in parts of 2048 (64 columns x 32 rows x one part per workgroup) when those workgroups fit as well
-      const char* ex = getenv("RN_LOC_XSPLIT");
       const int ksx = (4 * h->R + 2047) / 2048, nwx = h->lc_ng + ((h->H + 63) / 64) * ((Bg + 31) / 32) * ksx + h->lc_nc + 1;
-      const int fx = ex ? atoi(ex) : 1;
+      const int fx = alt("loc_xsplit_never") ? 0 : (alt("loc_xsplit_always") ? 2 : 1);
       if (fx && ksx <= 4 && (h->R >= 512 || fx == 2) && nwx <= h->ncu && nwx - 1 <= 256) { h->lcb_xs = 16; nwb = nwx; }
     }
     // (R <= 2048: its kernels hold at most 64 k-steps of K = 4R per wave; the hybrid forward chain above that runs with the
     // per-step backward)
     {   // R above 2048: the phased backward chain of loc_big.hpp (P / C / L phases of (H + R) / 64 * 4 workgroups)
-      const int ebig = getenv("RN_PERSIST_LOC_BIG") ? atoi(getenv("RN_PERSIST_LOC_BIG")) : 1;
       const int steps = h->R / 128, nwg = (h->H + h->R) / 64 * 4;
-      h->persist_big_bwd = ebig && (eb ? atoi(eb) : 1) && h->lp && h->kind == RECNET_REC_LOCAL && h->R > 2048 && h->R % 128 == 0 &&
+      h->persist_big_bwd = chain_on("loc_big") && chain_on("loc_bwd") && h->lp && h->kind == RECNET_REC_LOCAL && h->R > 2048 && h->R % 128 == 0 &&
                            (steps >= 18 && steps <= 32 && (steps & 1) == 0) && h->H % 64 == 0 && h->H <= 512 && h->RA <= 128 && (h->RA & 7) == 0 &&
-                           h->B <= 64 && Bg == h->B && h->Tm <= 32 && h->F <= 40 && nwg <= h->ncu && nwg <= 256 && h->R / 16 < nwg && h->B < nwg;
+                           Bg <= 64 && h->B <= 64 * 2 * RN_MAX_ROW_GROUPS && h->Tm <= 32 && h->F <= 40 && nwg <= h->ncu && nwg <= 256 && h->R / 16 < nwg && Bg < nwg;
     }
-    h->persist_loc_bwd = (eb ? atoi(eb) : 1) && h->persist_loc && h->R <= 2048 && (h->H & 15) == 0 && !(Bg > 64 && h->R > 1536) &&
+    h->persist_loc_bwd = chain_on("loc_bwd") && h->persist_loc && h->R <= 2048 && (h->H & 15) == 0 && !(Bg > 64 && h->R > 1536) &&
                          nwb <= h->ncu && nwb - 1 <= 256;
   }
   {
     h->use_wcomb_t = h->lp && (h->B <= 128 || Bg < h->B);
-    const char* eb = getenv("RN_PERSIST_DEC_BWD");
     int dev = 0, ncu = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -453,7 +468,7 @@ int recnet_create(const recnet_config* cfg, recnet_handle** out) {
     // without the reserve (the collective does not wait for it), but its first steps would spin until CUs free up.
     const char* er = getenv("RN_RESERVE_CUS");
     const int reserve = er ? atoi(er) : 0;
-    h->persist_dec_bwd = (eb ? atoi(eb) : 1) && h->persist_dec && h->use_wcomb_t && (h->H & 15) == 0 && (h->ldWS & 7) == 0 &&
+    h->persist_dec_bwd = chain_on("dec_bwd") && h->persist_dec && h->use_wcomb_t && (h->H & 15) == 0 && (h->ldWS & 7) == 0 &&
                          (NAb > Bg ? NAb : Bg) + 1 + reserve <= ncu;
   }
   {
@@ -559,6 +574,7 @@ int recnet_bind_workspace(recnet_handle* h, void* workspace, size_t bytes) {
   if (!h->s2) {
     h->overlap = 1;
     // (a lowest-priority side stream was measured in round 4: 2.63 against 1.82 ms — the side work is on the critical path often enough)
+    // (non-default stream priorities for the side streams — lowest or highest — cost 0.12 ms at C2 and 0.07 at C3, round 6: default priority)
     HIPCHK(hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking));
     for (int i = 0; i < 24; ++i) HIPCHK(hipEventCreateWithFlags(&h->ev[i], hipEventDisableTiming));

@@ -1040,6 +1040,12 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
       { if (p.partial) wait_part(fb + ph); else if (p.master) rc_wait_release(p.bar + 256, fb + ph); else rc_wait(p.bar, fb + ph); }
     }
   }
+  if (p.partial) {
+    // the launch epoch may only move once every workgroup has read it: a full barrier, once, at the end (phase T: above every step's)
+    __syncthreads();
+    rc_arrive(p.bar, fb + (unsigned)p.T);
+    if (wg == 0) rc_wait(p.bar, fb + (unsigned)p.T);
+  }
   // ---- the accumulators: dUv (+ operand copy, zero padded), dw
   if (isB) {
     if (fk_on) {
@@ -1073,16 +1079,6 @@ __global__ __launch_bounds__(256) void dec_chain_bwd_kernel(const DecChainBwdArg
 #pragma unroll
       for (int ch = 1; ch < RN_FCH; ++ch) p.dwacc[((size_t)ch * Bs + b) * A + tid] = 0.f;
     }
-  }
-  if (p.partial) {
-    // the launch epoch may only move once every workgroup has read it: a full barrier, once, at the end (phase T: above every step's).
-    // Round 6: it sits behind the LAST stores of every workgroup, each of which has written its XCD's L2 back first (agent-scope
-    // release) — workgroup 0's end stamp then says "every result of this launch is in memory", and the streams that continue with
-    // the step's tail wait for the stamp (wait_chain_end_kernel) instead of for a cross-queue edge of the captured graph.
-    __threadfence();
-    __syncthreads();
-    rc_arrive(p.bar, fb + (unsigned)p.T);
-    if (wg == 0) rc_wait(p.bar, fb + (unsigned)p.T);
   }
   rc_epoch_bump(p.epoch, ep0);
   rc_poison(p.bar, p.poison);

@@ -115,23 +115,6 @@ __global__ void wait_chain_kernel(const unsigned long long* step_start, const un
     __builtin_amdgcn_s_sleep(8);
   }
 }
-// Round 6: the END of a chain as a stream-ordering primitive.  In the captured step a node whose successors lie on other hardware queues
-// hands over through signals — ~20 us in front of ALL its successors instead of ~6 to the next kernel of its own queue (measured at the
-// end of the BPTT chain, where the step's tail forks into three streams).  The side streams are therefore forked IN FRONT of the chain
-// (they run other work beside it anyway) and continue behind this one-wave kernel, which returns once the chain's END stamp is younger
-// than the step's start stamp; the chain's own stream keeps ONE successor.  Unlike wait_chain_kernel this wait carries a data dependence:
-// the chain kernel stamps its end only after a final grid barrier that every workgroup reaches behind its last stores and an
-// agent-scope release (dec_chain_bwd_kernel), and giving up (seconds) poisons the step's loss like rc_give_up.
-__global__ void wait_chain_end_kernel(const unsigned long long* step_start, const unsigned long long* chain_end, float* poison) {
-  const unsigned long long t0 = wall_clock64();
-  for (;;) {
-    const unsigned long long s = __hip_atomic_load(step_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long e = __hip_atomic_load(chain_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (e >= s && e != 0ull) break;
-    if (wall_clock64() - t0 > 400000000ull) { if (threadIdx.x == 0) *poison = __builtin_nanf(""); break; }      // 4 s
-    __builtin_amdgcn_s_sleep(4);
-  }
-}
 // Every wait in the chain kernels is bounded: a launch whose workgroups are not all resident (two such launches sharing
 // the GPU) would otherwise spin forever and take the device with it.  After ~2^22 polls (seconds) a waiter raises the
 // sticky word bar[257]; every wait of this and of later launches then falls through, and the kernel poisons the step's

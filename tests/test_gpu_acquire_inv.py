@@ -45,7 +45,6 @@ np.savez(out, **res)
 
 def _run(kind, variant, path, shape=(100, 28, 1536)):
     env = dict(os.environ)
-    env.pop("RN_LIB_PROBE", None)
     if variant:
         env["RN_LIB_VARIANT"] = variant
     else:

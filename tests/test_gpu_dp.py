@@ -35,8 +35,7 @@ def _worker(rank, world, port, kind, q):
     # Two ranks share ONE GPU here (test rig only).  The persistent chain kernels need every workgroup of a launch resident
     # and spin on grid barriers: two such launches from two processes could each hold part of the CUs and wait for the
     # rest forever.  One process per GPU (the supported deployment) cannot get there; this rig switches them off.
-    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC", "RN_PERSIST_LOC"):
-        os.environ[k] = "0"
+    os.environ["RN_PER_STEP"] = "rec,dec,loc"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     import recnet_amd as R
@@ -98,8 +97,7 @@ def _worker_giveup(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC", "RN_PERSIST_LOC"):
-        os.environ[k] = "0"
+    os.environ["RN_PER_STEP"] = "rec,dec,loc"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     import recnet_amd as R

@@ -17,7 +17,6 @@ TARGET = "tests/test_gpu_parity.py::test_benchmarked_update_path_matches_referen
 
 def _child(fault, case):
     env = dict(os.environ)
-    env.pop("RN_LIB_PROBE", None)
     env["RN_LIB_VARIANT"] = "fault"
     env["RN_FAULT"] = str(fault)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "%s[%s-graph_split_update-bf16]" % (TARGET, case)],

@@ -125,8 +125,7 @@ def test_chain_kernels_over_changing_batches_match_per_step_kernels(cell, kind, 
     recP = GU.formula_params(GU.rec_shapes(kind, H, D, RA, cell), 22)
     _, dec_a, rec_a = make_models(list(DIMS), kind, "bf16", decP, recP, cells=(cell, cell))
     step_a = R.TrainStep(dec_a, rec_a)
-    for k in ("RN_PERSIST_REC", "RN_PERSIST_DEC", "RN_PERSIST_LOC", "RN_PERSIST_LOC_BWD"):
-        monkeypatch.setenv(k, "0")
+    monkeypatch.setenv("RN_PER_STEP", "rec,dec,loc,loc_bwd")
     _, dec_b, rec_b = make_models(list(DIMS), kind, "bf16", decP, recP, cells=(cell, cell))
     step_b = R.TrainStep(dec_b, rec_b)
     for seed in (11, 12, 13):

@@ -1,8 +1,8 @@
 """Round-4 switches of the fused step, each held against the default: the grouped GEMM launches (RN_GEMM_GROUP), the Adam update in
 the epilogue of the pending d W_hh product (RN_ADAM_EPILOGUE), the decoder forward chain with the attention projection formed by
-the caption's own workgroup (RN_DEC_LOCAL_WH), the residency waits of the side branches (RN_WAIT_CHAIN) and the MSE + d loss / d out
+the caption's own workgroup (RN_ALT=dec_wh_in_phase_a switches back), the residency waits of the side branches (RN_WAIT_CHAIN) and the MSE + d loss / d out
 of the local reconstructor's output layer in that product's epilogue (RN_MSE_EPILOGUE); round 5: the decoder chains' hand-over
-inside a row part (RN_DEC_PARTIAL) and the forward chain's phase A tiled by row parts (RN_DEC_ROWPARTS).  (Round 6: the vendor-library switches of
+inside a row part (RN_ALT=dec_relayed_barrier) and the forward chain's phase A tiled by row parts (RN_ALT=dec_all_rows).  (Round 6: the vendor-library switches of
 round 5 are gone with the library — every product runs on the hand-written kernels.)  Every switch changes
 the SCHEDULE or the summation order of a product, never the arithmetic: parameters after four replayed steps (split reconstructor
 update, flushed) agree to rounding with the default's, the losses of every step to 1e-4 (bf16 operands).
@@ -57,10 +57,11 @@ def _run(kind, env):
 
 
 @pytest.mark.parametrize("kind", ["global", "local"])
-@pytest.mark.parametrize("knob", ["RN_GEMM_GROUP", "RN_ADAM_EPILOGUE", "RN_DEC_LOCAL_WH", "RN_WAIT_CHAIN", "RN_MSE_EPILOGUE", "RN_DEC_PARTIAL", "RN_DEC_ROWPARTS"])
+@pytest.mark.parametrize("knob", ["RN_GEMM_GROUP=0", "RN_ADAM_EPILOGUE=0", "RN_ALT=dec_wh_in_phase_a", "RN_WAIT_CHAIN=0", "RN_MSE_EPILOGUE=0",
+                                  "RN_ALT=dec_relayed_barrier", "RN_ALT=dec_all_rows"])
 def test_switch_off_equals_default(knob, kind):
     p0, l0 = _run(kind, {})
-    p1, l1 = _run(kind, {knob: "0"})
+    p1, l1 = _run(kind, dict([knob.split("=")]))
     assert np.allclose(l0[:, :7], l1[:, :7], rtol=1e-4, atol=0), (knob, l0[:, 6], l1[:, 6])
     # the comparison has teeth: the updates moved the loss by far more than its tolerance ...
     assert abs(l0[3, 6] - l0[0, 6]) > 100 * 1e-4 * abs(l0[0, 6]), l0[:, 6]

@@ -479,6 +479,9 @@ HYBRID = {
     "LOC_R2304_H64_B48_big_backward": ([48, 3, 2304, 29, 8, 64, 16, 16], [(5 * i) % 7 for i in range(48)]),
     "LOC_R2560_H64_B20_big_backward": ([20, 3, 2560, 29, 8, 64, 16, 8], [(3 * i) % 6 for i in range(20)]),
     "LOC_R3840_H64_B24_big_backward": ([24, 3, 3840, 29, 8, 64, 16, 16], [(7 * i) % 9 for i in range(24)]),
+    # round 6: batches above 64 captions at R > 2048 run both local chains in row groups of <= 64
+    "LOC_R3584_H64_B65_row_groups_big_backward": ([65, 3, 3584, 29, 8, 64, 16, 16], [(5 * i) % 7 for i in range(65)]),
+    "LOC_R3584_H64_B128_row_groups_big_backward": ([128, 3, 3584, 29, 8, 64, 16, 16], [(5 * i) % 7 for i in range(128)]),
 }
 
 
@@ -487,7 +490,7 @@ HYBRID = {
 def test_hybrid_forward_chain_vs_oracle(case, prec, monkeypatch):
     """The regulariser is left out on both sides (lambda_reg = 0 in the oracle, no add_reg_grad): the reference's float32
     `torch.norm` over the 26-51 M elements of W_hh is off by up to 3e-3 (tests/test_gpu_configs.py), which is the oracle's
-    error.  CE and MSE parts and every gradient are compared.  bf16: also against the per-step kernels (RN_LOC_HYBRID=0)."""
+    error.  CE and MSE parts and every gradient are compared.  bf16: also against the per-step kernels (RN_ALT=loc_no_hybrid, RN_PER_STEP=loc_big)."""
     dims, lens = HYBRID[case]
     B, F, D, V, E, H, A, RA = dims
     decP = GU.formula_params(GU.decoder_shapes(V, E, H, A, D), 31)
@@ -507,12 +510,13 @@ def test_hybrid_forward_chain_vs_oracle(case, prec, monkeypatch):
         return step.engine.scalar_dict(), g, n_chain
 
     sc, g, n_chain = run()
-    assert n_chain == (1 if prec == "bf16" else 0), "the hybrid chain kernel is the bf16 path's forward for this shape"
+    n_groups = (B + 63) // 64      # (row groups of the local chains above 64 captions)
+    assert n_chain == (n_groups if prec == "bf16" else 0), "the hybrid chain kernel is the bf16 path's forward for this shape"
     if prec == "bf16" and "big_backward" in case:
         C, dec, rec = make_models(dims, "local", prec, decP, recP)
         st0 = R.TrainStep(dec, rec)
         T0, w0 = st0.prepare(targets.numpy())
-        assert st0.engine.profile_site(8, lambda: st0.fwd_bwd(enc.cuda(), targets.cuda(), T0, w0, seed=6), 1)[0] == 1, "loc_big backward chain not taken"
+        assert st0.engine.profile_site(8, lambda: st0.fwd_bwd(enc.cuda(), targets.cuda(), T0, w0, seed=6), 1)[0] == n_groups, "loc_big backward chain not taken"
     st = O.TrainState(decP, recP, "local")
     drop = O.Dropper("hash", seed=6)
     dl, hid, _, ce, _ = O.forward_decoder(st.dec, enc, targets, targets > 0, drop=drop, lambda_reg=0.0, return_parts=True)
@@ -531,8 +535,8 @@ def test_hybrid_forward_chain_vs_oracle(case, prec, monkeypatch):
                     np.savez(os.path.join(os.environ["RN_TEST_DUMP"], "%s_%s_%s.npz" % (case, grp, k)), got=g[grp][k], want=v.grad.numpy())
     assert not bad, bad
     if prec == "bf16":
-        monkeypatch.setenv("RN_LOC_HYBRID", "0")
-        monkeypatch.setenv("RN_PERSIST_LOC_BIG", "0")
+        monkeypatch.setenv("RN_ALT", "loc_no_hybrid")
+        monkeypatch.setenv("RN_PER_STEP", "loc_big")
         sc0, g0, n0 = run()
         assert n0 == 0
         for grp in g:
@@ -567,7 +571,7 @@ def test_batches_above_112_captions_stay_on_the_persistent_chains(kind, monkeypa
 @pytest.mark.parametrize("case", [c for c in sorted(EDGE) if c.startswith("LOC_")] + sorted(EDGE_KSPLIT))
 def test_local_backward_chain_with_k_split_forced(case, monkeypatch):
     """lcb_xsplit_role is selected from R = 512 up; forced here so the small ragged shapes run through it as well."""
-    monkeypatch.setenv("RN_LOC_XSPLIT", "2")
+    monkeypatch.setenv("RN_ALT", "loc_xsplit_always")
     test_fused_step_vs_oracle_edge_shapes(case, "local", "bf16")
 
 
@@ -595,33 +599,34 @@ def test_local_chains_in_row_groups_of_their_own(case):
 @pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 37, 256)])
 def test_reconstructor_input_written_by_the_decoder_chain_equals_the_separate_kernel(cell, B, R, monkeypatch):
     """dec_chain_kernel writes the global reconstructor's LSTM input [h_t ; drop_t(mp)] (global_reconstructor.py:38-41) itself
-    (RN_DEC_XCAT=0: xcat_global_kernel behind the chain)."""
-    _chain_variants({"RN_DEC_XCAT": "0"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
+    (RN_ALT=dec_no_xcat: xcat_global_kernel behind the chain)."""
+    _chain_variants({"RN_ALT": "dec_no_xcat"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
 
 
 @pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 100, 1536), ("LSTM", 57, 1040), ("LSTM", 112, 2048)])
 def test_output_layer_epilogue_of_the_forward_chain_equals_the_separate_kernels(cell, B, R, monkeypatch):
     """rec_chain_kernel's epilogue (out = mean_t h_t . W_o^T + b_o, squared-error partial sums, d out and its operand copy behind one more
-    barrier phase: train.py:96-103) against the split-K GEMM + reduction + MSE kernel it replaces (RN_REC_EPILOGUE=0): the headline size,
+    barrier phase: train.py:96-103) against the split-K GEMM + reduction + MSE kernel it replaces (RN_ALT=rec_epilogue_0): the headline size,
     the GRU cells, the smallest batch that takes the two-row-part tiling with a ragged last unit group, every panel row at 16 k-steps."""
-    _chain_variants({"RN_REC_EPILOGUE": "0"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
+    _chain_variants({"RN_ALT": "rec_epilogue_0"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
 
 
 @pytest.mark.parametrize("cell,B,R", [("LSTM", 100, 1536), ("GRU", 100, 1536), ("LSTM", 65, 1056), ("LSTM", 112, 1280)])
 def test_global_backward_chain_wide_tiling_equals_the_narrow_one(cell, B, R, monkeypatch):
     """rec_chain_bwd_kernel<48, 3, 2, 2, 16> (32 units x 32 rows, a third of the weights in LDS; B > 64, R in (1024, 1536]):
     the headline size, the GRU block map, one row in the third row part with the fewest k-steps, every panel row in use."""
-    _chain_variants({"RN_REC_BWD_WIDE": "0"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
+    _chain_variants({"RN_ALT": "rec_bwd_narrow"}, cell, monkeypatch, [B, 2, R, 29, 8, 32, 16, 16], [(7 * i) % 5 for i in range(B)])
 
 
 @pytest.mark.parametrize("cell", ["LSTM", "GRU"])
-@pytest.mark.parametrize("env", [{"RN_PERSIST_REC": "0"}, {"RN_PERSIST_REC_BWD": "0"}, {"RN_PERSIST_MS": "1"}, {"RN_PERSIST_MS": "2"},
-                                 {"RN_PERSIST_DEC": "0"}, {"RN_PERSIST_DEC_BWD": "0"}])
+@pytest.mark.parametrize("env", [{"RN_PER_STEP": "rec"}, {"RN_PER_STEP": "rec_bwd"}, {"RN_ALT": "rec_row_parts_1"}, {"RN_ALT": "rec_row_parts_2"},
+                                 {"RN_PER_STEP": "dec"}, {"RN_PER_STEP": "dec_bwd"}],
+                         ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_persistent_reconstructor_chain_variants(env, cell, monkeypatch):
     _chain_variants(env, cell, monkeypatch, [100, 3, 48, 29, 8, 32, 16, 16], [(7 * i) % 9 for i in range(100)])
 
 
-@pytest.mark.parametrize("env", [{"RN_PERSIST_REC": "0"}, {"RN_PERSIST_REC_BWD": "0"}])
+@pytest.mark.parametrize("env", [{"RN_PER_STEP": "rec"}, {"RN_PER_STEP": "rec_bwd"}], ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_persistent_reconstructor_chains_R2048(env, monkeypatch):
     """The largest reconstructor the chain kernels take (16 / 64 k-steps of resident weights per wave)."""
     _chain_variants(env, "LSTM", monkeypatch, [60, 2, 2048, 29, 8, 32, 16, 16], [(5 * i) % 4 for i in range(60)])
@@ -652,6 +657,6 @@ def _chain_variants(env, cell, monkeypatch, dims, lens):
     sc1, g1 = run()
     assert abs(sc0["rec_loss"] - sc1["rec_loss"]) <= 1e-5 * abs(sc0["rec_loss"])
     assert abs(sc0["dec_loss"] - sc1["dec_loss"]) <= 1e-6 * abs(sc0["dec_loss"])
-    bar = 1e-2 if any(k.startswith("RN_PERSIST_DEC") for k in env) else 2e-3    # bf16 dgates in the attention backward
+    bar = 1e-2 if env.get("RN_PER_STEP", "").startswith("dec") else 2e-3    # bf16 dgates in the attention backward
     bad = [(k, rel_err(g1[k], g0[k])) for k in g0 if rel_err(g1[k], g0[k]) > bar]
     assert not bad, bad

@@ -24,7 +24,7 @@ python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c
 python3 bench.py --defer 0 $x > $O/bench_c2_update_inside_the_step.json 2>/dev/null
 python3 bench.py $C3 --defer 0 $x > $O/bench_c3_update_inside_the_step.json 2>/dev/null
 RN_GEMM_GROUP=0 python3 bench.py $x > $O/bench_c2_no_grouped_launches.json 2>/dev/null
-RN_DEC_LOCAL_WH=0 python3 bench.py $x > $O/bench_c2_attention_projection_in_phase_A.json 2>/dev/null
+RN_ALT=dec_wh_in_phase_a python3 bench.py $x > $O/bench_c2_attention_projection_in_phase_A.json 2>/dev/null
 RN_ADAM_EPILOGUE=0 python3 bench.py $x > $O/bench_c2_adam_kernel_instead_of_epilogue.json 2>/dev/null
 RN_WAIT_CHAIN=0 python3 bench.py $x > $O/bench_c2_no_residency_waits.json 2>/dev/null
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --force-allreduce $x 2>/dev/null | tail -1 > $O/bench_c2_dp_one_rank_one_graph.json

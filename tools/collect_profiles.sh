@@ -48,7 +48,7 @@ python3 bench.py --batch 200 $x > $O/bench_c2_B200.json 2>/dev/null
 RN_ROW_GROUPS=0 python3 bench.py --batch 200 $x > $O/bench_c2_B200_per_step_kernels.json 2>/dev/null
 python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c4_weak_B256.json 2>/dev/null
 RN_ROW_GROUPS=0 python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c4_weak_B256_per_step_kernels.json 2>/dev/null
-RN_LOC_HYBRID=0 python3 bench.py $C5 $x > $O/bench_c5_per_step_forward.json 2>/dev/null
+RN_ALT=loc_no_hybrid python3 bench.py $C5 $x > $O/bench_c5_per_step_forward.json 2>/dev/null
 # PCIe-inclusive rate (never `value`): every step takes a fresh host batch through feed.DeviceFeeder
 python3 bench.py --feed 1 $x > $O/bench_c2_host_feed.json 2>/dev/null
 python3 bench.py --defer 1 $x > $O/bench_c2_deferred_reconstructor_update.json 2>/dev/null
@@ -56,20 +56,20 @@ python3 bench.py --defer 1 $x > $O/bench_c2_deferred_reconstructor_update.json 2
 python3 bench.py --defer 0 $x > $O/bench_c2_update_inside_the_step.json 2>/dev/null
 python3 bench.py --rec local --defer 0 $x > $O/bench_c3_update_inside_the_step.json 2>/dev/null
 RN_GEMM_GROUP=0 python3 bench.py $x > $O/bench_c2_no_grouped_launches.json 2>/dev/null
-RN_DEC_LOCAL_WH=0 python3 bench.py $x > $O/bench_c2_attention_projection_in_phase_A.json 2>/dev/null
+RN_ALT=dec_wh_in_phase_a python3 bench.py $x > $O/bench_c2_attention_projection_in_phase_A.json 2>/dev/null
 RN_ADAM_EPILOGUE=0 python3 bench.py $x > $O/bench_c2_adam_kernel_instead_of_epilogue.json 2>/dev/null
 RN_WAIT_CHAIN=0 python3 bench.py $x > $O/bench_c2_no_residency_waits.json 2>/dev/null
-RN_DEC_PARTIAL=0 python3 bench.py $x > $O/bench_c2_relayed_barrier_in_decoder_chains.json 2>/dev/null
-RN_DEC_ROWPARTS=0 python3 bench.py $x > $O/bench_c2_forward_phase_A_all_rows.json 2>/dev/null
+RN_ALT=dec_relayed_barrier python3 bench.py $x > $O/bench_c2_relayed_barrier_in_decoder_chains.json 2>/dev/null
+RN_ALT=dec_all_rows python3 bench.py $x > $O/bench_c2_forward_phase_A_all_rows.json 2>/dev/null
 # the data-parallel step at ONE rank (no byte crosses xGMI): one captured graph with the collectives inside / three graphs
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --force-allreduce $x > $O/bench_c2_dp_one_rank_one_graph.json 2>/dev/null
 RN_DP_ONE_GRAPH=0 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --force-allreduce $x > $O/bench_c2_dp_one_rank_three_graphs.json 2>/dev/null
 for i in 2 3; do python3 bench.py --feed 1 $x > $O/bench_c2_host_feed_$i.json 2>/dev/null; python3 bench.py $x > $O/bench_c2_resident_$i.json 2>/dev/null; done
 python3 tools/rccl_bucket_bench.py > $O/rccl_buckets_1rank_c2.json 2>/dev/null
 # in-kernel stamps of the chain kernels (probe build of the library)
-RN_LIB_PROBE=1 python3 tools/loc_chain_probe.py 100 28 1536 > $O/chain_probe_c3.txt 2>/dev/null
-RN_LIB_PROBE=1 python3 tools/loc_chain_probe.py 64 28 3584 > $O/chain_probe_c5.txt 2>/dev/null
-RN_LOC_HYBRID=0 RN_PERSIST_LOC_BIG=0 python3 bench.py $C5 $x > $O/bench_c5_per_step_kernels.json 2>/dev/null
+RN_LIB_VARIANT=probe python3 tools/loc_chain_probe.py 100 28 1536 > $O/chain_probe_c3.txt 2>/dev/null
+RN_LIB_VARIANT=probe python3 tools/loc_chain_probe.py 64 28 3584 > $O/chain_probe_c5.txt 2>/dev/null
+RN_ALT=loc_no_hybrid RN_PER_STEP=loc_big python3 bench.py $C5 $x > $O/bench_c5_per_step_kernels.json 2>/dev/null
 for cfg in c2 c5; do
   a="$C2"; [ $cfg = c5 ] && a="$C5"
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma_$cfg -- python3 bench.py $a $x --steps 10 --warmup 3 > /dev/null 2>&1

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Where a step of the local reconstructor's chain kernels goes: in-kernel wall-clock stamps (probe build of the library:
-`make -C reconstruction-network-for-video-captioning_amd/csrc probe`, loaded with RN_LIB_PROBE=1).
+`make -C reconstruction-network-for-video-captioning_amd/csrc probe`, loaded with RN_LIB_VARIANT=probe).
 
-   RN_LIB_PROBE=1 python tools/loc_chain_probe.py [B F D]
+   RN_LIB_VARIANT=probe python tools/loc_chain_probe.py [B F D]
 Prints, per role, the median over the steps of the intervals between consecutive stamps (us) and the step period."""
 import ctypes as C
 import os
@@ -10,7 +10,7 @@ import sys
 
 import numpy as np
 
-os.environ["RN_LIB_PROBE"] = "1"
+os.environ["RN_LIB_VARIANT"] = "probe"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import recnet_amd as R  # noqa: E402
