@@ -24,6 +24,8 @@ pmc() {  # name "bench args" kind B F D  kernel-pattern...   (one pair of counte
 import json,sys; d=json.load(sys.stdin); d.update(B=$B, F=$F, D=$D, kind='$kind', T=31, cell='LSTM', config='$n'); print(json.dumps(d))" > $O/pmc_traffic_${n}_$fn.json
   done
 }
+# PART=1: counter passes + traced runs of C2..C5 and the fp32 path; PART=2: everything else; unset: both (about 55 minutes)
+if [ "${PART:-0}" != "2" ]; then
 C2=""; C3="--rec local"; C4="--rec local --batch 32 --frames 40 --feat 2048"; C5="--rec local --batch 64 --frames 28 --feat 3584"
 # counter passes first: the bench lines below read the traffic of their dominant kernel from profiles/${RND}_pmc_traffic_*.json
 pmc c2 "$C2" global 100 28 1536 dec_chain_kernel dec_chain_bwd_kernel rec_chain_kernel rec_chain_bwd_kernel
@@ -37,7 +39,10 @@ run c4 "$C4" "--no-cpu-baseline --no-fp32-exact"
 run c5 "$C5" "--no-cpu-baseline --no-fp32-exact"
 # the exact-fp32 path under the tracer: how much of its step is launch / dependency latency
 run c2_f32 "--precision f32" "--no-cpu-baseline --no-fp32-exact"
+if [ "${PART:-0}" = "1" ]; then rm -rf $O/pmc_*_FETCH_SIZE $O/pmc_*_WRITE_SIZE $O/prof_*; ls $O | wc -l; exit 0; fi
+fi      # PART != 2
 x="--no-cpu-baseline --no-fp32-exact"
+C2=""; C3="--rec local"; C4="--rec local --batch 32 --frames 40 --feat 2048"; C5="--rec local --batch 64 --frames 28 --feat 3584"
 python3 bench.py --rec local --precision f32 $x > $O/bench_c3_f32.json 2>/dev/null
 python3 bench.py --rec none $x > $O/bench_decoder_only.json 2>/dev/null
 python3 bench.py --lengths msvd $x > $O/bench_c2_msvd_lengths.json 2>/dev/null
@@ -49,6 +54,9 @@ RN_ROW_GROUPS=0 python3 bench.py --batch 200 $x > $O/bench_c2_B200_per_step_kern
 python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c4_weak_B256.json 2>/dev/null
 RN_ROW_GROUPS=0 python3 bench.py --rec local --batch 256 --frames 40 --feat 2048 $x > $O/bench_c4_weak_B256_per_step_kernels.json 2>/dev/null
 RN_ALT=loc_no_hybrid python3 bench.py $C5 $x > $O/bench_c5_per_step_forward.json 2>/dev/null
+# round 6: 28 x 3584 at 128 captions per GPU — the local chains in two row groups, and the per-step kernels
+python3 bench.py --rec local --batch 128 --frames 28 --feat 3584 $x > $O/bench_c5_B128.json 2>/dev/null
+RN_ALT=loc_no_hybrid RN_PER_STEP=loc_big python3 bench.py --rec local --batch 128 --frames 28 --feat 3584 $x > $O/bench_c5_B128_per_step_kernels.json 2>/dev/null
 # PCIe-inclusive rate (never `value`): every step takes a fresh host batch through feed.DeviceFeeder
 python3 bench.py --feed 1 $x > $O/bench_c2_host_feed.json 2>/dev/null
 python3 bench.py --defer 1 $x > $O/bench_c2_deferred_reconstructor_update.json 2>/dev/null
@@ -82,5 +90,5 @@ ls -la $O
 ./tools/micro/gemm_probe > $O/gemm_probe.txt 2>&1
 python3 tools/gemm_cold_probe.py > $O/gemm_cold_vs_hipblaslt.txt 2>&1
 python3 tools/between_steps_probe.py global > $O/between_steps_c2.txt 2>&1
-python3 tools/soak.py 5000 > $O/soak.json 2> $O/soak.err
+python3 tools/soak.py 3000 > $O/soak.json 2> $O/soak.err
 ls $O | wc -l
