@@ -80,7 +80,6 @@ __global__ void norm_finalize_kernel(const float* __restrict__ norms, int n, flo
 __global__ __launch_bounds__(256) void norm_all_kernel(const TensorDesc* __restrict__ tab, const float* __restrict__ partial, int ntens,
                                                        float* __restrict__ out_norm, float max_norm, float* total_out, float* clip_out,
                                                        float* sum_out) {
-  __shared__ float sm[4];
   __shared__ float nrm[16];
   __shared__ int cn[16], c0[16];
   // every thread's partial sums of all tensors first — their loads are independent and in flight together (tensor by tensor, each
@@ -95,14 +94,21 @@ __global__ __launch_bounds__(256) void norm_all_kernel(const TensorDesc* __restr
     for (int c = threadIdx.x; c < cn[i]; c += 256) s += partial[c0[i] + c];
     sp[i] = s;
   }
+  // the sixteen block sums with ONE barrier (round 6: block_sum256 per tensor was 32 barriers on the step's tail): every wave reduces its
+  // sixteen values, lane 0 stores them, thread i adds the four wave sums of tensor i in block_sum256's order — the same numbers, bit for bit
+  __shared__ float ws[4][16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    if (i < ntens) {      // (block-uniform)
-      const float s = block_sum256(sp[i], sm);
-      if (threadIdx.x == 0) { nrm[i] = sqrtf(s); out_norm[i] = nrm[i]; }
-      __syncthreads();
-    }
+    const float w = wave_sum(sp[i]);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6][i] = w;
   }
+  __syncthreads();
+  if ((int)threadIdx.x < ntens) {
+    const int i = threadIdx.x;
+    const float s = ws[0][i] + ws[1][i] + ws[2][i] + ws[3][i];
+    nrm[i] = sqrtf(s); out_norm[i] = nrm[i];
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
   float ss = 0.f, sn = 0.f;
   for (int i = 0; i < ntens; ++i) { ss += nrm[i] * nrm[i]; sn += nrm[i]; }

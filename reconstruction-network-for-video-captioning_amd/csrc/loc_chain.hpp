@@ -133,7 +133,7 @@ typedef _Float16 lc_h4 __attribute__((ext_vector_type(4)));
 // caption workgroups sum (NG <= 4 NQ).
 template <int STEPS, int PF, int RB, int SR = STEPS, int NQ = 32>
 __global__ __launch_bounds__(256) void loc_chain_kernel(const LocChainArgs p) {
-  constexpr int CG = 4, UW = 16, ROWS = RB * 16, RED_LD = CG * 16 + 1, NP = STEPS / 2, KG = UW / 8, SX = 4, NPR = SR / 2;
+  constexpr int CG = 4, UW = 16, ROWS = RB * 16, NP = STEPS / 2, KG = UW / 8, SX = 4, NPR = SR / 2;
   static_assert(SR % 2 == 0 && SR <= STEPS && SR >= 2 * PF, "resident k-steps: whole pairs, at least the prefetch distance");
   extern __shared__ __attribute__((aligned(16))) float lc_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -394,7 +394,6 @@ __global__ __launch_bounds__(256) void rec_chain_kernel(const RecChainArgs p) {
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int cell = RC_CELL(c);
-      const int row = cell < ROWS * UW ? cell / UW : 0, ul = cell % UW;
       float g4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) g4[q] = xg[c][q] + gsum[q][c];
